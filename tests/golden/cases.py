@@ -1,0 +1,76 @@
+"""Parity cases shared by make_golden.py (reference run, build container only) and the tests.
+
+Each case fixes a model geometry, a weight seed and a batch seed; weights and inputs are
+regenerated from the seeds (x2-vlm_amd/synthetic.py), so fixtures hold outputs only.
+Vision width/heads are fixed at 768/12 by the reference's beit_base_patch16 (beit2.py:439-446).
+"""
+
+CASES = {
+    # 2x2 patch grid (N=5), narrow text tower: every op of the path, seconds on CPU, full tensors kept
+    "tiny": dict(image_res=32, vision_layers=2, hidden=128, heads=2, ffn=256, vocab=512, max_pos=64,
+                 text_layers=4, fusion_at=2, embed_dim=32, batch=4, seq_len=8, max_masks=3,
+                 ragged=True, region=False, frames=0, wseed=11, bseed=12),
+    # same geometry, region/bbox path: idx_to_group_img, masked mean pooling, 5th fusion pass, GIoU
+    "tiny_region": dict(image_res=32, vision_layers=2, hidden=128, heads=2, ffn=256, vocab=512, max_pos=64,
+                        text_layers=4, fusion_at=2, embed_dim=32, batch=6, n_images=3, seq_len=8,
+                        max_masks=3, ragged=True, region=True, frames=0, wseed=13, bseed=14),
+    # video path: frames folded into the batch, frame position embedding, frame mean (xvlm.py:615-661)
+    "tiny_video": dict(image_res=32, vision_layers=1, hidden=128, heads=2, ffn=256, vocab=512, max_pos=64,
+                       text_layers=3, fusion_at=2, embed_dim=32, batch=3, seq_len=8, max_masks=3,
+                       ragged=True, region=False, frames=2, wseed=15, bseed=16),
+    # the real token geometry (N=197, L=30, d_h=64, 12 heads, V=30522) on a shallow stack
+    "base_shallow": dict(image_res=224, vision_layers=2, hidden=768, heads=12, ffn=3072, vocab=30522,
+                         max_pos=512, text_layers=3, fusion_at=2, embed_dim=256, batch=4, seq_len=30,
+                         max_masks=12, ragged=True, region=False, frames=0, wseed=21, bseed=22),
+    # full X2VLM-base (configs/pretrain/x2vlm_base_4m.yaml): 12 + 12 + 6 layers, 254.76 M params
+    "base_full": dict(image_res=224, vision_layers=12, hidden=768, heads=12, ffn=3072, vocab=30522,
+                      max_pos=512, text_layers=18, fusion_at=12, embed_dim=256, batch=4, seq_len=30,
+                      max_masks=12, ragged=False, region=False, frames=0, wseed=31, bseed=32),
+}
+
+
+def model_config(case, workdir):
+    """Write the two small JSON files the reference's builders read (xvlm.py:122-137, 245-249)
+    and return the config dict XVLM(config=...) takes."""
+    import json
+    import os
+    c = CASES[case]
+    os.makedirs(workdir, exist_ok=True)
+    vis = os.path.join(workdir, "config_beit2_base.json")
+    with open(vis, "w") as f:
+        json.dump({"ckpt": "", "vision_width": 768, "patch_size": 16}, f)
+    tdir = os.path.join(workdir, "bert-base-uncased-%s" % case)
+    os.makedirs(tdir, exist_ok=True)
+    with open(os.path.join(tdir, "config.json"), "w") as f:
+        json.dump(bert_config_dict(c), f)
+    cfg = dict(use_beit_v2=True, vision_config=vis, image_res=c["image_res"], patch_size=16,
+               vision_num_hidden_layers=c["vision_layers"], text_encoder=tdir,
+               text_num_hidden_layers=c["text_layers"], text_fusion_start_at=c["fusion_at"],
+               embed_dim=c["embed_dim"], temp=0.07, max_tokens=c["seq_len"], max_masks=c["max_masks"],
+               accelerator={"FP16_OPT_LEVEL": "O0"})
+    if c["frames"]:
+        cfg.update(video_encoding="avgpool", frame_len=c["frames"], add_frame_pos=True)
+    return cfg
+
+
+def bert_config_dict(c):
+    return dict(vocab_size=c["vocab"], hidden_size=c["hidden"], num_attention_heads=c["heads"],
+                intermediate_size=c["ffn"], max_position_embeddings=c["max_pos"], type_vocab_size=2,
+                hidden_act="gelu", hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1,
+                layer_norm_eps=1e-12, initializer_range=0.02, pad_token_id=0, model_type="bert")
+
+
+SMALL = 4096  # grads with at most this many elements are stored in full
+
+
+def reduce_out(t, full):
+    """What a fixture keeps of an activation tensor: everything (tiny cases) or a corner slice
+    plus three global moments (big cases).  Tests apply the same function to the tested path."""
+    import numpy as np
+    import torch
+    t = t.detach().to("cpu", torch.float64)
+    if full or t.numel() <= SMALL:
+        return {"full": t.numpy().astype(np.float32)}
+    sl = tuple(slice(0, min(s, 4 if i < t.dim() - 1 else 16)) for i, s in enumerate(t.shape))
+    return {"slice": t[sl].numpy().astype(np.float32),
+            "moments": np.array([t.sum().item(), t.abs().sum().item(), (t * t).sum().item()])}
