@@ -1,0 +1,321 @@
+"""GPU parity of every HIP kernel (through the C ABI) against the oracle's primitives on the same
+seeded inputs.  Inputs that the kernels take in bf16 are rounded to bf16 first, so the comparison
+isolates kernel arithmetic (fp32 accumulate) from input quantisation.
+
+Tolerances (relative to each tensor's max-abs): fp32-out kernels 1e-5; bf16-out kernels 6e-3 (one
+bf16 rounding of the output is 2^-9 = 3.9e-3 of the element, plus fp32 summation-order noise)."""
+import importlib
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import x2vlm_oracle as O
+
+pytestmark = pytest.mark.gpu
+dev = "cuda"
+
+
+@pytest.fixture(scope="module")
+def K():
+    return importlib.import_module("x2-vlm_amd.kernels")
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def bf(t):
+    return t.to(torch.bfloat16)
+
+
+def relerr(got, ref):
+    got = got.detach().float().cpu().double()
+    ref = ref.detach().double()
+    return float((got - ref).abs().max() / ref.abs().max().clamp_min(1e-12))
+
+
+@pytest.mark.parametrize("M,N,K_", [(256, 256, 128), (300, 200, 192), (788, 2304, 768), (12608, 768, 768), (100, 30528, 64)])
+def test_gemm_nt_plain_and_epilogues(K, M, N, K_):
+    A, B = bf(rnd(M, K_, seed=1)), bf(rnd(N, K_, seed=2, scale=K_ ** -0.5))
+    ref = A.float() @ B.float().t()
+    out = K.gemm_nt(A.to(dev), B.to(dev), out_dtype=torch.float32)
+    assert relerr(out, ref) < 1e-5
+    out = K.gemm_nt(A.to(dev), B.to(dev))
+    assert relerr(out, ref) < 6e-3
+    if N > 4096:
+        return
+    bias, gamma, resid = rnd(N, seed=3), rnd(N, seed=4), rnd(M, N, seed=5)
+    # bias + GELU, pre-activation saved
+    aux = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+    out = K.gemm_nt(A.to(dev), B.to(dev), bias=bias.to(dev), aux=aux, act=1, out_dtype=torch.float32)
+    assert relerr(out, O.gelu(ref + bias)) < 1e-5
+    assert relerr(aux, ref + bias) < 6e-3
+    # GELU' epilogue reads the saved pre-activation
+    pre = bf(rnd(M, N, seed=6))
+    out = K.gemm_nt(A.to(dev), B.to(dev), aux=pre.to(dev), act=2, out_dtype=torch.float32)
+    x = pre.float().requires_grad_(True)
+    O.gelu(x).sum().backward()
+    assert relerr(out, ref * x.grad) < 1e-5
+    # layer-scale + residual (aux receives acc + bias)
+    aux = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+    out = K.gemm_nt(A.to(dev), B.to(dev), bias=bias.to(dev), gamma=gamma.to(dev), resid=resid.to(dev), aux=aux,
+                    out_dtype=torch.float32)
+    assert relerr(out, resid + gamma * (ref + bias)) < 1e-5
+    assert relerr(aux, ref + bias) < 6e-3
+
+
+def test_gemm_nt_strided_views(K):
+    """operands / outputs that are column slices of wider buffers (fused QKV layouts)."""
+    M, Kd = 394, 128
+    wide = bf(rnd(M, 3 * Kd, seed=7)).to(dev)
+    B = bf(rnd(256, Kd, seed=8)).to(dev)
+    outw = torch.zeros(M, 512, device=dev, dtype=torch.bfloat16)
+    K.gemm_nt(wide[:, Kd:2 * Kd], B, out=outw[:, 256:])
+    ref = wide[:, Kd:2 * Kd].float().cpu() @ B.float().cpu().t()
+    assert relerr(outw[:, 256:], ref) < 6e-3
+    assert float(outw[:, :256].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("Mc,N,K_", [(128, 128, 128), (788, 768, 768), (1920, 256, 3072), (12608, 768, 2304), (100, 136, 72)])
+def test_gemm_tn_grouped(K, Mc, N, K_):
+    dY, X = bf(rnd(Mc, N, seed=1)), bf(rnd(Mc, K_, seed=2))
+    ref = dY.float().t() @ X.float()
+    dW = torch.full((N, K_), 7.0, device=dev)
+    K.gemm_tn_grouped([(dY.to(dev), X.to(dev), dW)])
+    assert relerr(dW, ref) < 1e-5
+    K.gemm_tn_grouped([(dY.to(dev), X.to(dev), dW)], accumulate=True)
+    assert relerr(dW, 2 * ref) < 1e-5
+    dW.zero_()
+    K.gemm_tn_grouped([(dY.to(dev), X.to(dev), dW)], accumulate=True, split=3)
+    assert relerr(dW, ref) < 1e-5
+
+
+def test_gemm_tn_group_of_problems_and_padded_rows(K):
+    probs, refs = [], []
+    for i, (Mc, N, K_) in enumerate([(500, 256, 128), (500, 128, 384), (700, 64, 64), (64, 8, 8)]):
+        dY, X = bf(rnd(Mc, N, seed=10 + i)), bf(rnd(Mc, K_, seed=20 + i))
+        probs.append((dY.to(dev), X.to(dev), torch.empty(N, K_, device=dev)))
+        refs.append(dY.float().t() @ X.float())
+    # readable row width larger than N (vocabulary padded to a multiple of 64: N=250 of ld=256)
+    dY, X = bf(rnd(300, 256, seed=31)), bf(rnd(300, 64, seed=32))
+    probs.append((dY.to(dev), X.to(dev), torch.empty(250, 64, device=dev), 256, 64))
+    refs.append(dY.float().t()[:250] @ X.float())
+    K.gemm_tn_grouped(probs)
+    for p, r in zip(probs, refs):
+        assert relerr(p[2], r) < 1e-5
+
+
+def attn_ref(q, k, v, scale, add):
+    """oracle attention on (B,H,L,d) fp32 leaves; returns out and grads for dout."""
+    return O.attention_core(q, k, v, scale, add)
+
+
+def run_attention(K, B, Bkv, H, Lq, Lk, use_bias, use_mask, kv_map, seed):
+    d = 64
+    qh = bf(rnd(B, Lq, H * d, seed=seed)); kh = bf(rnd(Bkv, Lk, H * d, seed=seed + 1)); vh = bf(rnd(Bkv, Lk, H * d, seed=seed + 2))
+    doh = bf(rnd(B, Lq, H * d, seed=seed + 3))
+    scale = d ** -0.5
+    bias = rnd(H, Lq, Lk, seed=seed + 4) if use_bias else None
+    mask = None
+    if use_mask:
+        keep = (torch.rand(B, Lk, generator=torch.Generator().manual_seed(seed + 5)) > 0.3).float()
+        keep[:, 0] = 1
+        mask = (1 - keep) * -10000.0
+    # ---- oracle (CPU fp32, autograd) ----
+    q = qh.float().view(B, Lq, H, d).permute(0, 2, 1, 3).requires_grad_(True)
+    k0 = kh.float().view(Bkv, Lk, H, d).permute(0, 2, 1, 3).requires_grad_(True)
+    v0 = vh.float().view(Bkv, Lk, H, d).permute(0, 2, 1, 3).requires_grad_(True)
+    idx = torch.tensor(kv_map) if kv_map is not None else torch.arange(B)
+    bias_leaf = bias.clone().requires_grad_(True) if use_bias else None
+    add = None
+    if use_bias:
+        add = bias_leaf.unsqueeze(0)
+    if use_mask:
+        add = mask[:, None, None, :] if add is None else add + mask[:, None, None, :]
+    out = attn_ref(q, k0[idx], v0[idx], scale, add)
+    out.backward(doh.float().view(B, Lq, H, d).permute(0, 2, 1, 3))
+    ref_out = out.permute(0, 2, 1, 3).reshape(B, Lq, H * d)
+    # ---- HIP ----
+    Lkp, Lqp = K.round_up(Lk, 64), K.round_up(Lq, 64)
+    kw = {}
+    if use_bias:
+        bp = torch.zeros(H, Lq, Lkp); bp[:, :, :Lk] = bias
+        bT = torch.zeros(H, Lk, Lqp); bT[:, :, :Lq] = bias.transpose(1, 2)
+        kw.update(bias=bp.to(dev), biasT=bT.to(dev))
+    if use_mask:
+        mp = torch.zeros(B, Lkp); mp[:, :Lk] = mask
+        kw["mask"] = mp.to(dev)
+    if kv_map is not None:
+        kv_idx = torch.tensor(kv_map, dtype=torch.int32)
+        order = torch.argsort(kv_idx, stable=True).to(torch.int32)
+        counts = torch.bincount(kv_idx, minlength=Bkv)
+        off = torch.zeros(Bkv + 1, dtype=torch.int32); off[1:] = torch.cumsum(counts, 0)
+        kw.update(kv_idx=kv_idx.to(dev), seq_off=off.to(dev), seq_ids=order.to(dev))
+    qd, kd, vd, dod = (t.reshape(-1, H * d).to(dev) for t in (qh, kh, vh, doh))
+    od = torch.empty_like(qd)
+    lse = torch.empty(B * H * Lq, device=dev); delta = torch.empty_like(lse)
+    K.attn_fwd(K.view3(qd, B, Lq), K.view3(kd, Bkv, Lk), K.view3(vd, Bkv, Lk), B, Bkv, H, Lq, Lk, scale,
+               K.view3(od, B, Lq), lse, **{k_: v_ for k_, v_ in kw.items() if k_ not in ("biasT", "seq_off", "seq_ids")})
+    assert relerr(od.view(B, Lq, H * d), ref_out) < 8e-3
+    dq, dk, dv = torch.empty_like(qd), torch.empty_like(kd), torch.empty_like(vd)
+    dS = torch.zeros(B, H, Lq, Lkp, device=dev, dtype=torch.bfloat16) if use_bias else None
+    K.attn_bwd(K.view3(qd, B, Lq), K.view3(kd, Bkv, Lk), K.view3(vd, Bkv, Lk), K.view3(od, B, Lq), K.view3(dod, B, Lq),
+               B, Bkv, H, Lq, Lk, scale, lse, delta, K.view3(dq, B, Lq), K.view3(dk, Bkv, Lk), K.view3(dv, Bkv, Lk),
+               dS=dS, **kw)
+    tol = 1.5e-2   # P and dS are rounded to bf16 before the second MFMA
+    assert relerr(dq.view(B, Lq, H * d), q.grad.permute(0, 2, 1, 3).reshape(B, Lq, H * d)) < tol
+    assert relerr(dk.view(Bkv, Lk, H * d), k0.grad.permute(0, 2, 1, 3).reshape(Bkv, Lk, H * d)) < tol
+    assert relerr(dv.view(Bkv, Lk, H * d), v0.grad.permute(0, 2, 1, 3).reshape(Bkv, Lk, H * d)) < tol
+    if use_bias:
+        assert relerr(dS[..., :Lk].float().sum(0), bias_leaf.grad) < tol
+
+
+def test_attention_vision_bias(K):
+    run_attention(K, B=3, Bkv=3, H=12, Lq=197, Lk=197, use_bias=True, use_mask=False, kv_map=None, seed=100)
+
+
+def test_attention_text_self_mask(K):
+    run_attention(K, B=5, Bkv=5, H=12, Lq=30, Lk=30, use_bias=False, use_mask=True, kv_map=None, seed=200)
+    run_attention(K, B=3, Bkv=3, H=2, Lq=8, Lk=8, use_bias=False, use_mask=True, kv_map=None, seed=210)
+    run_attention(K, B=2, Bkv=2, H=4, Lq=40, Lk=40, use_bias=False, use_mask=True, kv_map=None, seed=220)
+
+
+def test_attention_cross_shared_kv(K):
+    run_attention(K, B=6, Bkv=3, H=12, Lq=30, Lk=197, use_bias=False, use_mask=True, kv_map=[0, 2, 1, 1, 0, 1], seed=300)
+    run_attention(K, B=4, Bkv=2, H=2, Lq=8, Lk=5, use_bias=False, use_mask=False, kv_map=[1, 0, 1, 1], seed=310)
+
+
+def test_attention_long_keys(K):
+    """N = 577 (384 px) exercises many key tiles of the online softmax."""
+    run_attention(K, B=1, Bkv=1, H=2, Lq=577, Lk=577, use_bias=True, use_mask=False, kv_map=None, seed=400)
+
+
+@pytest.mark.parametrize("rows,D,period", [(37, 768, 0), (788, 768, 0), (4 * 196, 768, 196), (50, 128, 0), (9, 1536, 0)])
+def test_layernorm(K, rows, D, period):
+    total = rows if period == 0 else rows // period * (period + 1)
+    x = rnd(total, D, seed=1, scale=2.0) + 0.5
+    w, b = rnd(D, seed=2) * 0.1 + 1, rnd(D, seed=3) * 0.1
+    dy = rnd(total, D, seed=4)
+    sel = torch.arange(total) if period == 0 else torch.tensor([r + r // period + 1 for r in range(rows)])
+    xl = x.clone().requires_grad_(True); wl = w.clone().requires_grad_(True); bl = b.clone().requires_grad_(True)
+    ref = O.layer_norm(xl[sel], wl, bl, 1e-6)
+    ref.backward(dy[sel])
+    yb, yf, mean, rstd = K.layernorm_fwd(x.to(dev), w.to(dev), b.to(dev), 1e-6, rows=rows, period=period, want_f32=True)
+    assert relerr(yf[sel], ref) < 1e-5 and relerr(yb[sel], ref) < 6e-3
+    dw, db = torch.zeros(D, device=dev), torch.zeros(D, device=dev)
+    dres = rnd(total, D, seed=5)
+    dx, dxb = K.layernorm_bwd(dy.to(dev), x.to(dev), mean, rstd, w.to(dev), dw, db, dres=dres.to(dev), period=period,
+                              want_bf16=True)
+    assert relerr(dx[sel], xl.grad[sel] + dres[sel]) < 2e-5
+    assert relerr(dxb[sel], xl.grad[sel] + dres[sel]) < 6e-3
+    assert relerr(dw, wl.grad) < 2e-5 and relerr(db, bl.grad) < 2e-5
+
+
+def test_colsum_layerscale_casts(K):
+    y = bf(rnd(500, 768, seed=1))
+    out = torch.zeros(768, device=dev)
+    K.colsum_bf16(y.to(dev), out)
+    assert relerr(out, y.float().sum(0)) < 1e-5
+    dx, u, gamma = rnd(500, 768, seed=2), bf(rnd(500, 768, seed=3)), rnd(768, seed=4)
+    dg, dbias = torch.zeros(768, device=dev), torch.zeros(768, device=dev)
+    du = K.layerscale_bwd(dx.to(dev), u.to(dev), gamma.to(dev), dg, dbias)
+    assert relerr(du, dx * gamma) < 6e-3
+    assert relerr(dg, (dx * u.float()).sum(0)) < 1e-5 and relerr(dbias, (dx * gamma).sum(0)) < 1e-5
+    w = rnd(300, 200, seed=5)
+    assert torch.equal(K.cast_bf16(w.to(dev)).cpu(), bf(w))
+    plain, tr = K.cast_transpose_bf16(w.to(dev), ldt=320)
+    assert torch.equal(plain.cpu(), bf(w)) and torch.equal(tr[:, :300].cpu(), bf(w).t()) and float(tr[:, 300:].abs().max()) == 0
+
+
+def test_patch_tokens_pool_relpos(K):
+    cfg = O.OracleConfig(image_res=64, vision_layers=1)
+    img = rnd(3, 3, 64, 64, seed=1)
+    cols = K.patchify(img.to(dev), 16)
+    B, g, p = 3, 4, 16
+    ref = img.view(B, 3, g, p, g, p).permute(0, 2, 4, 1, 3, 5).reshape(B * g * g, 3 * p * p)
+    assert torch.equal(cols.cpu(), bf(ref))
+    patch, cls = rnd(B * 16, 768, seed=2), rnd(768, seed=3)
+    x = K.assemble_tokens(patch.to(dev), cls.to(dev), B, 16)
+    refx = torch.cat([cls.expand(B, 1, 768), patch.view(B, 16, 768)], 1)
+    assert torch.equal(x.cpu(), refx)
+    dcls = torch.zeros(768, device=dev)
+    dpatch = K.assemble_tokens_bwd(x, dcls)
+    assert torch.equal(dpatch.cpu(), bf(patch)) and relerr(dcls, cls * B) < 1e-6
+    w = torch.rand(B, 16, generator=torch.Generator().manual_seed(4)).round()
+    w[:, 0] = 1
+    for wt in (None, w):
+        xx = refx.clone().to(dev)
+        K.pool_tokens(xx, None if wt is None else wt.to(dev))
+        ww = torch.ones(B, 16) if wt is None else wt
+        pooled = (ww.unsqueeze(-1) * refx[:, 1:]).sum(1) / ww.sum(1, keepdim=True)
+        assert relerr(xx[:, 0], pooled) < 1e-6
+        gg = refx.clone().to(dev)
+        K.pool_tokens(gg, None if wt is None else wt.to(dev), bwd=True)
+        refg = refx[:, 1:] + (ww / ww.sum(1, keepdim=True)).unsqueeze(-1) * refx[:, :1]
+        assert relerr(gg[:, 1:], refg) < 1e-6 and float(gg[:, 0].abs().max()) == 0
+    idx = O.relative_position_index(4)
+    table = rnd(int(idx.max()) + 1, 12, seed=5)
+    bias, biasT = K.relpos_bias(table.to(dev), idx.to(dev))
+    refb = table[idx.reshape(-1)].view(17, 17, 12).permute(2, 0, 1)
+    assert torch.equal(bias[:, :, :17].cpu(), refb) and torch.equal(biasT[:, :, :17].cpu(), refb.transpose(1, 2))
+    dS = bf(rnd(2, 12, 17, 64, seed=6)); dS[..., 17:] = 0
+    dtab = torch.zeros_like(table).to(dev)
+    K.relpos_bias_bwd(dS.to(dev), idx.to(dev), dtab)
+    tl = table.clone().requires_grad_(True)
+    (tl[idx.reshape(-1)].view(17, 17, 12).permute(2, 0, 1) * dS[..., :17].float().sum(0)).sum().backward()
+    assert relerr(dtab, tl.grad) < 1e-5
+
+
+def test_embed_gather_linear_l2norm(K):
+    V, D, L, Bn = 100, 128, 8, 5
+    ids = torch.randint(0, V, (Bn, L), generator=torch.Generator().manual_seed(1))
+    word, pos, typ = rnd(V, D, seed=2), rnd(16, D, seed=3), rnd(2, D, seed=4)
+    out = K.embed_fwd(ids.to(dev), word.to(dev), pos.to(dev), typ.to(dev))
+    ref = word[ids] + pos[:L] + typ[0]
+    assert relerr(out.view(Bn, L, D), ref) < 1e-6
+    g = rnd(Bn * L, D, seed=5)
+    dword, dpos, dtyp = torch.zeros(V, D, device=dev), torch.zeros(16, D, device=dev), torch.zeros(2, D, device=dev)
+    K.embed_bwd(ids.to(dev), g.to(dev), dword, dpos, dtyp)
+    rw = torch.zeros(V, D).index_add_(0, ids.reshape(-1), g)
+    assert relerr(dword, rw) < 1e-5 and relerr(dpos[:L], g.view(Bn, L, D).sum(0)) < 1e-5 and relerr(dtyp[0], g.sum(0)) < 1e-5
+    src = rnd(6, 40, seed=6); idx = torch.tensor([3, 3, 0, 5], dtype=torch.int32)
+    d32, d16 = K.gather_rows(src.to(dev), idx.to(dev), 40, want_bf16=True)
+    assert torch.equal(d32.cpu(), src[idx.long()]) and torch.equal(d16.cpu(), bf(src[idx.long()]))
+    acc = torch.zeros(6, 40, device=dev)
+    K.scatter_add_rows(d32, idx.to(dev), acc, 40)
+    assert relerr(acc, torch.zeros(6, 40).index_add_(0, idx.long(), src[idx.long()])) < 1e-6
+    A, Bm, bias = rnd(70, 50, seed=7), rnd(30, 50, seed=8), rnd(30, seed=9)
+    assert relerr(K.linear_f32(A.to(dev), Bm.to(dev), bias=bias.to(dev)), A @ Bm.t() + bias) < 1e-5
+    assert relerr(K.linear_f32(A.t().contiguous().to(dev), Bm.t().contiguous().to(dev), transA=True, transB=True, alpha=0.5),
+                  0.5 * A @ Bm.t()) < 1e-5
+    x = rnd(9, 32, seed=10); dy = rnd(9, 32, seed=11)
+    xl = x.clone().requires_grad_(True)
+    y = torch.nn.functional.normalize(xl, dim=-1); y.backward(dy)
+    assert relerr(K.l2norm(x.to(dev)), y) < 1e-6 and relerr(K.l2norm(x.to(dev), dy.to(dev)), xl.grad) < 1e-5
+
+
+def test_cross_entropy_and_sampling(K):
+    R, Cv, ld = 20, 1000, 1024
+    z = rnd(R, ld, seed=1, scale=3.0)
+    lab = torch.randint(0, Cv, (R,), generator=torch.Generator().manual_seed(2)); lab[3] = -100; lab[7] = -100
+    zl = z[:, :Cv].clone().requires_grad_(True)
+    loss = O.cross_entropy(zl, lab); loss.backward()
+    stat, lse = K.ce_fwd(z.to(dev), lab.to(dev), C_valid=Cv)
+    assert abs(float(stat[0]) - float(loss)) < 1e-5 * float(loss) and float(stat[1]) == R - 2
+    g = torch.tensor([0.7], device=dev)
+    dl = K.ce_bwd(z.to(dev), lab.to(dev), lse, g, stat, C_valid=Cv)
+    assert relerr(dl[:, :Cv], 0.7 * zl.grad) < 1e-5 and float(dl[:, Cv:].abs().max()) == 0
+    n = 64
+    sim = rnd(n, n, seed=3, scale=2.0)
+    u = torch.rand(n, generator=torch.Generator().manual_seed(4))
+    pick = K.sample_negatives(sim.to(dev), u.to(dev)).cpu().long()
+    w = torch.softmax(sim, 1) + 1e-5; w.fill_diagonal_(0)
+    cdf = torch.cumsum(w.double(), 1)
+    refpick = (cdf > (u.double() * cdf[:, -1]).unsqueeze(1)).float().argmax(1)
+    assert (pick != torch.arange(n)).all() and (pick == refpick).float().mean() > 0.95
+    x = rnd(1000, seed=5); dy = rnd(1000, seed=6)
+    xl = x.clone().requires_grad_(True); O.gelu(xl).backward(dy)
+    assert relerr(K.gelu_f32(x.to(dev)), O.gelu(x)) < 1e-6 and relerr(K.gelu_f32(x.to(dev), dy.to(dev)), xl.grad) < 1e-5

@@ -1,0 +1,97 @@
+"""ctypes binding of libx2vlm_hip.so (C ABI declared in include/x2vlm_hip.h).
+
+The product path has no fallback: if the HIP library is missing or cannot be loaded this module
+raises, and every op of the package fails with it.  Build it with __graft_entry__.build() or
+x2-vlm_amd/csrc/build.sh (hipcc --offload-arch=gfx950).
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libx2vlm_hip.so")
+
+P, I, L, F = C.c_void_p, C.c_int, C.c_long, C.c_float
+
+
+class AttnArgs(C.Structure):
+    """Mirror of `struct AttnArgs` in csrc/attention.hip (same order, same types)."""
+    _fields_ = [(n, P) for n in ("Q", "K", "V", "O", "dO", "Out", "dQ", "dK", "dV", "dS", "LSE", "Delta")] + \
+               [(n, L) for n in ("q_bs", "q_rs", "k_bs", "k_rs", "v_bs", "v_rs", "o_bs", "o_rs",
+                                 "dq_bs", "dq_rs", "dk_bs", "dk_rs", "dv_bs", "dv_rs", "do_bs", "do_rs")] + \
+               [(n, I) for n in ("B", "Bkv", "H", "Lq", "Lk")] + [("scale", F)] + \
+               [("bias", P), ("bias_ld", I), ("biasT", P), ("biasT_ld", I), ("mask", P), ("mask_ld", I),
+                ("kv_idx", P), ("seq_off", P), ("seq_ids", P), ("ds_ld", I)]
+
+
+# name -> argtypes (all return int: 0 ok, < 0 error; message via x2_last_error)
+_SIGS = {
+    "x2_gemm_nt": [P, P, P, I, I, I, I, I, I, P, P, P, I, P, I, I, I, P],
+    "x2_gemm_tn_grouped": [P, I, I, I, P],
+    "x2_attn_fwd": [C.POINTER(AttnArgs), P],
+    "x2_attn_bwd": [C.POINTER(AttnArgs), P],
+    "x2_layernorm_fwd": [P, P, P, P, P, P, P, I, I, F, I, P],
+    "x2_layernorm_bwd": [P, P, P, P, P, P, P, P, P, P, I, I, I, P],
+    "x2_colsum_bf16": [P, P, I, I, I, P],
+    "x2_layerscale_bwd": [P, P, P, P, P, P, I, I, P],
+    "x2_cast_bf16": [P, P, L, P],
+    "x2_cast_transpose_bf16": [P, P, P, I, I, I, P],
+    "x2_patchify": [P, P, I, I, I, P],
+    "x2_assemble_tokens": [P, P, P, I, I, I, P],
+    "x2_assemble_tokens_bwd": [P, P, P, I, I, I, P],
+    "x2_pool_tokens": [P, P, I, I, I, I, P],
+    "x2_relpos_bias": [P, P, P, P, I, I, I, I, P],
+    "x2_relpos_bias_bwd": [P, P, P, I, I, I, I, P],
+    "x2_embed_fwd": [P, P, P, P, P, I, I, I, P],
+    "x2_embed_bwd": [P, P, P, P, P, I, I, I, P],
+    "x2_gather_rows": [P, P, P, P, I, L, P],
+    "x2_scatter_add_rows": [P, P, P, I, L, P],
+    "x2_linear_f32": [P, P, P, P, P, F, I, I, I, L, L, L, L, L, I, P],
+    "x2_l2norm": [P, P, P, I, I, I, P],
+    "x2_ce_fwd": [P, L, P, I, I, P, P, P, P],
+    "x2_ce_bwd": [P, L, P, P, P, P, F, I, I, P, P, L, P],
+    "x2_sample_negatives": [P, I, P, P, P, P],
+    "x2_gelu_f32": [P, P, P, L, P],
+    "x2_colsum_f32": [P, P, I, I, P],
+}
+EXPORTS = sorted(list(_SIGS) + ["x2_last_error", "x2_abi_version", "x2_device_cus"])
+
+_lib = None
+
+
+class X2HipError(RuntimeError):
+    pass
+
+
+def lib():
+    """The loaded library; raises X2HipError (never falls back) when it is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise X2HipError("HIP extension %s not built: run `python -c 'import __graft_entry__ as g; g.build()'`"
+                             % LIB_PATH)
+        try:
+            h = C.CDLL(LIB_PATH)
+        except OSError as e:  # pragma: no cover
+            raise X2HipError("cannot load %s: %s" % (LIB_PATH, e))
+        for name, sig in _SIGS.items():
+            fn = getattr(h, name)
+            fn.argtypes, fn.restype = sig, I
+        h.x2_last_error.restype = C.c_char_p
+        h.x2_abi_version.restype = I
+        h.x2_device_cus.restype = I
+        _lib = h
+    return _lib
+
+
+def call(name, *args):
+    """Invoke an entry point on torch's current HIP stream; raise on a non-zero return."""
+    h = lib()
+    rc = getattr(h, name)(*args, torch.cuda.current_stream().cuda_stream)
+    if rc != 0:
+        raise X2HipError("%s failed (%d): %s" % (name, rc, h.x2_last_error().decode()))
+
+
+def ptr(t):
+    return None if t is None else t.data_ptr()

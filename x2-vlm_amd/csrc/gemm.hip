@@ -1,0 +1,316 @@
+// bf16 MFMA GEMMs for gfx950 (MI355X): the dense contractions of the X^2-VLM step.
+//
+//   x2_gemm_nt : C[M,N] = epilogue(A[M,K] . B[N,K]^T)      forward linears and dgrads (on W^T copies)
+//   x2_gemm_tn : C[N,K] (+)= A[Mc,N]^T . B[Mc,K]           weight gradients, grouped (one launch / layer)
+//
+// Both: 128x128 output tile per 256-thread workgroup (4 waves, 2x2, 64x64 each = 4x4 MFMA
+// 16x16x32 bf16 tiles), contraction step 64, operands streamed HBM -> LDS with 16-byte
+// global_load_lds (no VGPR round trip), double-buffered with one barrier per step, XOR-swizzled
+// LDS images (swizzle applied on the per-lane SOURCE address, LDS image stays lane-linear),
+// XCD-aware tile order.  The TN kernel reads its fragments with ds_read_b64_tr_b16, so neither
+// activations nor gradients are ever transposed in HBM.
+//
+// Replaces (reference, all implicit ATen/cuBLAS calls): F.linear in beit2.py:131,160,62,66 and
+// xbert.py:338-350,428,497,512,798,822 and their autograd backward.
+#include "x2_common.h"
+
+#define BM 128
+#define BN 128
+#define BK 64
+#define TILE_BYTES (128 * 128)          // one operand tile: 128 rows x 64 bf16 (NT) or 64 rows x 128 bf16 (TN)
+#define STAGE_BYTES (2 * TILE_BYTES)
+#define GEMM_LDS_BYTES (2 * STAGE_BYTES)
+
+struct GemmNT {
+  const bf16_t* A; const bf16_t* B; void* C;
+  const float* bias; const float* gamma; const float* resid; bf16_t* aux;
+  int M, N, K;
+  int lda, ldb, ldc, ldr, ldaux;
+  int act;      // 0 none | 1 GELU (aux <- pre-activation) | 2 multiply by GELU'(aux)
+  int out_f32;  // C is float (1) or bf16 (0)
+};
+
+// ---------------------------------------------------------------------------------------------
+// NT: both operands K-contiguous.  LDS image per operand: [128 rows][8 chunks of 16 B], chunk c of
+// row r stored at chunk position c ^ (r & 7)  -> conflict-free ds_read_b128 fragment reads.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNT p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tiles_n = (p.N + BN - 1) / BN;
+  const int nwg = gridDim.x;
+  const int t = xcd_remap(blockIdx.x, nwg);
+  const int m0 = (t / tiles_n) * BM, n0 = (t % tiles_n) * BN;
+
+  // per-thread global sources for the 4+4 chunks this thread stages per K-step
+  const bf16_t* srcA[4]; const bf16_t* srcB[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int q = i * 256 + tid, row = q >> 3, c = (q & 7) ^ (row & 7);
+    int ra = m0 + row; ra = ra < p.M ? ra : p.M - 1;
+    int rb = n0 + row; rb = rb < p.N ? rb : p.N - 1;
+    srcA[i] = p.A + (size_t)ra * p.lda + c * 8;
+    srcB[i] = p.B + (size_t)rb * p.ldb + c * 8;
+  }
+  auto stage = [&](int kt, int buf) {
+    char* base = smem + buf * STAGE_BYTES;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      glds16(srcA[i] + (size_t)kt * BK, base + (i * 256 + wave * 64) * 16);
+      glds16(srcB[i] + (size_t)kt * BK, base + TILE_BYTES + (i * 256 + wave * 64) * 16);
+    }
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const uint32_t lds0 = lds_addr(smem);
+  const int frow = lane & 15, fg = lane >> 4, fsw = lane & 7;
+  const uint32_t offA = (uint32_t)((wm * 64 + frow) * 128);
+  const uint32_t offB = (uint32_t)(TILE_BYTES + (wn * 64 + frow) * 128);
+
+  const int nk = p.K / BK;
+  stage(0, 0);
+  for (int kt = 0; kt < nk; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
+    const uint32_t sb = lds0 + (kt & 1) * STAGE_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const uint32_t cs = (uint32_t)(((ks * 4 + fg) ^ fsw) << 4);
+      bf16x8 a[4], b[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = lds_read_b128(sb + offA + i * 2048 + cs);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b[j] = lds_read_b128(sb + offB + j * 2048 + cs);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          // operands swapped: accumulator tile = C^T, i.e. lane holds (m = frow, 4 consecutive n)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+    }
+  }
+
+  // ---- epilogue: bias / GELU / GELU' / layer-scale + residual, 8- or 16-byte stores ----
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + wm * 64 + i * 16 + frow;
+    if (m >= p.M) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + wn * 64 + j * 16 + fg * 4;
+      if (n >= p.N) continue;
+      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+      if (p.bias) {
+        const float4 bb = *reinterpret_cast<const float4*>(p.bias + n);
+        v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
+      }
+      if (p.act == 1) {
+        *reinterpret_cast<u32x2*>(p.aux + (size_t)m * p.ldaux + n) = u32x2{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = gelu_f(v[r]);
+      } else if (p.act == 2) {
+        const u32x2 pre = *reinterpret_cast<const u32x2*>(p.aux + (size_t)m * p.ldaux + n);
+        v[0] *= dgelu_f(bf_lo(pre[0])); v[1] *= dgelu_f(bf_hi(pre[0]));
+        v[2] *= dgelu_f(bf_lo(pre[1])); v[3] *= dgelu_f(bf_hi(pre[1]));
+      } else if (p.aux) {
+        *reinterpret_cast<u32x2*>(p.aux + (size_t)m * p.ldaux + n) = u32x2{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])};
+      }
+      if (p.gamma) {
+        const float4 g = *reinterpret_cast<const float4*>(p.gamma + n);
+        v[0] *= g.x; v[1] *= g.y; v[2] *= g.z; v[3] *= g.w;
+      }
+      if (p.resid) {
+        const float4 rr = *reinterpret_cast<const float4*>(p.resid + (size_t)m * p.ldr + n);
+        v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w;
+      }
+      if (p.out_f32)
+        *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n) = float4{v[0], v[1], v[2], v[3]};
+      else
+        *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(p.C) + (size_t)m * p.ldc + n) =
+            u32x2{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])};
+    }
+  }
+}
+
+extern "C" int x2_gemm_nt(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
+                          const float* bias, const float* gamma, const float* resid, int ldr, void* aux, int ldaux,
+                          int act, int out_f32, void* stream) {
+  X2_REQUIRE(M > 0 && N > 0 && K > 0, "x2_gemm_nt: empty problem M=%d N=%d K=%d", M, N, K);
+  X2_REQUIRE(K % BK == 0, "x2_gemm_nt: K=%d must be a multiple of %d", K, BK);
+  X2_REQUIRE(N % 4 == 0, "x2_gemm_nt: N=%d must be a multiple of 4", N);
+  X2_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && ldc % 4 == 0, "x2_gemm_nt: leading dims must keep 16-byte rows");
+  X2_REQUIRE(act == 0 || aux, "x2_gemm_nt: act=%d needs aux", act);
+  X2_REQUIRE((!resid || ldr % 4 == 0) && (!aux || ldaux % 4 == 0), "x2_gemm_nt: ldr/ldaux alignment");
+  GemmNT p{(const bf16_t*)A, (const bf16_t*)B, C, bias, gamma, resid, (bf16_t*)aux, M, N, K, lda, ldb, ldc, ldr, ldaux, act, out_f32};
+  const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+  hipLaunchKernelGGL(gemm_nt_kernel, dim3(tiles), dim3(256), GEMM_LDS_BYTES, (hipStream_t)stream, p);
+  return x2_check_launch("x2_gemm_nt");
+}
+
+// ---------------------------------------------------------------------------------------------
+// TN (weight gradients): C[n][k] (+)= sum_m A[m][n] * B[m][k].  Operand tiles are [64 m][128 cols]
+// (row-major as they sit in HBM, 256-byte rows), 16 chunks of 16 B per row, chunk c of row r at
+// position c ^ (f(r) << 1), f(r) = (r & 3) | ((r >> 3 & 1) << 2)  -> conflict-free transposing reads.
+// Grouped: up to 8 problems per launch (all weight gradients of one layer), optional split over
+// the contraction (gridDim.y) with fp32 atomics when the layer has too few tiles to fill 256 CUs.
+// ---------------------------------------------------------------------------------------------
+struct TNProblem {
+  const bf16_t* A; const bf16_t* B; float* C;
+  int Mc, N, K;           // contraction length, output rows, output cols
+  int lda, ldb, ldc;
+  int n_ld, k_ld;         // readable columns of A / B rows (>= N / K, multiple of 8)
+  int tile_begin, tiles_k;
+};
+struct GemmTNGroup { TNProblem p[8]; int count; int accumulate; };
+
+__device__ __forceinline__ int tn_f(int r) { return (r & 3) | (((r >> 3) & 1) << 2); }
+
+__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmTNGroup g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wn = wave >> 1, wk = wave & 1;
+  int t = xcd_remap(blockIdx.x, gridDim.x);
+  int pi = 0;
+#pragma unroll
+  for (int i = 1; i < 8; ++i) if (i < g.count && t >= g.p[i].tile_begin) pi = i;
+  const TNProblem p = g.p[pi];
+  t -= p.tile_begin;
+  const int n0 = (t / p.tiles_k) * 128, k0 = (t % p.tiles_k) * 128;
+  const int steps = (p.Mc + BK - 1) / BK;
+  const int per = (steps + gridDim.y - 1) / gridDim.y;
+  const int s_begin = blockIdx.y * per, s_end = min(steps, s_begin + per);
+  if (s_begin >= s_end) return;
+
+  const bf16_t* srcA[4]; const bf16_t* srcB[4]; int rowq[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int q = i * 256 + tid, row = q >> 4, c = (q & 15) ^ (tn_f(row) << 1);
+    int ca = n0 + c * 8; ca = ca <= p.n_ld - 8 ? ca : p.n_ld - 8;
+    int cb = k0 + c * 8; cb = cb <= p.k_ld - 8 ? cb : p.k_ld - 8;
+    rowq[i] = row;
+    srcA[i] = p.A + (size_t)row * p.lda + ca;
+    srcB[i] = p.B + (size_t)row * p.ldb + cb;
+  }
+  auto stage = [&](int s, int buf) {
+    char* base = smem + buf * STAGE_BYTES;
+    const int mbase = s * BK;
+    if (mbase + BK <= p.Mc) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        glds16(srcA[i] + (size_t)mbase * p.lda, base + (i * 256 + wave * 64) * 16);
+        glds16(srcB[i] + (size_t)mbase * p.ldb, base + TILE_BYTES + (i * 256 + wave * 64) * 16);
+      }
+    } else {  // ragged last step: rows past Mc contribute zeros
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        u32x4 va = u32x4{0, 0, 0, 0}, vb = u32x4{0, 0, 0, 0};
+        if (mbase + rowq[i] < p.Mc) {
+          va = *reinterpret_cast<const u32x4*>(srcA[i] + (size_t)mbase * p.lda);
+          vb = *reinterpret_cast<const u32x4*>(srcB[i] + (size_t)mbase * p.ldb);
+        }
+        *reinterpret_cast<u32x4*>(base + (i * 256 + tid) * 16) = va;
+        *reinterpret_cast<u32x4*>(base + TILE_BYTES + (i * 256 + tid) * 16) = vb;
+      }
+    }
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const uint32_t lds0 = lds_addr(smem);
+  const int fi = lane & 15, fg = lane >> 4, fr = fi >> 2, fc4 = fi & 3;
+  const int fsw = (fr | ((fg & 1) << 2)) << 1;                 // f(R) << 1 for every row this lane addresses
+  // byte offset of this lane's address inside a tile for MFMA k-step ks, second half adds 4 rows
+  const uint32_t rowoff = (uint32_t)((fg * 8 + fr) * 256 + (fc4 & 1) * 8);
+
+  stage(s_begin, 0);
+  for (int s = s_begin; s < s_end; ++s) {
+    const int it = s - s_begin;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (s + 1 < s_end) stage(s + 1, (it + 1) & 1);
+    const uint32_t sb = lds0 + (it & 1) * STAGE_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 xa[4], ya[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {   // B operand tile (activations X): output k index
+        const uint32_t ch = (uint32_t)(((2 * (wk * 4 + i) + (fc4 >> 1)) ^ fsw) << 4);
+        const uint32_t a0 = sb + TILE_BYTES + ks * 32 * 256 + rowoff + ch;
+        xa[i] = lds_read_tr_frag(a0, a0 + 4 * 256);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {   // A operand tile (output grads dY): output n index
+        const uint32_t ch = (uint32_t)(((2 * (wn * 4 + j) + (fc4 >> 1)) ^ fsw) << 4);
+        const uint32_t a0 = sb + ks * 32 * 256 + rowoff + ch;
+        ya[j] = lds_read_tr_frag(a0, a0 + 4 * 256);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          // D[row = k][col = n]: lane holds n = fi and 4 consecutive k -> 16-byte stores along K
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa[i], ya[j], acc[i][j], 0, 0, 0);
+    }
+  }
+
+  const bool atomic = gridDim.y > 1;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int n = n0 + wn * 64 + j * 16 + fi;
+    if (n >= p.N) continue;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int k = k0 + wk * 64 + i * 16 + fg * 4;
+      if (k >= p.K) continue;
+      float* dst = p.C + (size_t)n * p.ldc + k;
+      if (atomic) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) atomicAdd(dst + r, acc[i][j][r]);
+      } else if (g.accumulate) {
+        float4 o = *reinterpret_cast<float4*>(dst);
+        o.x += acc[i][j][0]; o.y += acc[i][j][1]; o.z += acc[i][j][2]; o.w += acc[i][j][3];
+        *reinterpret_cast<float4*>(dst) = o;
+      } else {
+        *reinterpret_cast<float4*>(dst) = float4{acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+      }
+    }
+  }
+}
+
+// problems: `count` rows of 11 int64: {A, B, C, Mc, N, K, lda, ldb, ldc, n_ld, k_ld}
+extern "C" int x2_gemm_tn_grouped(const int64_t* problems, int count, int accumulate, int split, void* stream) {
+  X2_REQUIRE(count >= 1 && count <= 8, "x2_gemm_tn_grouped: count=%d not in [1,8]", count);
+  X2_REQUIRE(split >= 1, "x2_gemm_tn_grouped: split=%d", split);
+  X2_REQUIRE(split == 1 || accumulate, "x2_gemm_tn_grouped: split>1 adds atomically: pass accumulate=1 and a defined C");
+  GemmTNGroup g; g.count = count; g.accumulate = accumulate;
+  int tiles = 0;
+  for (int i = 0; i < count; ++i) {
+    const int64_t* q = problems + i * 11;
+    TNProblem& p = g.p[i];
+    p.A = (const bf16_t*)q[0]; p.B = (const bf16_t*)q[1]; p.C = (float*)q[2];
+    p.Mc = (int)q[3]; p.N = (int)q[4]; p.K = (int)q[5]; p.lda = (int)q[6]; p.ldb = (int)q[7]; p.ldc = (int)q[8];
+    p.n_ld = (int)q[9]; p.k_ld = (int)q[10];
+    X2_REQUIRE(p.Mc > 0 && p.N > 0 && p.K > 0, "x2_gemm_tn_grouped[%d]: empty problem", i);
+    X2_REQUIRE(p.K % 4 == 0 && p.ldc % 4 == 0, "x2_gemm_tn_grouped[%d]: K, ldc must be multiples of 4", i);
+    X2_REQUIRE(p.lda % 8 == 0 && p.ldb % 8 == 0 && p.n_ld % 8 == 0 && p.k_ld % 8 == 0 && p.n_ld >= 8 && p.k_ld >= 8,
+               "x2_gemm_tn_grouped[%d]: rows must be 16-byte granular", i);
+    X2_REQUIRE(p.n_ld <= p.lda && p.k_ld <= p.ldb, "x2_gemm_tn_grouped[%d]: n_ld/k_ld exceed leading dims", i);
+    p.tile_begin = tiles; p.tiles_k = (p.K + 127) / 128;
+    tiles += ((p.N + 127) / 128) * p.tiles_k;
+  }
+  hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles, split), dim3(256), GEMM_LDS_BYTES, (hipStream_t)stream, g);
+  return x2_check_launch("x2_gemm_tn_grouped");
+}

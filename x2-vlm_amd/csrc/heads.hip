@@ -1,0 +1,285 @@
+// Embedding, gather/scatter, small fp32 linear, L2-normalise, softmax cross-entropy and
+// hard-negative sampling kernels of the X^2-VLM step (gfx950).  These are the latency/HBM-bound
+// ends of the path: BertEmbeddings (xbert.py:189-216), masked-position gather (xbert.py:1588-1589),
+// projection heads + F.normalize (xvlm.py:785-792), ITC / ITM / MLM cross-entropies
+// (xvlm.py:794-826, 895-899, xbert.py:1660-1661), torch.multinomial hard negatives (xvlm.py:828-857).
+#include "x2_common.h"
+
+// ------------------------------------------------------------------------------------ embeddings
+// out[r][:] = word[ids[r]][:] + pos[r % L][:] + type0[:]      (fp32; the LayerNorm that follows is separate)
+__global__ __launch_bounds__(256) void embed_fwd_kernel(const long* __restrict__ ids, const float* __restrict__ word,
+                                                        const float* __restrict__ pos, const float* __restrict__ type0,
+                                                        float* __restrict__ out, int R, int L, int D) {
+  const int r = blockIdx.x;
+  const long id = ids[r];
+  const int l = r % L;
+  for (int d = threadIdx.x * 4; d < D; d += 1024) {
+    const float4 a = *reinterpret_cast<const float4*>(word + id * D + d), b = *reinterpret_cast<const float4*>(pos + (long)l * D + d),
+                 c = *reinterpret_cast<const float4*>(type0 + d);
+    *reinterpret_cast<float4*>(out + (long)r * D + d) = float4{a.x + b.x + c.x, a.y + b.y + c.y, a.z + b.z + c.z, a.w + b.w + c.w};
+  }
+}
+extern "C" int x2_embed_fwd(const long* ids, const float* word, const float* pos, const float* type0, float* out, int R, int L, int D,
+                            void* stream) {
+  X2_REQUIRE(R > 0 && L > 0 && D % 4 == 0, "x2_embed_fwd: R=%d L=%d D=%d", R, L, D);
+  hipLaunchKernelGGL(embed_fwd_kernel, dim3(R), dim3(256), 0, (hipStream_t)stream, ids, word, pos, type0, out, R, L, D);
+  return x2_check_launch("x2_embed_fwd");
+}
+// dword[ids[r]] += g[r] ; dpos[r % L] += g[r] ; dtype0 += g[r].  Block = 32 rows; type-0 partials kept in registers.
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const long* __restrict__ ids, const float* __restrict__ g, float* dword,
+                                                        float* dpos, float* dtype0, int R, int L, int D) {
+  const int r0 = blockIdx.x * 32, r1 = min(R, r0 + 32);
+  for (int d = threadIdx.x * 4; d < D; d += 1024) {
+    float4 t{0.f, 0.f, 0.f, 0.f};
+    for (int r = r0; r < r1; ++r) {
+      const float4 v = *reinterpret_cast<const float4*>(g + (long)r * D + d);
+      float* w = dword + ids[r] * D + d; float* p = dpos + (long)(r % L) * D + d;
+      atomicAdd(w, v.x); atomicAdd(w + 1, v.y); atomicAdd(w + 2, v.z); atomicAdd(w + 3, v.w);
+      atomicAdd(p, v.x); atomicAdd(p + 1, v.y); atomicAdd(p + 2, v.z); atomicAdd(p + 3, v.w);
+      t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+    }
+    atomicAdd(dtype0 + d, t.x); atomicAdd(dtype0 + d + 1, t.y); atomicAdd(dtype0 + d + 2, t.z); atomicAdd(dtype0 + d + 3, t.w);
+  }
+}
+extern "C" int x2_embed_bwd(const long* ids, const float* g, float* dword, float* dpos, float* dtype0, int R, int L, int D, void* stream) {
+  X2_REQUIRE(R > 0 && L > 0 && D % 4 == 0, "x2_embed_bwd: R=%d L=%d D=%d", R, L, D);
+  hipLaunchKernelGGL(embed_bwd_kernel, dim3((R + 31) / 32), dim3(256), 0, (hipStream_t)stream, ids, g, dword, dpos, dtype0, R, L, D);
+  return x2_check_launch("x2_embed_bwd");
+}
+
+// ------------------------------------------------------------------------------------ row gather / scatter-add
+// dst[r][:] = src[idx[r]][:]  (rows of `len` floats, len % 4 == 0); optional bf16 copy.
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ src, const int* __restrict__ idx, float* dst,
+                                                          bf16_t* dstb, long len) {
+  const long r = blockIdx.y;
+  const float* s = src + (long)idx[r] * len;
+  for (long e = (blockIdx.x * 256L + threadIdx.x) * 4; e < len; e += (long)gridDim.x * 1024) {
+    const float4 v = *reinterpret_cast<const float4*>(s + e);
+    if (dst) *reinterpret_cast<float4*>(dst + r * len + e) = v;
+    if (dstb) *reinterpret_cast<u32x2*>(dstb + r * len + e) = u32x2{pack_bf16(v.x, v.y), pack_bf16(v.z, v.w)};
+  }
+}
+extern "C" int x2_gather_rows(const float* src, const int* idx, float* dst, void* dst_bf16, int R, long len, void* stream) {
+  X2_REQUIRE(R > 0 && len > 0 && len % 4 == 0, "x2_gather_rows: R=%d len=%ld", R, len);
+  const int bx = (int)((len / 4 + 255) / 256 < 64 ? (len / 4 + 255) / 256 : 64);
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(bx, R), dim3(256), 0, (hipStream_t)stream, src, idx, dst, (bf16_t*)dst_bf16, len);
+  return x2_check_launch("x2_gather_rows");
+}
+// dst[idx[r]][:] += src[r][:]
+__global__ __launch_bounds__(256) void scatter_add_rows_kernel(const float* __restrict__ src, const int* __restrict__ idx, float* dst,
+                                                               long len) {
+  const long r = blockIdx.y;
+  float* d = dst + (long)idx[r] * len;
+  for (long e = (blockIdx.x * 256L + threadIdx.x) * 4; e < len; e += (long)gridDim.x * 1024) {
+    const float4 v = *reinterpret_cast<const float4*>(src + r * len + e);
+    atomicAdd(d + e, v.x); atomicAdd(d + e + 1, v.y); atomicAdd(d + e + 2, v.z); atomicAdd(d + e + 3, v.w);
+  }
+}
+extern "C" int x2_scatter_add_rows(const float* src, const int* idx, float* dst, int R, long len, void* stream) {
+  X2_REQUIRE(R > 0 && len > 0 && len % 4 == 0, "x2_scatter_add_rows: R=%d len=%ld", R, len);
+  const int bx = (int)((len / 4 + 255) / 256 < 64 ? (len / 4 + 255) / 256 : 64);
+  hipLaunchKernelGGL(scatter_add_rows_kernel, dim3(bx, R), dim3(256), 0, (hipStream_t)stream, src, idx, dst, len);
+  return x2_check_launch("x2_scatter_add_rows");
+}
+
+// ------------------------------------------------------------------------------------ small fp32 linear
+// C[m][n] (+)= alpha * sum_k A[m*sam + k*sak] * B[n*sbn + k*sbk] (+ bias[n]); alpha read from device if alpha_ptr.
+// 64x64 tile, 256 threads x (4x4) outputs, K step 16 through LDS.  For the heads (M <= a few hundred).
+__global__ __launch_bounds__(256) void linear_f32_kernel(const float* __restrict__ A, const float* __restrict__ B, float* C,
+                                                         const float* __restrict__ bias, const float* alpha_ptr, float alpha, int M, int N,
+                                                         int K, long sam, long sak, long sbn, long sbk, long ldc, int accumulate) {
+  __shared__ float As[16][65], Bs[16][65];
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+  float acc[4][4] = {};
+  for (int k0 = 0; k0 < K; k0 += 16) {
+    for (int e = threadIdx.x; e < 1024; e += 256) {
+      const int kk = e & 15, rr = e >> 4;
+      const int m = m0 + rr, n = n0 + rr, k = k0 + kk;
+      As[kk][rr] = (m < M && k < K) ? A[m * sam + k * sak] : 0.f;
+      Bs[kk][rr] = (n < N && k < K) ? B[n * sbn + k * sbk] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+      float a[4], b[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { a[i] = As[kk][ty * 4 + i]; b[i] = Bs[kk][tx * 4 + i]; }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] += a[i] * b[j];
+    }
+    __syncthreads();
+  }
+  const float al = alpha_ptr ? alpha * alpha_ptr[0] : alpha;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int m = m0 + ty * 4 + i, n = n0 + tx * 4 + j;
+      if (m < M && n < N) {
+        float v = al * acc[i][j] + (bias ? bias[n] : 0.f);
+        if (accumulate) v += C[m * ldc + n];
+        C[m * ldc + n] = v;
+      }
+    }
+}
+extern "C" int x2_linear_f32(const float* A, const float* B, float* C, const float* bias, const float* alpha_ptr, float alpha, int M,
+                             int N, int K, long sam, long sak, long sbn, long sbk, long ldc, int accumulate, void* stream) {
+  X2_REQUIRE(M > 0 && N > 0 && K > 0, "x2_linear_f32: M=%d N=%d K=%d", M, N, K);
+  hipLaunchKernelGGL(linear_f32_kernel, dim3((N + 63) / 64, (M + 63) / 64), dim3(256), 0, (hipStream_t)stream, A, B, C, bias, alpha_ptr,
+                     alpha, M, N, K, sam, sak, sbn, sbk, ldc, accumulate);
+  return x2_check_launch("x2_linear_f32");
+}
+
+// ------------------------------------------------------------------------------------ L2 normalise rows
+// y = x / max(||x||, 1e-12) ; bwd: dx = (dy - y * <dy, y>) / max(||x||, eps).  One wave per row.
+__global__ __launch_bounds__(256) void l2norm_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* out, int R, int D,
+                                                     int bwd) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= R) return;
+  float ss = 0.f, dot = 0.f;
+  for (int d = lane; d < D; d += 64) { const float v = x[(long)row * D + d]; ss += v * v; if (bwd) dot += v * dy[(long)row * D + d]; }
+  ss = wave_sum(ss);
+  const float nrm = fmaxf(sqrtf(ss), 1e-12f), inv = 1.f / nrm;
+  if (!bwd) { for (int d = lane; d < D; d += 64) out[(long)row * D + d] = x[(long)row * D + d] * inv; return; }
+  dot = wave_sum(dot) * inv * inv;   // <dy, y> / ||x||
+  for (int d = lane; d < D; d += 64) out[(long)row * D + d] = dy[(long)row * D + d] * inv - x[(long)row * D + d] * dot * inv;
+}
+extern "C" int x2_l2norm(const float* x, const float* dy, float* out, int R, int D, int bwd, void* stream) {
+  X2_REQUIRE(R > 0 && D > 0 && (!bwd || dy), "x2_l2norm: R=%d D=%d", R, D);
+  hipLaunchKernelGGL(l2norm_kernel, dim3((R + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, dy, out, R, D, bwd);
+  return x2_check_launch("x2_l2norm");
+}
+
+// ------------------------------------------------------------------------------------ softmax cross-entropy
+// One workgroup per row.  fwd: lse[r], loss_row[r] = lse - logit[label] (0 and not counted when label == ignore).
+__device__ __forceinline__ float block_reduce(float v, float* sh, bool is_max) {
+  v = is_max ? wave_max(v) : wave_sum(v);
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  __syncthreads();
+  if (l == 0) sh[w] = v;
+  __syncthreads();
+  float r = sh[0];
+  for (int i = 1; i < (int)(blockDim.x >> 6); ++i) r = is_max ? fmaxf(r, sh[i]) : r + sh[i];
+  return r;
+}
+__global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ logits, long ld, const long* __restrict__ labels, int C,
+                                                     float* lse, float* loss_row) {
+  __shared__ float sh[8];
+  const int r = blockIdx.x;
+  const float* z = logits + (long)r * ld;
+  float mx = -INFINITY;
+  for (int c = threadIdx.x; c < C; c += 256) mx = fmaxf(mx, z[c]);
+  mx = block_reduce(mx, sh, true);
+  float s = 0.f;
+  for (int c = threadIdx.x; c < C; c += 256) s += __expf(z[c] - mx);
+  s = block_reduce(s, sh, false);
+  if (threadIdx.x == 0) {
+    const float l = mx + logf(s);
+    const long lab = labels[r];
+    lse[r] = l;
+    loss_row[r] = lab >= 0 ? l - z[lab] : 0.f;
+  }
+}
+// loss = sum(loss_row) / count(label >= 0); out[0] = loss, out[1] = count
+__global__ __launch_bounds__(256) void ce_reduce_kernel(const float* __restrict__ loss_row, const long* __restrict__ labels, int R, float* out) {
+  __shared__ float sh[8];
+  float s = 0.f, n = 0.f;
+  for (int r = threadIdx.x; r < R; r += 256) { s += loss_row[r]; n += labels[r] >= 0 ? 1.f : 0.f; }
+  s = block_reduce(s, sh, false);
+  n = block_reduce(n, sh, false);
+  if (threadIdx.x == 0) { out[0] = s / n; out[1] = n; }
+}
+// dlogits[r][c] = (exp(z - lse) - [c == label]) * gscale * g[0] / count ; rows with ignored label -> 0 ; pad columns C..ldd-1 -> 0
+__global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ logits, long ld, const long* __restrict__ labels,
+                                                     const float* __restrict__ lse, const float* __restrict__ g, const float* __restrict__ stat,
+                                                     float gscale, int C, float* dlf, bf16_t* dlb, long ldd) {
+  const int r = blockIdx.x;
+  const long lab = labels[r];
+  const float sc = lab >= 0 ? gscale * g[0] / stat[1] : 0.f;
+  const float l = lse[r];
+  const float* z = logits + (long)r * ld;
+  for (int c = threadIdx.x; c < ldd; c += 256) {
+    float v = 0.f;
+    if (c < C && lab >= 0) v = (__expf(z[c] - l) - (c == lab ? 1.f : 0.f)) * sc;
+    if (dlf) dlf[(long)r * ldd + c] = v;
+    if (dlb) dlb[(long)r * ldd + c] = f2bf(v);
+  }
+}
+extern "C" int x2_ce_fwd(const float* logits, long ld, const long* labels, int R, int C, float* lse, float* loss_row, float* out2,
+                         void* stream) {
+  X2_REQUIRE(R > 0 && C > 0 && ld >= C, "x2_ce_fwd: R=%d C=%d ld=%ld", R, C, ld);
+  hipLaunchKernelGGL(ce_fwd_kernel, dim3(R), dim3(256), 0, (hipStream_t)stream, logits, ld, labels, C, lse, loss_row);
+  hipLaunchKernelGGL(ce_reduce_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, loss_row, labels, R, out2);
+  return x2_check_launch("x2_ce_fwd");
+}
+extern "C" int x2_ce_bwd(const float* logits, long ld, const long* labels, const float* lse, const float* g, const float* stat,
+                         float gscale, int R, int C, float* dl_f32, void* dl_bf16, long ldd, void* stream) {
+  X2_REQUIRE(R > 0 && C > 0 && ldd >= C && (dl_f32 || dl_bf16), "x2_ce_bwd: R=%d C=%d ldd=%ld", R, C, ldd);
+  hipLaunchKernelGGL(ce_bwd_kernel, dim3(R), dim3(256), 0, (hipStream_t)stream, logits, ld, labels, lse, g, stat, gscale, C, dl_f32,
+                     (bf16_t*)dl_bf16, ldd);
+  return x2_check_launch("x2_ce_bwd");
+}
+
+// ------------------------------------------------------------------------------------ hard negatives
+// Row b: w[j] = softmax_j(sim[b][j]) + 1e-5, w[b] = 0 (or w[j] = 0 where group[j] == group[b]); draw one j
+// with the uniform u[b] in [0,1) by inverse CDF.  One workgroup (<= 1024 columns) per row; no host sync.
+__global__ __launch_bounds__(256) void sample_negatives_kernel(const float* __restrict__ sim, int n, const long* __restrict__ group,
+                                                               const float* __restrict__ u, int* out) {
+  __shared__ float sh[8];
+  __shared__ float w[1024];
+  const int b = blockIdx.x;
+  const float* z = sim + (long)b * n;
+  float mx = -INFINITY;
+  for (int c = threadIdx.x; c < n; c += 256) mx = fmaxf(mx, z[c]);
+  mx = block_reduce(mx, sh, true);
+  float s = 0.f;
+  for (int c = threadIdx.x; c < n; c += 256) s += __expf(z[c] - mx);
+  s = block_reduce(s, sh, false);
+  for (int c = threadIdx.x; c < n; c += 256) {
+    const bool same = group ? group[c] == group[b] : c == b;
+    w[c] = same ? 0.f : __expf(z[c] - mx) / s + 1e-5f;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float tot = 0.f;
+    for (int c = 0; c < n; ++c) tot += w[c];
+    const float t = u[b] * tot;
+    float cum = 0.f; int pick = -1;
+    for (int c = 0; c < n; ++c) { cum += w[c]; if (w[c] > 0.f && cum > t) { pick = c; break; } }
+    if (pick < 0) for (int c = n - 1; c >= 0; --c) if (w[c] > 0.f) { pick = c; break; }
+    out[b] = pick;
+  }
+}
+extern "C" int x2_sample_negatives(const float* sim, int n, const long* group, const float* u, int* out, void* stream) {
+  X2_REQUIRE(n > 1 && n <= 1024, "x2_sample_negatives: n=%d not in (1,1024]", n);
+  hipLaunchKernelGGL(sample_negatives_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, sim, n, group, u, out);
+  return x2_check_launch("x2_sample_negatives");
+}
+
+// ------------------------------------------------------------------------------------ elementwise
+// y = gelu(x) (fp32, exact erf) and its backward dx = dy * gelu'(x); used by the two small MLP heads
+__global__ __launch_bounds__(256) void gelu_f32_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* out, long n) {
+  const long i = blockIdx.x * 256L + threadIdx.x;
+  if (i < n) out[i] = dy ? dy[i] * dgelu_f(x[i]) : gelu_f(x[i]);
+}
+extern "C" int x2_gelu_f32(const float* x, const float* dy, float* out, long n, void* stream) {
+  X2_REQUIRE(n > 0, "x2_gelu_f32: n=%ld", n);
+  hipLaunchKernelGGL(gelu_f32_kernel, dim3((int)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, dy, out, n);
+  return x2_check_launch("x2_gelu_f32");
+}
+// out[n] += sum_m x[m][n]  (fp32 column sums: small-head bias gradients)
+__global__ __launch_bounds__(256) void colsum_f32_kernel(const float* __restrict__ x, float* out, int M, int N) {
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= N) return;
+  float s = 0.f;
+  for (int m = 0; m < M; ++m) s += x[(long)m * N + n];
+  out[n] += s;
+}
+extern "C" int x2_colsum_f32(const float* x, float* out, int M, int N, void* stream) {
+  X2_REQUIRE(M > 0 && N > 0, "x2_colsum_f32: M=%d N=%d", M, N);
+  hipLaunchKernelGGL(colsum_f32_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, out, M, N);
+  return x2_check_launch("x2_colsum_f32");
+}

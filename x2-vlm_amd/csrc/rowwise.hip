@@ -1,0 +1,371 @@
+// HBM-bound row-wise kernels of the X^2-VLM step (gfx950): LayerNorm fwd/bwd, layer-scale
+// backward, column sums (bias gradients), dtype casts / weight transposes, patch extraction and
+// token assembly, mean pooling.  One wave per row where rows are reduced (wavefront shuffle
+// reductions, fp32 statistics), 16-byte accesses throughout.
+//
+// Reference sites: nn.LayerNorm in beit2.py:175,181,411 (eps 1e-6), xbert.py:214,422,506,796
+// (eps 1e-12), xvlm.py:166 (eps 1e-5); gamma_1/gamma_2 layer scale beit2.py:206-207;
+// PatchEmbed beit2.py:225-232; cls-token concat beit2.py:385-387; mean pooling beit2.py:409-416.
+#include "x2_common.h"
+
+// row r of a (B, period+1, D) token tensor with token 0 skipped  (period == 0: plain rows)
+__device__ __forceinline__ long remap_row(int r, int period) { return period > 0 ? (long)r + r / period + 1 : r; }
+
+// ---------------------------------------------------------------------------------- LayerNorm fwd
+// x fp32 [rows][D] -> y_bf16 / y_f32 (either may be null), mean/rstd saved for the backward.
+#define LN_MAXV 8   // float4 per lane: D <= 2048
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                            const float* __restrict__ bsh, bf16_t* yb, float* yf,
+                                                            float* mean, float* rstd, int rows, int D, float eps, int period) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const long gr = remap_row(row, period);
+  const float* xr = x + gr * D;
+  float4 v[LN_MAXV];
+  float s = 0.f;
+  const int nv = D >> 2;
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const int c = lane + i * 64;
+    if (c < nv) { v[i] = *reinterpret_cast<const float4*>(xr + c * 4); s += v[i].x + v[i].y + v[i].z + v[i].w; }
+  }
+  const float mu = wave_sum(s) / D;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const int c = lane + i * 64;
+    if (c < nv) { const float a = v[i].x - mu, b = v[i].y - mu, cc = v[i].z - mu, d = v[i].w - mu; q += a * a + b * b + cc * cc + d * d; }
+  }
+  const float rs = rsqrtf(wave_sum(q) / D + eps);
+  if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const int c = lane + i * 64;
+    if (c < nv) {
+      const float4 ww = *reinterpret_cast<const float4*>(w + c * 4), bb = *reinterpret_cast<const float4*>(bsh + c * 4);
+      const float4 o{(v[i].x - mu) * rs * ww.x + bb.x, (v[i].y - mu) * rs * ww.y + bb.y, (v[i].z - mu) * rs * ww.z + bb.z, (v[i].w - mu) * rs * ww.w + bb.w};
+      if (yf) *reinterpret_cast<float4*>(yf + gr * D + c * 4) = o;
+      if (yb) *reinterpret_cast<u32x2*>(yb + gr * D + c * 4) = u32x2{pack_bf16(o.x, o.y), pack_bf16(o.z, o.w)};
+    }
+  }
+}
+
+extern "C" int x2_layernorm_fwd(const float* x, const float* w, const float* b, void* y_bf16, float* y_f32, float* mean,
+                                float* rstd, int rows, int D, float eps, int period, void* stream) {
+  X2_REQUIRE(rows > 0 && D > 0 && D % 4 == 0 && D <= 256 * LN_MAXV, "x2_layernorm_fwd: rows=%d D=%d (D%%4==0, D<=2048)", rows, D);
+  hipLaunchKernelGGL(layernorm_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, w, b, (bf16_t*)y_bf16,
+                     y_f32, mean, rstd, rows, D, eps, period);
+  return x2_check_launch("x2_layernorm_fwd");
+}
+
+// ---------------------------------------------------------------------------------- LayerNorm bwd
+// dx = dres + rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * w ; dw += sum dy*xhat ; db += sum dy.
+// Each wave walks `rows_per_wave` rows keeping its dw/db partials in registers, then one atomic per column.
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                            const float* __restrict__ w, const float* dres, float* dx, bf16_t* dxb,
+                                                            float* dw, float* db, int rows, int D, int period, int rows_per_wave) {
+  const int lane = threadIdx.x & 63, wv = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int nv = D >> 2;
+  float4 ww[LN_MAXV], aw[LN_MAXV], ab[LN_MAXV];
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const int c = lane + i * 64;
+    ww[i] = c < nv ? *reinterpret_cast<const float4*>(w + c * 4) : float4{0.f, 0.f, 0.f, 0.f};
+    aw[i] = float4{0.f, 0.f, 0.f, 0.f}; ab[i] = float4{0.f, 0.f, 0.f, 0.f};
+  }
+  const int r0 = wv * rows_per_wave, r1 = min(rows, r0 + rows_per_wave);
+  for (int row = r0; row < r1; ++row) {
+    const long gr = remap_row(row, period);
+    const float mu = mean[row], rs = rstd[row];
+    float4 g[LN_MAXV], xh[LN_MAXV];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+      const int c = lane + i * 64;
+      if (c < nv) {
+        const float4 d = *reinterpret_cast<const float4*>(dy + gr * D + c * 4), xv = *reinterpret_cast<const float4*>(x + gr * D + c * 4);
+        xh[i] = float4{(xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs};
+        g[i] = float4{d.x * ww[i].x, d.y * ww[i].y, d.z * ww[i].z, d.w * ww[i].w};
+        s1 += g[i].x + g[i].y + g[i].z + g[i].w;
+        s2 += g[i].x * xh[i].x + g[i].y * xh[i].y + g[i].z * xh[i].z + g[i].w * xh[i].w;
+        aw[i].x += d.x * xh[i].x; aw[i].y += d.y * xh[i].y; aw[i].z += d.z * xh[i].z; aw[i].w += d.w * xh[i].w;
+        ab[i].x += d.x; ab[i].y += d.y; ab[i].z += d.z; ab[i].w += d.w;
+      }
+    }
+    const float m1 = wave_sum(s1) / D, m2 = wave_sum(s2) / D;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+      const int c = lane + i * 64;
+      if (c < nv) {
+        float4 o{rs * (g[i].x - m1 - xh[i].x * m2), rs * (g[i].y - m1 - xh[i].y * m2), rs * (g[i].z - m1 - xh[i].z * m2), rs * (g[i].w - m1 - xh[i].w * m2)};
+        if (dres) { const float4 rr = *reinterpret_cast<const float4*>(dres + gr * D + c * 4); o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w; }
+        if (dx) *reinterpret_cast<float4*>(dx + gr * D + c * 4) = o;
+        if (dxb) *reinterpret_cast<u32x2*>(dxb + gr * D + c * 4) = u32x2{pack_bf16(o.x, o.y), pack_bf16(o.z, o.w)};
+      }
+    }
+  }
+  if (r0 < r1) {
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+      const int c = lane + i * 64;
+      if (c < nv) {
+        atomicAdd(dw + c * 4 + 0, aw[i].x); atomicAdd(dw + c * 4 + 1, aw[i].y); atomicAdd(dw + c * 4 + 2, aw[i].z); atomicAdd(dw + c * 4 + 3, aw[i].w);
+        atomicAdd(db + c * 4 + 0, ab[i].x); atomicAdd(db + c * 4 + 1, ab[i].y); atomicAdd(db + c * 4 + 2, ab[i].z); atomicAdd(db + c * 4 + 3, ab[i].w);
+      }
+    }
+  }
+}
+
+extern "C" int x2_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* w,
+                                const float* dres, float* dx, void* dx_bf16, float* dw, float* db, int rows, int D, int period,
+                                void* stream) {
+  X2_REQUIRE(rows > 0 && D > 0 && D % 4 == 0 && D <= 256 * LN_MAXV, "x2_layernorm_bwd: rows=%d D=%d", rows, D);
+  X2_REQUIRE(dw && db, "x2_layernorm_bwd: dw/db (accumulated with atomics) required");
+  const int rpw = rows >= 16384 ? 8 : (rows >= 2048 ? 4 : 1);
+  const int waves = (rows + rpw - 1) / rpw;
+  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((waves + 3) / 4), dim3(256), 0, (hipStream_t)stream, dy, x, mean, rstd, w, dres, dx,
+                     (bf16_t*)dx_bf16, dw, db, rows, D, period, rpw);
+  return x2_check_launch("x2_layernorm_bwd");
+}
+
+// ---------------------------------------------------------------------------------- column sums
+// out[n] += sum_m Y[m][n]  (bias gradients).  Block = 256 threads = 8 columns each, walks ROWS rows.
+#define CS_ROWS 32
+__global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16_t* __restrict__ y, float* out, int M, int N, int ld) {
+  const int c0 = (blockIdx.y * 256 + threadIdx.x) * 8;
+  if (c0 >= N) return;
+  const int r0 = blockIdx.x * CS_ROWS, r1 = min(M, r0 + CS_ROWS);
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int r = r0; r < r1; ++r) {
+    const u32x4 v = *reinterpret_cast<const u32x4*>(y + (long)r * ld + c0);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { acc[2 * e] += bf_lo(v[e]); acc[2 * e + 1] += bf_hi(v[e]); }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) if (c0 + e < N) atomicAdd(out + c0 + e, acc[e]);
+}
+extern "C" int x2_colsum_bf16(const void* y, float* out, int M, int N, int ld, void* stream) {
+  X2_REQUIRE(M > 0 && N > 0 && N % 8 == 0 && ld % 8 == 0, "x2_colsum_bf16: M=%d N=%d ld=%d (N, ld multiples of 8)", M, N, ld);
+  hipLaunchKernelGGL(colsum_bf16_kernel, dim3((M + CS_ROWS - 1) / CS_ROWS, (N + 2047) / 2048), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)y, out, M, N, ld);
+  return x2_check_launch("x2_colsum_bf16");
+}
+
+// ---------------------------------------------------------------------------------- layer-scale backward
+// forward was  x_out = x_in + gamma * u  (u = aux, bf16).  Given dX (fp32):  dU = gamma * dX (bf16),
+// dgamma[n] += sum_m dX*u,  dbias[n] += sum_m dU.   Thread = 4 columns, block walks CS_ROWS rows.
+__global__ __launch_bounds__(256) void layerscale_bwd_kernel(const float* __restrict__ dx, const bf16_t* __restrict__ u,
+                                                             const float* __restrict__ gamma, bf16_t* du, float* dgamma,
+                                                             float* dbias, int M, int D) {
+  const int c0 = (blockIdx.y * 256 + threadIdx.x) * 4;
+  if (c0 >= D) return;
+  const int r0 = blockIdx.x * CS_ROWS, r1 = min(M, r0 + CS_ROWS);
+  const float4 gm = *reinterpret_cast<const float4*>(gamma + c0);
+  float ag[4] = {0.f, 0.f, 0.f, 0.f}, ab[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int r = r0; r < r1; ++r) {
+    const float4 d = *reinterpret_cast<const float4*>(dx + (long)r * D + c0);
+    const u32x2 uu = *reinterpret_cast<const u32x2*>(u + (long)r * D + c0);
+    const float o0 = d.x * gm.x, o1 = d.y * gm.y, o2 = d.z * gm.z, o3 = d.w * gm.w;
+    *reinterpret_cast<u32x2*>(du + (long)r * D + c0) = u32x2{pack_bf16(o0, o1), pack_bf16(o2, o3)};
+    ag[0] += d.x * bf_lo(uu[0]); ag[1] += d.y * bf_hi(uu[0]); ag[2] += d.z * bf_lo(uu[1]); ag[3] += d.w * bf_hi(uu[1]);
+    ab[0] += o0; ab[1] += o1; ab[2] += o2; ab[3] += o3;
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { atomicAdd(dgamma + c0 + e, ag[e]); atomicAdd(dbias + c0 + e, ab[e]); }
+}
+extern "C" int x2_layerscale_bwd(const float* dx, const void* u, const float* gamma, void* du, float* dgamma, float* dbias, int M,
+                                 int D, void* stream) {
+  X2_REQUIRE(M > 0 && D > 0 && D % 4 == 0, "x2_layerscale_bwd: M=%d D=%d", M, D);
+  hipLaunchKernelGGL(layerscale_bwd_kernel, dim3((M + CS_ROWS - 1) / CS_ROWS, (D + 1023) / 1024), dim3(256), 0, (hipStream_t)stream, dx,
+                     (const bf16_t*)u, gamma, (bf16_t*)du, dgamma, dbias, M, D);
+  return x2_check_launch("x2_layerscale_bwd");
+}
+
+// ---------------------------------------------------------------------------------- casts
+__global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ s, bf16_t* __restrict__ d, long n4) {
+  long i = blockIdx.x * 256L + threadIdx.x;
+  const long st = (long)gridDim.x * 256;
+  for (; i < n4; i += st) {
+    const float4 v = *reinterpret_cast<const float4*>(s + i * 4);
+    *reinterpret_cast<u32x2*>(d + i * 4) = u32x2{pack_bf16(v.x, v.y), pack_bf16(v.z, v.w)};
+  }
+}
+extern "C" int x2_cast_bf16(const float* src, void* dst, long n, void* stream) {
+  X2_REQUIRE(n > 0 && n % 4 == 0, "x2_cast_bf16: n=%ld must be a positive multiple of 4", n);
+  const long n4 = n / 4;
+  const int blocks = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
+  hipLaunchKernelGGL(cast_bf16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, n4);
+  return x2_check_launch("x2_cast_bf16");
+}
+
+// fp32 [R][C] -> bf16 [R][C] (optional) and bf16 transposed [C][ldt] (ldt >= R; columns R..ldt-1 left untouched).
+// 64x64 tiles through LDS (padded), coalesced on both sides.
+__global__ __launch_bounds__(256) void cast_transpose_kernel(const float* __restrict__ s, bf16_t* d, bf16_t* dT, int R, int C, int ldt) {
+  __shared__ float tile[64][65];
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int i = ty; i < 64; i += 4) {
+    const int r = r0 + i, c = c0 + tx;
+    float v = 0.f;
+    if (r < R && c < C) { v = s[(long)r * C + c]; if (d) d[(long)r * C + c] = f2bf(v); }
+    tile[i][tx] = v;
+  }
+  __syncthreads();
+  for (int i = ty; i < 64; i += 4) {
+    const int c = c0 + i, r = r0 + tx;
+    if (c < C && r < R) dT[(long)c * ldt + r] = f2bf(tile[tx][i]);
+  }
+}
+extern "C" int x2_cast_transpose_bf16(const float* src, void* dst, void* dstT, int R, int C, int ldt, void* stream) {
+  X2_REQUIRE(R > 0 && C > 0 && ldt >= R && dstT, "x2_cast_transpose_bf16: R=%d C=%d ldt=%d", R, C, ldt);
+  hipLaunchKernelGGL(cast_transpose_kernel, dim3((C + 63) / 64, (R + 63) / 64), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst,
+                     (bf16_t*)dstT, R, C, ldt);
+  return x2_check_launch("x2_cast_transpose_bf16");
+}
+
+// ---------------------------------------------------------------------------------- patches / tokens
+// image fp32 (B,3,R,R) -> patch rows bf16 [B*g*g][3*ps*ps], column = c*ps*ps + py*ps + px (Conv2d weight order)
+__global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ img, bf16_t* __restrict__ cols, int B, int R, int ps) {
+  const int g = R / ps, kk = 3 * ps * ps;
+  const long total = (long)B * g * g * kk / 4;
+  long i = blockIdx.x * 256L + threadIdx.x;
+  const long st = (long)gridDim.x * 256;
+  for (; i < total; i += st) {
+    const long e = i * 4;
+    const int col = (int)(e % kk);
+    const long prow = e / kk;
+    const int px = col % ps, py = (col / ps) % ps, c = col / (ps * ps);
+    const int pxg = (int)(prow % g), pyg = (int)((prow / g) % g), b = (int)(prow / ((long)g * g));
+    const float4 v = *reinterpret_cast<const float4*>(img + (((long)b * 3 + c) * R + pyg * ps + py) * R + pxg * ps + px);
+    *reinterpret_cast<u32x2*>(cols + e) = u32x2{pack_bf16(v.x, v.y), pack_bf16(v.z, v.w)};
+  }
+}
+extern "C" int x2_patchify(const float* image, void* cols, int B, int R, int ps, void* stream) {
+  X2_REQUIRE(B > 0 && R > 0 && ps > 0 && R % ps == 0 && ps % 4 == 0, "x2_patchify: B=%d R=%d ps=%d", B, R, ps);
+  const long total = (long)B * (R / ps) * (R / ps) * 3 * ps * ps / 4;
+  const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  hipLaunchKernelGGL(patchify_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, image, (bf16_t*)cols, B, R, ps);
+  return x2_check_launch("x2_patchify");
+}
+
+// x[b][0][:] = cls ; x[b][1+p][:] = patch[b*P+p][:]            (fp32, D % 4 == 0)
+__global__ __launch_bounds__(256) void assemble_tokens_kernel(const float* __restrict__ patch, const float* __restrict__ cls,
+                                                              float* __restrict__ x, int B, int P, int D) {
+  const long total = (long)B * (P + 1) * D / 4;
+  long i = blockIdx.x * 256L + threadIdx.x;
+  const long st = (long)gridDim.x * 256;
+  for (; i < total; i += st) {
+    const long e = i * 4;
+    const int d = (int)(e % D);
+    const long row = e / D;
+    const int tkn = (int)(row % (P + 1)), b = (int)(row / (P + 1));
+    const float4 v = tkn == 0 ? *reinterpret_cast<const float4*>(cls + d)
+                              : *reinterpret_cast<const float4*>(patch + ((long)b * P + tkn - 1) * D + d);
+    *reinterpret_cast<float4*>(x + e) = v;
+  }
+}
+extern "C" int x2_assemble_tokens(const float* patch, const float* cls, float* x, int B, int P, int D, void* stream) {
+  X2_REQUIRE(B > 0 && P > 0 && D % 4 == 0, "x2_assemble_tokens: B=%d P=%d D=%d", B, P, D);
+  const long total = (long)B * (P + 1) * D / 4;
+  const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  hipLaunchKernelGGL(assemble_tokens_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, patch, cls, x, B, P, D);
+  return x2_check_launch("x2_assemble_tokens");
+}
+
+// backward of assemble: dpatch_bf16[b*P+p][:] = dx[b][1+p][:] ; dcls[:] += sum_b dx[b][0][:]
+__global__ __launch_bounds__(256) void assemble_tokens_bwd_kernel(const float* __restrict__ dx, bf16_t* __restrict__ dpatch,
+                                                                  float* dcls, int B, int P, int D) {
+  const long total = (long)B * (P + 1) * D / 4;
+  long i = blockIdx.x * 256L + threadIdx.x;
+  const long st = (long)gridDim.x * 256;
+  for (; i < total; i += st) {
+    const long e = i * 4;
+    const int d = (int)(e % D);
+    const long row = e / D;
+    const int tkn = (int)(row % (P + 1)), b = (int)(row / (P + 1));
+    const float4 v = *reinterpret_cast<const float4*>(dx + e);
+    if (tkn == 0) { atomicAdd(dcls + d, v.x); atomicAdd(dcls + d + 1, v.y); atomicAdd(dcls + d + 2, v.z); atomicAdd(dcls + d + 3, v.w); }
+    else *reinterpret_cast<u32x2*>(dpatch + ((long)b * P + tkn - 1) * D + d) = u32x2{pack_bf16(v.x, v.y), pack_bf16(v.z, v.w)};
+  }
+}
+extern "C" int x2_assemble_tokens_bwd(const float* dx, void* dpatch, float* dcls, int B, int P, int D, void* stream) {
+  X2_REQUIRE(B > 0 && P > 0 && D % 4 == 0, "x2_assemble_tokens_bwd: B=%d P=%d D=%d", B, P, D);
+  const long total = (long)B * (P + 1) * D / 4;
+  const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  hipLaunchKernelGGL(assemble_tokens_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dx, (bf16_t*)dpatch, dcls, B, P, D);
+  return x2_check_launch("x2_assemble_tokens_bwd");
+}
+
+// token 0 of every sample <- (weighted) mean of its patch tokens.  w: [B][P] weights or null (plain mean).
+// fwd: x[b][0][:] = sum_p w[b][p] x[b][1+p][:] / sum_p w[b][p]
+// bwd (add=1): g[b][1+p][:] += w[b][p] / sum_p w * g[b][0][:]  (token-0 row of g is then zeroed)
+__global__ __launch_bounds__(256) void pool_tokens_kernel(float* x, const float* __restrict__ w, int B, int P, int D, int bwd) {
+  const int b = blockIdx.x, d = (blockIdx.y * 256 + threadIdx.x) * 4;
+  if (d >= D) return;
+  float* xb = x + (long)b * (P + 1) * D;
+  float wsum = (float)P;
+  if (w) { wsum = 0.f; for (int p = 0; p < P; ++p) wsum += w[(long)b * P + p]; }
+  if (!bwd) {
+    float4 acc{0.f, 0.f, 0.f, 0.f};
+    for (int p = 0; p < P; ++p) {
+      const float wp = w ? w[(long)b * P + p] : 1.f;
+      const float4 v = *reinterpret_cast<const float4*>(xb + (long)(1 + p) * D + d);
+      acc.x += wp * v.x; acc.y += wp * v.y; acc.z += wp * v.z; acc.w += wp * v.w;
+    }
+    const float inv = 1.f / wsum;
+    *reinterpret_cast<float4*>(xb + d) = float4{acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv};
+  } else {
+    const float4 g0 = *reinterpret_cast<const float4*>(xb + d);
+    const float inv = 1.f / wsum;
+    for (int p = 0; p < P; ++p) {
+      const float wp = (w ? w[(long)b * P + p] : 1.f) * inv;
+      float4 v = *reinterpret_cast<float4*>(xb + (long)(1 + p) * D + d);
+      v.x += wp * g0.x; v.y += wp * g0.y; v.z += wp * g0.z; v.w += wp * g0.w;
+      *reinterpret_cast<float4*>(xb + (long)(1 + p) * D + d) = v;
+    }
+    *reinterpret_cast<float4*>(xb + d) = float4{0.f, 0.f, 0.f, 0.f};
+  }
+}
+extern "C" int x2_pool_tokens(float* x, const float* w, int B, int P, int D, int bwd, void* stream) {
+  X2_REQUIRE(B > 0 && P > 0 && D % 4 == 0, "x2_pool_tokens: B=%d P=%d D=%d", B, P, D);
+  hipLaunchKernelGGL(pool_tokens_kernel, dim3(B, (D + 1023) / 1024), dim3(256), 0, (hipStream_t)stream, x, w, B, P, D, bwd);
+  return x2_check_launch("x2_pool_tokens");
+}
+
+// ---------------------------------------------------------------------------------- rel-pos bias
+// bias[h][i][j] = table[index[i][j]][h] for i,j < N (padded [H][N][ld]); biasT[h][j][i] likewise [H][N][ldT].
+__global__ __launch_bounds__(256) void relpos_bias_kernel(const float* __restrict__ table, const long* __restrict__ index,
+                                                          float* bias, float* biasT, int N, int H, int ld, int ldT) {
+  const long total = (long)N * N;
+  long e = blockIdx.x * 256L + threadIdx.x;
+  if (e >= total) return;
+  const int i = (int)(e / N), j = (int)(e % N);
+  const long idx = index[e];
+  for (int h = 0; h < H; ++h) {
+    const float v = table[idx * H + h];
+    bias[((long)h * N + i) * ld + j] = v;
+    if (biasT) biasT[((long)h * N + j) * ldT + i] = v;
+  }
+}
+extern "C" int x2_relpos_bias(const float* table, const long* index, float* bias, float* biasT, int N, int H, int ld, int ldT, void* stream) {
+  X2_REQUIRE(N > 0 && H > 0 && ld >= N && (!biasT || ldT >= N), "x2_relpos_bias: N=%d H=%d ld=%d ldT=%d", N, H, ld, ldT);
+  hipLaunchKernelGGL(relpos_bias_kernel, dim3((int)(((long)N * N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, table, index, bias,
+                     biasT, N, H, ld, ldT);
+  return x2_check_launch("x2_relpos_bias");
+}
+// dtable[index[i][j]][h] += sum_b dS[b][h][i][j]   (dS bf16 [B][H][N][ld])
+__global__ __launch_bounds__(256) void relpos_bias_bwd_kernel(const bf16_t* __restrict__ dS, const long* __restrict__ index,
+                                                              float* dtable, int B, int N, int H, int ld) {
+  const int h = blockIdx.y, i = blockIdx.x;
+  for (int j = threadIdx.x; j < N; j += 256) {
+    float acc = 0.f;
+    for (int b = 0; b < B; ++b) acc += bf2f(dS[(((long)b * H + h) * N + i) * ld + j]);
+    atomicAdd(dtable + index[(long)i * N + j] * H + h, acc);
+  }
+}
+extern "C" int x2_relpos_bias_bwd(const void* dS, const long* index, float* dtable, int B, int N, int H, int ld, void* stream) {
+  X2_REQUIRE(B > 0 && N > 0 && H > 0 && ld >= N, "x2_relpos_bias_bwd: B=%d N=%d H=%d ld=%d", B, N, H, ld);
+  hipLaunchKernelGGL(relpos_bias_bwd_kernel, dim3(N, H), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dS, index, dtable, B, N, H, ld);
+  return x2_check_launch("x2_relpos_bias_bwd");
+}

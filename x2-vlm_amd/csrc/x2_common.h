@@ -1,0 +1,87 @@
+// Shared device/host helpers for the X^2-VLM gfx950 kernels.  gfx950 (CDNA4, wave64) only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef uint16_t bf16_t;                                               // raw bf16 bits
+typedef __attribute__((ext_vector_type(8))) short bf16x8;              // one MFMA A/B fragment (4 VGPRs)
+typedef __attribute__((ext_vector_type(4))) short bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;               // one 16x16 accumulator tile
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+
+#define X2_OK 0
+#define X2_ERR_ARG (-1)
+#define X2_ERR_LAUNCH (-2)
+
+void x2_set_error(const char* fmt, ...);
+int x2_check_launch(const char* what);
+
+#define X2_REQUIRE(cond, ...) do { if (!(cond)) { x2_set_error(__VA_ARGS__); return X2_ERR_ARG; } } while (0)
+
+// ---- bf16 <-> f32 (round to nearest even) ----
+__device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  uint32_t u = __float_as_uint(f);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+// two f32 -> packed bf16x2 (lo = a, hi = b), hardware RNE convert (probes/probe_isa.hip: CVTPK)
+__device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
+  uint32_t r;
+  asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ float bf_lo(uint32_t u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bf_hi(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
+
+// exact (erf) GELU and its derivative, fp32
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float dgelu_f(float x) {
+  return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+}
+
+// ---- wave64 reductions ----
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// ---- LDS helpers ----
+__device__ __forceinline__ uint32_t lds_addr(const void* p) { return (uint32_t)(uintptr_t)p; }
+
+// 16-byte read of an MFMA fragment
+__device__ __forceinline__ bf16x8 lds_read_b128(uint32_t byte_addr) {
+  return *reinterpret_cast<const __attribute__((address_space(3))) bf16x8*>((uintptr_t)byte_addr);
+}
+// Transposing read (gfx950): within each 16-lane group, lane 4r+c supplies the address of 4 bf16 at
+// [row r][cols 4c..4c+3]; lane i receives {[0][i],[1][i],[2][i],[3][i]}.  Verified by probes/probe_isa.hip.
+__device__ __forceinline__ bf16x4 lds_read_tr64(uint32_t byte_addr) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (__attribute__((address_space(3))) bf16x4*)(uintptr_t)byte_addr);
+}
+// two transposing reads -> one 8-element MFMA fragment (slots 0..3 from `a0`, 4..7 from `a1`)
+__device__ __forceinline__ bf16x8 lds_read_tr_frag(uint32_t a0, uint32_t a1) {
+  const bf16x4 lo = lds_read_tr64(a0), hi = lds_read_tr64(a1);
+  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+__device__ __forceinline__ void lds_wait_all() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+// async 16-byte global -> LDS copy; LDS destination = wave-uniform `lds_base` + lane*16
+__device__ __forceinline__ void glds16(const void* gptr, void* lds_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gptr,
+                                   (__attribute__((address_space(3))) void*)lds_base, 16, 0, 0);
+}
+
+// XCD-aware, bijective block-id remap: consecutive logical ids land on the same XCD (8 XCDs,
+// hardware round-robins blockIdx over XCDs).  cdna guide section 5.5 T1.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}

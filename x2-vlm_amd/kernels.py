@@ -1,0 +1,309 @@
+"""Tensor-level wrappers over the C ABI (one Python function per entry point of
+include/x2vlm_hip.h).  They only check shapes/dtypes, allocate outputs with torch (device memory
+is PyTorch's job) and launch on the current HIP stream.  No arithmetic happens in Python.
+"""
+import ctypes as C
+
+import torch
+
+from ._lib import AttnArgs, call, ptr
+
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+def _rows(t):
+    assert t.dim() == 2 and t.stride(1) == 1, "expected a row-major 2-D tensor (got strides %s)" % (t.stride(),)
+    return t.stride(0)
+
+
+def round_up(x, m):
+    return (x + m - 1) // m * m
+
+
+# ----------------------------------------------------------------------------- GEMMs
+
+def gemm_nt(A, B, *, bias=None, gamma=None, resid=None, aux=None, act=0, out=None, out_dtype=BF16):
+    """out[M,N] = epilogue(A[M,K] @ B[N,K]^T).  act: 0 none (aux, if given, receives acc+bias),
+    1 GELU (aux receives the pre-activation), 2 multiply by GELU'(aux).  Then *gamma, +resid."""
+    assert A.dtype == BF16 and B.dtype == BF16 and A.shape[1] == B.shape[1]
+    M, K = A.shape
+    N = B.shape[0]
+    if out is None:
+        out = torch.empty(M, N, device=A.device, dtype=out_dtype)
+    assert out.shape == (M, N) and out.dtype in (BF16, F32)
+    for t in (bias, gamma):
+        assert t is None or (t.dtype == F32 and t.numel() == N and t.is_contiguous())
+    assert resid is None or (resid.dtype == F32 and resid.shape == (M, N))
+    assert aux is None or (aux.dtype == BF16 and aux.shape == (M, N))
+    call("x2_gemm_nt", ptr(A), ptr(B), ptr(out), M, N, K, _rows(A), _rows(B), _rows(out), ptr(bias), ptr(gamma),
+         ptr(resid), _rows(resid) if resid is not None else 0, ptr(aux), _rows(aux) if aux is not None else 0,
+         act, 1 if out.dtype == F32 else 0)
+    return out
+
+
+def gemm_tn_grouped(problems, accumulate=False, split=1):
+    """Weight gradients of one layer in one launch.  problems: list of (dY[Mc,N] bf16, X[Mc,K] bf16,
+    dW[N,K] fp32) or 5-tuples with (n_ld, k_ld) = readable row widths when they exceed N / K."""
+    rows = []
+    for pr in problems:
+        dY, X, dW = pr[:3]
+        assert dY.dtype == BF16 and X.dtype == BF16 and dW.dtype == F32 and dY.shape[0] == X.shape[0]
+        N, K = dW.shape
+        n_ld, k_ld = (pr[3], pr[4]) if len(pr) == 5 else (dY.shape[1], X.shape[1])
+        assert dY.shape[1] >= N or n_ld >= N
+        rows.append([dY.data_ptr(), X.data_ptr(), dW.data_ptr(), dY.shape[0], N, K, _rows(dY), _rows(X), _rows(dW),
+                     n_ld, k_ld])
+    for i in range(0, len(rows), 8):
+        chunk = rows[i:i + 8]
+        arr = (C.c_int64 * (11 * len(chunk)))(*[v for r in chunk for v in r])
+        call("x2_gemm_tn_grouped", arr, len(chunk), 1 if accumulate else 0, split)
+
+
+# ----------------------------------------------------------------------------- attention
+
+def _attn_args(q, k, v, B, Bkv, H, Lq, Lk, scale, bias=None, biasT=None, mask=None, kv_idx=None, seq_off=None,
+               seq_ids=None):
+    """q/k/v: (tensor, batch_stride, row_stride) views in elements; data pointer already at head 0."""
+    a = AttnArgs()
+    a.Q, a.q_bs, a.q_rs = q
+    a.K, a.k_bs, a.k_rs = k
+    a.V, a.v_bs, a.v_rs = v
+    a.B, a.Bkv, a.H, a.Lq, a.Lk, a.scale = B, Bkv, H, Lq, Lk, scale
+    if bias is not None:
+        assert bias.dtype == F32 and bias.dim() == 3 and bias.is_contiguous()
+        a.bias, a.bias_ld = bias.data_ptr(), bias.shape[2]
+    if biasT is not None:
+        assert biasT.dtype == F32 and biasT.dim() == 3 and biasT.is_contiguous()
+        a.biasT, a.biasT_ld = biasT.data_ptr(), biasT.shape[2]
+    if mask is not None:
+        assert mask.dtype == F32 and mask.dim() == 2 and mask.is_contiguous() and mask.shape[0] == B
+        a.mask, a.mask_ld = mask.data_ptr(), mask.shape[1]
+    if kv_idx is not None:
+        assert kv_idx.dtype == torch.int32 and kv_idx.numel() == B
+        a.kv_idx = kv_idx.data_ptr()
+    if seq_off is not None:
+        assert seq_off.dtype == torch.int32 and seq_ids.dtype == torch.int32
+        a.seq_off, a.seq_ids = seq_off.data_ptr(), seq_ids.data_ptr()
+    return a
+
+
+def view3(t, B, L, col0=0):
+    """(ptr, batch stride, row stride) of a [B*L, W] row-major bf16 buffer read from column col0."""
+    assert t.dtype == BF16 and t.dim() == 2 and t.stride(1) == 1 and t.shape[0] == B * L
+    return (t.data_ptr() + 2 * col0, L * t.stride(0), t.stride(0))
+
+
+def attn_fwd(q, k, v, B, Bkv, H, Lq, Lk, scale, out, lse, **kw):
+    a = _attn_args(q, k, v, B, Bkv, H, Lq, Lk, scale, **kw)
+    a.Out, a.o_bs, a.o_rs = out
+    assert lse.dtype == F32 and lse.numel() == B * H * Lq
+    a.LSE = lse.data_ptr()
+    call("x2_attn_fwd", C.byref(a))
+
+
+def attn_bwd(q, k, v, o, do, B, Bkv, H, Lq, Lk, scale, lse, delta, dq, dk, dv, dS=None, **kw):
+    a = _attn_args(q, k, v, B, Bkv, H, Lq, Lk, scale, **kw)
+    a.O, a.o_bs, a.o_rs = o
+    a.dO, a.do_bs, a.do_rs = do
+    a.dQ, a.dq_bs, a.dq_rs = dq
+    a.dK, a.dk_bs, a.dk_rs = dk
+    a.dV, a.dv_bs, a.dv_rs = dv
+    a.LSE, a.Delta = lse.data_ptr(), delta.data_ptr()
+    if dS is not None:
+        assert dS.dtype == BF16 and dS.is_contiguous() and dS.shape[:3] == (B, H, Lq)
+        a.dS, a.ds_ld = dS.data_ptr(), dS.shape[3]
+    call("x2_attn_bwd", C.byref(a))
+
+
+# ----------------------------------------------------------------------------- row-wise
+
+def layernorm_fwd(x, w, b, eps, *, rows=None, period=0, want_bf16=True, want_f32=False, y_bf16=None, y_f32=None):
+    """x fp32 [R_total, D]; with period>0 only rows r + r//period + 1 (token 0 of each sample skipped)."""
+    assert x.dtype == F32 and x.is_contiguous()
+    D = x.shape[-1]
+    x2 = x.view(-1, D)
+    R = x2.shape[0] if rows is None else rows
+    if want_bf16 and y_bf16 is None:
+        y_bf16 = torch.empty_like(x2, dtype=BF16)
+    if want_f32 and y_f32 is None:
+        y_f32 = torch.empty_like(x2)
+    mean = torch.empty(R, device=x.device, dtype=F32)
+    rstd = torch.empty(R, device=x.device, dtype=F32)
+    call("x2_layernorm_fwd", ptr(x2), ptr(w), ptr(b), ptr(y_bf16), ptr(y_f32), ptr(mean), ptr(rstd), R, D, eps, period)
+    return y_bf16, y_f32, mean, rstd
+
+
+def layernorm_bwd(dy, x, mean, rstd, w, dw, db, *, dres=None, period=0, want_f32=True, want_bf16=False, dx=None):
+    assert dy.dtype == F32 and x.dtype == F32 and dy.is_contiguous() and x.is_contiguous()
+    D = x.shape[-1]
+    R = mean.numel()
+    if want_f32 and dx is None:
+        dx = torch.empty_like(x) if period == 0 else torch.zeros_like(x)
+    dxb = torch.empty(x.shape, device=x.device, dtype=BF16) if want_bf16 else None
+    call("x2_layernorm_bwd", ptr(dy), ptr(x), ptr(mean), ptr(rstd), ptr(w), ptr(dres), ptr(dx), ptr(dxb), ptr(dw), ptr(db),
+         R, D, period)
+    return dx, dxb
+
+
+def colsum_bf16(y, out):
+    call("x2_colsum_bf16", ptr(y), ptr(out), y.shape[0], y.shape[1], _rows(y))
+
+
+def layerscale_bwd(dx, u, gamma, dgamma, dbias):
+    du = torch.empty_like(u)
+    call("x2_layerscale_bwd", ptr(dx), ptr(u), ptr(gamma), ptr(du), ptr(dgamma), ptr(dbias), u.shape[0], u.shape[1])
+    return du
+
+
+def cast_bf16(src, out=None):
+    assert src.dtype == F32 and src.is_contiguous() and src.numel() % 4 == 0
+    if out is None:
+        out = torch.empty_like(src, dtype=BF16)
+    call("x2_cast_bf16", ptr(src), ptr(out), src.numel())
+    return out
+
+
+def cast_transpose_bf16(src, want_plain=True, ldt=None):
+    """fp32 [R,C] -> (bf16 [R,C] or None, bf16 [C, ldt]) with ldt >= R (pad columns zero)."""
+    assert src.dtype == F32 and src.dim() == 2 and src.is_contiguous()
+    R, Cc = src.shape
+    ldt = R if ldt is None else ldt
+    plain = torch.empty(R, Cc, device=src.device, dtype=BF16) if want_plain else None
+    tr = (torch.zeros if ldt > R else torch.empty)(Cc, ldt, device=src.device, dtype=BF16)
+    call("x2_cast_transpose_bf16", ptr(src), ptr(plain), ptr(tr), R, Cc, ldt)
+    return plain, tr
+
+
+def patchify(image, ps):
+    assert image.dtype == F32 and image.is_contiguous() and image.dim() == 4 and image.shape[1] == 3
+    B, _, R, _ = image.shape
+    g = R // ps
+    cols = torch.empty(B * g * g, 3 * ps * ps, device=image.device, dtype=BF16)
+    call("x2_patchify", ptr(image), ptr(cols), B, R, ps)
+    return cols
+
+
+def assemble_tokens(patch, cls, B, P):
+    D = patch.shape[1]
+    x = torch.empty(B, P + 1, D, device=patch.device, dtype=F32)
+    call("x2_assemble_tokens", ptr(patch), ptr(cls), ptr(x), B, P, D)
+    return x
+
+
+def assemble_tokens_bwd(dx, dcls):
+    B, T, D = dx.shape
+    dpatch = torch.empty(B * (T - 1), D, device=dx.device, dtype=BF16)
+    call("x2_assemble_tokens_bwd", ptr(dx), ptr(dpatch), ptr(dcls), B, T - 1, D)
+    return dpatch
+
+
+def pool_tokens(x, w=None, bwd=False):
+    """In place on x fp32 [B, 1+P, D]: fwd writes token 0 = (weighted) mean of patch tokens; bwd spreads the
+    token-0 gradient onto the patch rows and zeroes it."""
+    B, T, D = x.shape
+    assert x.dtype == F32 and x.is_contiguous() and (w is None or (w.dtype == F32 and w.shape == (B, T - 1) and w.is_contiguous()))
+    call("x2_pool_tokens", ptr(x), ptr(w), B, T - 1, D, 1 if bwd else 0)
+    return x
+
+
+def relpos_bias(table, index, want_T=True):
+    N = index.shape[0]
+    H = table.shape[1]
+    ld = round_up(N, 64)
+    bias = torch.zeros(H, N, ld, device=table.device, dtype=F32)
+    biasT = torch.zeros(H, N, ld, device=table.device, dtype=F32) if want_T else None
+    call("x2_relpos_bias", ptr(table), ptr(index), ptr(bias), ptr(biasT), N, H, ld, ld)
+    return bias, biasT
+
+
+def relpos_bias_bwd(dS, index, dtable):
+    B, H, N, ld = dS.shape
+    call("x2_relpos_bias_bwd", ptr(dS), ptr(index), ptr(dtable), B, N, H, ld)
+
+
+# ----------------------------------------------------------------------------- embeddings, heads, losses
+
+def embed_fwd(ids, word, pos, type_emb):
+    R, L = ids.numel(), ids.shape[-1]
+    D = word.shape[1]
+    out = torch.empty(R, D, device=word.device, dtype=F32)
+    call("x2_embed_fwd", ptr(ids), ptr(word), ptr(pos), ptr(type_emb), ptr(out), R, L, D)
+    return out
+
+
+def embed_bwd(ids, g, dword, dpos, dtype):
+    R, L = ids.numel(), ids.shape[-1]
+    call("x2_embed_bwd", ptr(ids), ptr(g), ptr(dword), ptr(dpos), ptr(dtype), R, L, g.shape[-1])
+
+
+def gather_rows(src, idx, row_len, want_f32=True, want_bf16=False):
+    R = idx.numel()
+    assert src.dtype == F32 and src.is_contiguous() and idx.dtype == torch.int32
+    dst = torch.empty(R, row_len, device=src.device, dtype=F32) if want_f32 else None
+    dstb = torch.empty(R, row_len, device=src.device, dtype=BF16) if want_bf16 else None
+    call("x2_gather_rows", ptr(src), ptr(idx), ptr(dst), ptr(dstb), R, row_len)
+    return dst, dstb
+
+
+def scatter_add_rows(src, idx, dst, row_len):
+    assert src.dtype == F32 and dst.dtype == F32 and src.is_contiguous() and dst.is_contiguous()
+    call("x2_scatter_add_rows", ptr(src), ptr(idx), ptr(dst), idx.numel(), row_len)
+
+
+def linear_f32(A, B, *, bias=None, transA=False, transB=False, alpha=1.0, alpha_ptr=None, out=None, accumulate=False):
+    """out[M,N] (+)= alpha * op(A) @ op(B)^T + bias, fp32.  op(A) is [M,K] (A is [K,M] if transA);
+    op(B) is [N,K] (B is [K,N] if transB)."""
+    assert A.dtype == F32 and B.dtype == F32 and A.dim() == 2 and B.dim() == 2
+    M, K = (A.shape[1], A.shape[0]) if transA else A.shape
+    N = B.shape[1] if transB else B.shape[0]
+    sam, sak = (A.stride(1), A.stride(0)) if transA else (A.stride(0), A.stride(1))
+    sbn, sbk = (B.stride(1), B.stride(0)) if transB else (B.stride(0), B.stride(1))
+    if out is None:
+        assert not accumulate
+        out = torch.empty(M, N, device=A.device, dtype=F32)
+    call("x2_linear_f32", ptr(A), ptr(B), ptr(out), ptr(bias), ptr(alpha_ptr), alpha, M, N, K, sam, sak, sbn, sbk,
+         out.stride(0), 1 if accumulate else 0)
+    return out
+
+
+def l2norm(x, dy=None):
+    out = torch.empty_like(x)
+    call("x2_l2norm", ptr(x), ptr(dy), ptr(out), x.shape[0], x.shape[1], 0 if dy is None else 1)
+    return out
+
+
+def ce_fwd(logits, labels, C_valid=None):
+    """logits fp32 [R, ld]; returns (stat[2] = (mean loss, #valid rows), lse[R])."""
+    R, ld = logits.shape
+    Cv = ld if C_valid is None else C_valid
+    lse = torch.empty(R, device=logits.device, dtype=F32)
+    rows = torch.empty(R, device=logits.device, dtype=F32)
+    stat = torch.empty(2, device=logits.device, dtype=F32)
+    call("x2_ce_fwd", ptr(logits), ld, ptr(labels), R, Cv, ptr(lse), ptr(rows), ptr(stat))
+    return stat, lse
+
+
+def ce_bwd(logits, labels, lse, g, stat, C_valid=None, gscale=1.0, out_dtype=F32):
+    R, ld = logits.shape
+    Cv = ld if C_valid is None else C_valid
+    dl = torch.empty(R, ld, device=logits.device, dtype=out_dtype)
+    call("x2_ce_bwd", ptr(logits), ld, ptr(labels), ptr(lse), ptr(g), ptr(stat), gscale, R, Cv,
+         ptr(dl) if out_dtype == F32 else None, ptr(dl) if out_dtype == BF16 else None, ld)
+    return dl
+
+
+def sample_negatives(sim, u, group=None):
+    n = sim.shape[0]
+    out = torch.empty(n, device=sim.device, dtype=torch.int32)
+    call("x2_sample_negatives", ptr(sim), n, ptr(group), ptr(u), ptr(out))
+    return out
+
+
+def gelu_f32(x, dy=None):
+    out = torch.empty_like(x)
+    call("x2_gelu_f32", ptr(x), ptr(dy), ptr(out), x.numel())
+    return out
+
+
+def colsum_f32(x, out):
+    call("x2_colsum_f32", ptr(x), ptr(out), x.shape[0], x.shape[1])
