@@ -1,0 +1,178 @@
+#!/usr/bin/env python3
+"""X^2-VLM pre-training step throughput on MI355X: image-text pairs/s (fwd+bwd), X2VLM-base, 224 px,
+per-GPU batch 64, 30-token captions, ITC+ITM+MLM losses (BASELINE.json metric / configs[1]).
+
+  python bench.py --gpus N --steps K --warmup W
+N>1 is launched by torch.distributed.run (one rank per GPU, RCCL): gradients are all-reduced in
+buckets overlapped with backward, the ITC features are all-gathered; weak scaling (64 pairs/GPU).
+Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel (the bf16 MFMA GEMM) against
+the 2.5 PFLOP/s dense bf16 peak from HIP-event timings of its launches; `cpu_baseline` times the
+CPU oracle (oracle/, the validated restatement of the reference) on this box's host cores.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import tempfile
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+F_MIN_GFLOP = 183.5      # fwd+bwd FLOPs per pair actually executed (K/V de-duplicated), SURVEY.md 8(d), L=30
+PEAK_TFLOPS = 2500.0     # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
+
+
+def synthetic_batch(rank, B, L, res, vocab=30522, masks=12):
+    """per-rank generator seed 1234+rank."""
+    g = torch.Generator().manual_seed(1234 + rank)
+    image = torch.randn(B, 3, res, res, generator=g)
+    ids = torch.randint(1000, 30000, (B, L), generator=g)
+    ids[:, 0], ids[:, -1] = 101, 102
+    atts = torch.ones(B, L, dtype=torch.long)
+    pos = torch.stack([torch.sort(torch.randperm(L - 2, generator=g)[:masks] + 1).values for _ in range(B)])
+    return dict(image=image, text_ids=ids, text_atts=atts, masked_pos=pos, masked_ids=torch.gather(ids, 1, pos),
+                text_ids_masked=ids.scatter(1, pos, 103))
+
+
+def cpu_baseline(seconds=20.0):
+    """The oracle (CPU fp32 restatement, pinned to the reference's golden vectors) on the host cores:
+    X2VLM-base, B=4 sample of the same workload."""
+    from oracle import x2vlm_oracle as O
+    synthetic = importlib.import_module("x2-vlm_amd.synthetic")
+    cores = os.cpu_count() or 1
+    threads = min(cores, 64)
+    torch.set_num_threads(threads)
+    cfg = O.OracleConfig()
+    sd = O.make_params(cfg, 0, synthetic.synth_tensor)
+    B = 4
+    b = synthetic_batch(0, B, 30, 224)
+    neg = synthetic.synth_negatives(0, B)
+    n, t0, first = 0, time.time(), None
+    while True:
+        for t in sd.values():
+            t.grad = None
+        ts = time.time()
+        losses, _ = O.xvlm_forward(sd, cfg, b, neg)
+        sum(losses.values()).backward()
+        if first is None:
+            first = time.time() - ts          # warm-up iteration, not counted
+            t0 = time.time()
+            continue
+        n += 1
+        if time.time() - t0 > seconds or n >= 8:
+            break
+    dt = time.time() - t0
+    return {"value": round(B * n / dt, 3), "unit": "pairs/s", "cores": threads, "kind": "port",
+            "sample": "oracle fp32, X2VLM-base, B=4, %d timed steps after 1 warm-up (%.1fs), %d torch threads" % (n, dt, threads)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--seq-len", type=int, default=30)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--eval-mode", action="store_true", help="model.eval(): dropout / DropPath off (not the headline number)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world)
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    K = importlib.import_module("x2-vlm_amd.kernels")
+    mp = importlib.import_module("x2-vlm_amd.model_pretrain")
+    cfgs = importlib.import_module("x2-vlm_amd.configs")
+    acc = importlib.import_module("x2-vlm_amd.accelerator")
+
+    torch.manual_seed(0)
+    cfg = cfgs.pretrain_config(tempfile.mkdtemp(), "base", 224)
+    model = mp.XVLM(config=cfg, load_vision_params=False, load_text_params=False, pretraining=True).to(dev)
+    model.train(not args.eval_mode)
+    ddp = acc.GradientBuckets(model, world) if world > 1 else None
+    batch = {k: v.to(dev) for k, v in synthetic_batch(rank, args.batch, args.seq_len, 224).items()}
+
+    eng = importlib.import_module("x2-vlm_amd.engine")
+
+    def step():
+        eng.BANK.invalidate()        # as after an optimizer step: fp32 master weights are re-cast to bf16 inside the step
+        model.zero_grad(set_to_none=True)
+        loss = model(batch["image"], batch["text_ids"], batch["text_atts"], text_ids_masked=batch["text_ids_masked"],
+                     masked_pos=batch["masked_pos"], masked_ids=batch["masked_ids"])
+        total = loss["loss_itc"] + loss["loss_itm"] + loss["loss_mlm"]
+        total.backward()
+        if ddp is not None:
+            ddp.finish()
+        return loss
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+    pairs_s = world * args.batch * args.steps / dt
+
+    # dominant kernel: every bf16 MFMA GEMM launch of one more step, HIP events on the launch stream
+    roof = None
+    if rank == 0:
+        K.GEMM_TIMER = []
+        step()
+        torch.cuda.synchronize()
+        ms = sum(a.elapsed_time(b) for a, b, _ in K.GEMM_TIMER)
+        fl = sum(f for _, _, f in K.GEMM_TIMER)
+        n_launch = len(K.GEMM_TIMER)
+        K.GEMM_TIMER = None
+        ach = fl / (ms * 1e-3) / 1e12
+        roof = {"bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(ach / PEAK_TFLOPS, 4), "traffic": None,
+                "kernel": "gemm_nt_kernel+gemm_tn_kernel", "launches_per_step": n_launch,
+                "avg_launch_us": round(1e3 * ms / n_launch, 1), "gemm_ms_per_step": round(ms, 2),
+                "gemm_gflop_per_step": round(fl / 1e9, 1),
+                "whole_step_tflops": round(pairs_s / world * F_MIN_GFLOP / 1e3, 1),
+                "whole_step_frac": round(pairs_s / world * F_MIN_GFLOP / 1e3 / PEAK_TFLOPS, 4)}
+    if world > 1:
+        dist.barrier()
+    if rank == 0:
+        out = {"metric": "image-text pairs/sec (fwd+bwd) X2VLM-base 224px bs=64/GPU", "value": round(pairs_s, 1),
+               "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": round(1e3 * dt / args.steps, 2), "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+               "config": {"workload": "X2VLM-base (BEiT2-base + BERT-base 12+6) pre-training step fwd+bwd, ITC+ITM+MLM, "
+                                      "224px, %d-token captions, 12 masks" % args.seq_len,
+                          "per_gpu_batch": args.batch, "global_batch": args.batch * world,
+                          "parallelism": "dp%d" % world, "mode": "eval (dropout/DropPath off)" if args.eval_mode else
+                          "train (BERT dropout 0.1, attention dropout 0.1, DropPath 0..0.1)",
+                          "losses": {k: round(float(v), 4) for k, v in loss.items()}},
+               "roofline": roof}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -26,6 +26,10 @@ CASES = {
     "base_full": dict(image_res=224, vision_layers=12, hidden=768, heads=12, ffn=3072, vocab=30522,
                       max_pos=512, text_layers=18, fusion_at=12, embed_dim=256, batch=4, seq_len=30,
                       max_masks=12, ragged=False, region=False, frames=0, wseed=31, bseed=32),
+    # BASELINE.json configs[1]: full X2VLM-base at the headline per-GPU batch 64 (ragged captions)
+    "base_full_b64": dict(image_res=224, vision_layers=12, hidden=768, heads=12, ffn=3072, vocab=30522,
+                          max_pos=512, text_layers=18, fusion_at=12, embed_dim=256, batch=64, seq_len=30,
+                          max_masks=12, ragged=True, region=False, frames=0, wseed=41, bseed=42),
 }
 
 

@@ -212,6 +212,9 @@ def test_layernorm(K, rows, D, period):
     assert relerr(dx[sel], xl.grad[sel] + dres[sel]) < 2e-5
     assert relerr(dxb[sel], xl.grad[sel] + dres[sel]) < 6e-3
     assert relerr(dw, wl.grad) < 2e-5 and relerr(db, bl.grad) < 2e-5
+    dw2, db2, dcol = torch.zeros(D, device=dev), torch.zeros(D, device=dev), torch.zeros(D, device=dev)
+    dx2, _ = K.layernorm_bwd(dy.to(dev), x.to(dev), mean, rstd, w.to(dev), dw2, db2, dcol=dcol, period=period)
+    assert relerr(dcol, xl.grad[sel].sum(0)) < 5e-5 and relerr(dx2[sel], xl.grad[sel]) < 2e-5
 
 
 def test_colsum_layerscale_casts(K):

@@ -32,7 +32,7 @@ _SIGS = {
     "x2_attn_fwd": [C.POINTER(AttnArgs), P],
     "x2_attn_bwd": [C.POINTER(AttnArgs), P],
     "x2_layernorm_fwd": [P, P, P, P, P, P, P, I, I, F, I, P],
-    "x2_layernorm_bwd": [P, P, P, P, P, P, P, P, P, P, I, I, I, P],
+    "x2_layernorm_bwd": [P, P, P, P, P, P, P, P, P, P, P, I, I, I, P],
     "x2_colsum_bf16": [P, P, I, I, I, P],
     "x2_layerscale_bwd": [P, P, P, P, P, P, I, I, P],
     "x2_cast_bf16": [P, P, L, P],
@@ -55,7 +55,7 @@ _SIGS = {
     "x2_gelu_f32": [P, P, P, L, P],
     "x2_colsum_f32": [P, P, I, I, P],
 }
-EXPORTS = sorted(list(_SIGS) + ["x2_last_error", "x2_abi_version", "x2_device_cus"])
+EXPORTS = sorted(list(_SIGS) + ["x2_last_error", "x2_abi_version", "x2_device_cus", "x2_tune"])
 
 _lib = None
 
@@ -81,6 +81,7 @@ def lib():
         h.x2_last_error.restype = C.c_char_p
         h.x2_abi_version.restype = I
         h.x2_device_cus.restype = I
+        h.x2_tune.argtypes, h.x2_tune.restype = [I, I], I
         _lib = h
     return _lib
 

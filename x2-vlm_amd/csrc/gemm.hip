@@ -28,7 +28,16 @@ struct GemmNT {
   int lda, ldb, ldc, ldr, ldaux;
   int act;      // 0 none | 1 GELU (aux <- pre-activation) | 2 multiply by GELU'(aux)
   int out_f32;  // C is float (1) or bf16 (0)
+  int group_m;  // tile raster: GROUP_M row-panels are walked column by column (L2 working set = GROUP_M A panels + a few B tiles)
 };
+
+// logical tile id -> (row tile, col tile): XCD-contiguous chunks, inside a chunk groups of `gm` row panels
+__device__ __forceinline__ void tile_coords(int t, int tiles_m, int tiles_n, int gm, int& tm, int& tn) {
+  const int gsz = gm * tiles_n, g = t / gsz, first = g * gm;
+  const int rows = min(gm, tiles_m - first), r = t - g * gsz;
+  tm = first + r % rows;
+  tn = r / rows;
+}
 
 // ---------------------------------------------------------------------------------------------
 // NT: both operands K-contiguous.  LDS image per operand: [128 rows][8 chunks of 16 B], chunk c of
@@ -39,10 +48,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNT p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
-  const int tiles_n = (p.N + BN - 1) / BN;
-  const int nwg = gridDim.x;
-  const int t = xcd_remap(blockIdx.x, nwg);
-  const int m0 = (t / tiles_n) * BM, n0 = (t % tiles_n) * BN;
+  const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
+  int tm, tn;
+  tile_coords(xcd_remap(blockIdx.x, gridDim.x), tiles_m, tiles_n, p.group_m, tm, tn);
+  const int m0 = tm * BM, n0 = tn * BN;
 
   // per-thread global sources for the 4+4 chunks this thread stages per K-step
   const bf16_t* srcA[4]; const bf16_t* srcB[4];
@@ -98,20 +107,35 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNT p) {
     }
   }
 
-  // ---- epilogue: bias / GELU / GELU' / layer-scale + residual, 8- or 16-byte stores ----
+  // ---- epilogue ----
+  // The accumulators hold C^T fragments (lane = one row m, 4 consecutive n per 16x16 tile), which would store
+  // as 16 scattered 32-byte pieces per instruction.  Each wave instead parks its 64x64 fp32 sub-tile in LDS
+  // (two 32-row halves, rows padded to 68 floats: conflict-free both ways) and re-reads it row-major, so that
+  // 16 lanes cover one 256-byte row segment: full-line loads of the residual / saved pre-activation and
+  // full-line stores of C and aux.  bias / GELU / GELU' / layer-scale / residual are applied on the way out.
+  __syncthreads();                                   // every wave is done reading the last operand tiles
+  float* stg = reinterpret_cast<float*>(smem) + wave * (32 * 68);
+  const int er = lane >> 4, ec = (lane & 15) * 4;    // read-back: row offset within a group of 4, column
+  const int n = n0 + wn * 64 + ec;
+  float4 bb{0.f, 0.f, 0.f, 0.f}, gg{1.f, 1.f, 1.f, 1.f};
+  const bool nok = n < p.N;
+  if (nok && p.bias) bb = *reinterpret_cast<const float4*>(p.bias + n);
+  if (nok && p.gamma) gg = *reinterpret_cast<const float4*>(p.gamma + n);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int m = m0 + wm * 64 + i * 16 + frow;
-    if (m >= p.M) continue;
+  for (int half = 0; half < 2; ++half) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int n = n0 + wn * 64 + j * 16 + fg * 4;
-      if (n >= p.N) continue;
-      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-      if (p.bias) {
-        const float4 bb = *reinterpret_cast<const float4*>(p.bias + n);
-        v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
-      }
+    for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        *reinterpret_cast<f32x4*>(stg + (ii * 16 + frow) * 68 + j * 16 + fg * 4) = acc[half * 2 + ii][j];
+    // same-wave LDS traffic only: no barrier, the compiler's lgkmcnt wait orders write -> read
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) {
+      const int row = rr * 4 + er;
+      const int m = m0 + wm * 64 + half * 32 + row;
+      const float4 a4 = *reinterpret_cast<const float4*>(stg + row * 68 + ec);
+      if (m >= p.M || !nok) continue;
+      float v[4] = {a4.x + bb.x, a4.y + bb.y, a4.z + bb.z, a4.w + bb.w};
       if (p.act == 1) {
         *reinterpret_cast<u32x2*>(p.aux + (size_t)m * p.ldaux + n) = u32x2{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])};
 #pragma unroll
@@ -123,13 +147,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNT p) {
       } else if (p.aux) {
         *reinterpret_cast<u32x2*>(p.aux + (size_t)m * p.ldaux + n) = u32x2{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])};
       }
-      if (p.gamma) {
-        const float4 g = *reinterpret_cast<const float4*>(p.gamma + n);
-        v[0] *= g.x; v[1] *= g.y; v[2] *= g.z; v[3] *= g.w;
-      }
+      v[0] *= gg.x; v[1] *= gg.y; v[2] *= gg.z; v[3] *= gg.w;
       if (p.resid) {
-        const float4 rr = *reinterpret_cast<const float4*>(p.resid + (size_t)m * p.ldr + n);
-        v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w;
+        const float4 rs = *reinterpret_cast<const float4*>(p.resid + (size_t)m * p.ldr + n);
+        v[0] += rs.x; v[1] += rs.y; v[2] += rs.z; v[3] += rs.w;
       }
       if (p.out_f32)
         *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n) = float4{v[0], v[1], v[2], v[3]};
@@ -138,6 +159,14 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNT p) {
             u32x2{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])};
     }
   }
+}
+
+// tuning knobs for A/B measurements (probes/bench_gemm.py): [0] GROUP_M of the NT raster, [1] TN raster group
+static int g_tune[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+extern "C" int x2_tune(int key, int value) {
+  if (key < 0 || key >= 8) return X2_ERR_ARG;
+  g_tune[key] = value;
+  return X2_OK;
 }
 
 extern "C" int x2_gemm_nt(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
@@ -149,7 +178,8 @@ extern "C" int x2_gemm_nt(const void* A, const void* B, void* C, int M, int N, i
   X2_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && ldc % 4 == 0, "x2_gemm_nt: leading dims must keep 16-byte rows");
   X2_REQUIRE(act == 0 || aux, "x2_gemm_nt: act=%d needs aux", act);
   X2_REQUIRE((!resid || ldr % 4 == 0) && (!aux || ldaux % 4 == 0), "x2_gemm_nt: ldr/ldaux alignment");
-  GemmNT p{(const bf16_t*)A, (const bf16_t*)B, C, bias, gamma, resid, (bf16_t*)aux, M, N, K, lda, ldb, ldc, ldr, ldaux, act, out_f32};
+  GemmNT p{(const bf16_t*)A, (const bf16_t*)B, C, bias, gamma, resid, (bf16_t*)aux, M, N, K, lda, ldb, ldc, ldr, ldaux, act, out_f32,
+           g_tune[0] > 0 ? g_tune[0] : 8};
   const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
   hipLaunchKernelGGL(gemm_nt_kernel, dim3(tiles), dim3(256), GEMM_LDS_BYTES, (hipStream_t)stream, p);
   return x2_check_launch("x2_gemm_nt");
@@ -184,7 +214,9 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmTNGroup g) {
   for (int i = 1; i < 8; ++i) if (i < g.count && t >= g.p[i].tile_begin) pi = i;
   const TNProblem p = g.p[pi];
   t -= p.tile_begin;
-  const int n0 = (t / p.tiles_k) * 128, k0 = (t % p.tiles_k) * 128;
+  int tnn, tkk;
+  tile_coords(t, (p.N + 127) / 128, p.tiles_k, 8, tnn, tkk);
+  const int n0 = tnn * 128, k0 = tkk * 128;
   const int steps = (p.Mc + BK - 1) / BK;
   const int per = (steps + gridDim.y - 1) / gridDim.y;
   const int s_begin = blockIdx.y * per, s_end = min(steps, s_begin + per);

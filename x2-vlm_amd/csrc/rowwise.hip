@@ -59,23 +59,27 @@ extern "C" int x2_layernorm_fwd(const float* x, const float* w, const float* b, 
 }
 
 // ---------------------------------------------------------------------------------- LayerNorm bwd
-// dx = dres + rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * w ; dw += sum dy*xhat ; db += sum dy.
-// Each wave walks `rows_per_wave` rows keeping its dw/db partials in registers, then one atomic per column.
+// dx = dres + rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * w ; dw += sum dy*xhat ; db += sum dy ;
+// optionally dcol += sum_rows dx (the bias gradient of the linear layer that produced the LN input).
+// A workgroup (4 waves) walks LNB_ROWS rows; each wave keeps its dw/db/dcol partials in registers, the
+// four waves are combined through LDS and the workgroup issues ONE atomic per column.
+#define LNB_ROWS 32
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
                                                             const float* __restrict__ w, const float* dres, float* dx, bf16_t* dxb,
-                                                            float* dw, float* db, int rows, int D, int period, int rows_per_wave) {
-  const int lane = threadIdx.x & 63, wv = blockIdx.x * 4 + (threadIdx.x >> 6);
+                                                            float* dw, float* db, float* dcol, int rows, int D, int period) {
+  extern __shared__ __attribute__((aligned(16))) float red[];      // [3][3 waves][D]
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int nv = D >> 2;
-  float4 ww[LN_MAXV], aw[LN_MAXV], ab[LN_MAXV];
+  float4 ww[LN_MAXV], aw[LN_MAXV], ab[LN_MAXV], ac[LN_MAXV];
 #pragma unroll
   for (int i = 0; i < LN_MAXV; ++i) {
     const int c = lane + i * 64;
     ww[i] = c < nv ? *reinterpret_cast<const float4*>(w + c * 4) : float4{0.f, 0.f, 0.f, 0.f};
-    aw[i] = float4{0.f, 0.f, 0.f, 0.f}; ab[i] = float4{0.f, 0.f, 0.f, 0.f};
+    aw[i] = float4{0.f, 0.f, 0.f, 0.f}; ab[i] = float4{0.f, 0.f, 0.f, 0.f}; ac[i] = float4{0.f, 0.f, 0.f, 0.f};
   }
-  const int r0 = wv * rows_per_wave, r1 = min(rows, r0 + rows_per_wave);
-  for (int row = r0; row < r1; ++row) {
+  const int r0 = blockIdx.x * LNB_ROWS, r1 = min(rows, r0 + LNB_ROWS);
+  for (int row = r0 + wv; row < r1; row += 4) {
     const long gr = remap_row(row, period);
     const float mu = mean[row], rs = rstd[row];
     float4 g[LN_MAXV], xh[LN_MAXV];
@@ -99,85 +103,136 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
       const int c = lane + i * 64;
       if (c < nv) {
         float4 o{rs * (g[i].x - m1 - xh[i].x * m2), rs * (g[i].y - m1 - xh[i].y * m2), rs * (g[i].z - m1 - xh[i].z * m2), rs * (g[i].w - m1 - xh[i].w * m2)};
+        ac[i].x += o.x; ac[i].y += o.y; ac[i].z += o.z; ac[i].w += o.w;
         if (dres) { const float4 rr = *reinterpret_cast<const float4*>(dres + gr * D + c * 4); o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w; }
         if (dx) *reinterpret_cast<float4*>(dx + gr * D + c * 4) = o;
         if (dxb) *reinterpret_cast<u32x2*>(dxb + gr * D + c * 4) = u32x2{pack_bf16(o.x, o.y), pack_bf16(o.z, o.w)};
       }
     }
   }
-  if (r0 < r1) {
+  // combine the 4 waves: waves 1..3 park their partials in LDS, wave 0 adds them and issues the atomics
+  if (wv > 0) {
 #pragma unroll
     for (int i = 0; i < LN_MAXV; ++i) {
       const int c = lane + i * 64;
       if (c < nv) {
+        *reinterpret_cast<float4*>(red + ((0 * 3 + wv - 1) * D) + c * 4) = aw[i];
+        *reinterpret_cast<float4*>(red + ((1 * 3 + wv - 1) * D) + c * 4) = ab[i];
+        *reinterpret_cast<float4*>(red + ((2 * 3 + wv - 1) * D) + c * 4) = ac[i];
+      }
+    }
+  }
+  __syncthreads();
+  if (wv == 0) {
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+      const int c = lane + i * 64;
+      if (c < nv) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const float4 a = *reinterpret_cast<const float4*>(red + ((0 * 3 + k) * D) + c * 4), b = *reinterpret_cast<const float4*>(red + ((1 * 3 + k) * D) + c * 4),
+                       cc = *reinterpret_cast<const float4*>(red + ((2 * 3 + k) * D) + c * 4);
+          aw[i].x += a.x; aw[i].y += a.y; aw[i].z += a.z; aw[i].w += a.w;
+          ab[i].x += b.x; ab[i].y += b.y; ab[i].z += b.z; ab[i].w += b.w;
+          ac[i].x += cc.x; ac[i].y += cc.y; ac[i].z += cc.z; ac[i].w += cc.w;
+        }
         atomicAdd(dw + c * 4 + 0, aw[i].x); atomicAdd(dw + c * 4 + 1, aw[i].y); atomicAdd(dw + c * 4 + 2, aw[i].z); atomicAdd(dw + c * 4 + 3, aw[i].w);
         atomicAdd(db + c * 4 + 0, ab[i].x); atomicAdd(db + c * 4 + 1, ab[i].y); atomicAdd(db + c * 4 + 2, ab[i].z); atomicAdd(db + c * 4 + 3, ab[i].w);
+        if (dcol) { atomicAdd(dcol + c * 4 + 0, ac[i].x); atomicAdd(dcol + c * 4 + 1, ac[i].y); atomicAdd(dcol + c * 4 + 2, ac[i].z); atomicAdd(dcol + c * 4 + 3, ac[i].w); }
       }
     }
   }
 }
 
 extern "C" int x2_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* w,
-                                const float* dres, float* dx, void* dx_bf16, float* dw, float* db, int rows, int D, int period,
-                                void* stream) {
+                                const float* dres, float* dx, void* dx_bf16, float* dw, float* db, float* dcol, int rows, int D,
+                                int period, void* stream) {
   X2_REQUIRE(rows > 0 && D > 0 && D % 4 == 0 && D <= 256 * LN_MAXV, "x2_layernorm_bwd: rows=%d D=%d", rows, D);
   X2_REQUIRE(dw && db, "x2_layernorm_bwd: dw/db (accumulated with atomics) required");
-  const int rpw = rows >= 16384 ? 8 : (rows >= 2048 ? 4 : 1);
-  const int waves = (rows + rpw - 1) / rpw;
-  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((waves + 3) / 4), dim3(256), 0, (hipStream_t)stream, dy, x, mean, rstd, w, dres, dx,
-                     (bf16_t*)dx_bf16, dw, db, rows, D, period, rpw);
+  X2_REQUIRE(!(dcol && dres), "x2_layernorm_bwd: dcol sums the LN-input gradient, which excludes dres");
+  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((rows + LNB_ROWS - 1) / LNB_ROWS), dim3(256), 9 * D * sizeof(float), (hipStream_t)stream, dy,
+                     x, mean, rstd, w, dres, dx, (bf16_t*)dx_bf16, dw, db, dcol, rows, D, period);
   return x2_check_launch("x2_layernorm_bwd");
 }
 
 // ---------------------------------------------------------------------------------- column sums
-// out[n] += sum_m Y[m][n]  (bias gradients).  Block = 256 threads = 8 columns each, walks ROWS rows.
-#define CS_ROWS 32
+// out[n] += sum_m Y[m][n]  (bias gradients).  Workgroup = 512 columns x CS_ROWS rows: 64 lanes x 16 B
+// across, 4 waves down; waves combined through LDS, one atomic per column per workgroup.
+#define CS_ROWS 64
 __global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16_t* __restrict__ y, float* out, int M, int N, int ld) {
-  const int c0 = (blockIdx.y * 256 + threadIdx.x) * 8;
-  if (c0 >= N) return;
+  __shared__ float red[3][512];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int c0 = blockIdx.y * 512 + tx * 8;
   const int r0 = blockIdx.x * CS_ROWS, r1 = min(M, r0 + CS_ROWS);
   float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  for (int r = r0; r < r1; ++r) {
-    const u32x4 v = *reinterpret_cast<const u32x4*>(y + (long)r * ld + c0);
+  if (c0 < N) {
+    for (int r = r0 + ty; r < r1; r += 4) {
+      const u32x4 v = *reinterpret_cast<const u32x4*>(y + (long)r * ld + c0);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { acc[2 * e] += bf_lo(v[e]); acc[2 * e + 1] += bf_hi(v[e]); }
+      for (int e = 0; e < 4; ++e) { acc[2 * e] += bf_lo(v[e]); acc[2 * e + 1] += bf_hi(v[e]); }
+    }
   }
+  if (ty > 0) {
 #pragma unroll
-  for (int e = 0; e < 8; ++e) if (c0 + e < N) atomicAdd(out + c0 + e, acc[e]);
+    for (int e = 0; e < 8; ++e) red[ty - 1][tx * 8 + e] = acc[e];
+  }
+  __syncthreads();
+  if (ty == 0 && c0 < N) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float v = acc[e] + red[0][tx * 8 + e] + red[1][tx * 8 + e] + red[2][tx * 8 + e];
+      if (c0 + e < N) atomicAdd(out + c0 + e, v);
+    }
+  }
 }
 extern "C" int x2_colsum_bf16(const void* y, float* out, int M, int N, int ld, void* stream) {
   X2_REQUIRE(M > 0 && N > 0 && N % 8 == 0 && ld % 8 == 0, "x2_colsum_bf16: M=%d N=%d ld=%d (N, ld multiples of 8)", M, N, ld);
-  hipLaunchKernelGGL(colsum_bf16_kernel, dim3((M + CS_ROWS - 1) / CS_ROWS, (N + 2047) / 2048), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(colsum_bf16_kernel, dim3((M + CS_ROWS - 1) / CS_ROWS, (N + 511) / 512), dim3(256), 0, (hipStream_t)stream,
                      (const bf16_t*)y, out, M, N, ld);
   return x2_check_launch("x2_colsum_bf16");
 }
 
 // ---------------------------------------------------------------------------------- layer-scale backward
 // forward was  x_out = x_in + gamma * u  (u = aux, bf16).  Given dX (fp32):  dU = gamma * dX (bf16),
-// dgamma[n] += sum_m dX*u,  dbias[n] += sum_m dU.   Thread = 4 columns, block walks CS_ROWS rows.
+// dgamma[n] += sum_m dX*u,  dbias[n] += sum_m dU.  Workgroup = 256 columns x LS_ROWS rows (64 lanes x 4
+// columns, 4 waves down), waves combined through LDS, one atomic per column per workgroup.
+#define LS_ROWS 32
 __global__ __launch_bounds__(256) void layerscale_bwd_kernel(const float* __restrict__ dx, const bf16_t* __restrict__ u,
                                                              const float* __restrict__ gamma, bf16_t* du, float* dgamma,
                                                              float* dbias, int M, int D) {
-  const int c0 = (blockIdx.y * 256 + threadIdx.x) * 4;
-  if (c0 >= D) return;
-  const int r0 = blockIdx.x * CS_ROWS, r1 = min(M, r0 + CS_ROWS);
-  const float4 gm = *reinterpret_cast<const float4*>(gamma + c0);
+  __shared__ float red[2][3][256];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int c0 = blockIdx.y * 256 + tx * 4;
+  const int r0 = blockIdx.x * LS_ROWS, r1 = min(M, r0 + LS_ROWS);
   float ag[4] = {0.f, 0.f, 0.f, 0.f}, ab[4] = {0.f, 0.f, 0.f, 0.f};
-  for (int r = r0; r < r1; ++r) {
-    const float4 d = *reinterpret_cast<const float4*>(dx + (long)r * D + c0);
-    const u32x2 uu = *reinterpret_cast<const u32x2*>(u + (long)r * D + c0);
-    const float o0 = d.x * gm.x, o1 = d.y * gm.y, o2 = d.z * gm.z, o3 = d.w * gm.w;
-    *reinterpret_cast<u32x2*>(du + (long)r * D + c0) = u32x2{pack_bf16(o0, o1), pack_bf16(o2, o3)};
-    ag[0] += d.x * bf_lo(uu[0]); ag[1] += d.y * bf_hi(uu[0]); ag[2] += d.z * bf_lo(uu[1]); ag[3] += d.w * bf_hi(uu[1]);
-    ab[0] += o0; ab[1] += o1; ab[2] += o2; ab[3] += o3;
+  if (c0 < D) {
+    const float4 gm = *reinterpret_cast<const float4*>(gamma + c0);
+    for (int r = r0 + ty; r < r1; r += 4) {
+      const float4 d = *reinterpret_cast<const float4*>(dx + (long)r * D + c0);
+      const u32x2 uu = *reinterpret_cast<const u32x2*>(u + (long)r * D + c0);
+      const float o0 = d.x * gm.x, o1 = d.y * gm.y, o2 = d.z * gm.z, o3 = d.w * gm.w;
+      *reinterpret_cast<u32x2*>(du + (long)r * D + c0) = u32x2{pack_bf16(o0, o1), pack_bf16(o2, o3)};
+      ag[0] += d.x * bf_lo(uu[0]); ag[1] += d.y * bf_hi(uu[0]); ag[2] += d.z * bf_lo(uu[1]); ag[3] += d.w * bf_hi(uu[1]);
+      ab[0] += o0; ab[1] += o1; ab[2] += o2; ab[3] += o3;
+    }
   }
+  if (ty > 0) {
 #pragma unroll
-  for (int e = 0; e < 4; ++e) { atomicAdd(dgamma + c0 + e, ag[e]); atomicAdd(dbias + c0 + e, ab[e]); }
+    for (int e = 0; e < 4; ++e) { red[0][ty - 1][tx * 4 + e] = ag[e]; red[1][ty - 1][tx * 4 + e] = ab[e]; }
+  }
+  __syncthreads();
+  if (ty == 0 && c0 < D) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      atomicAdd(dgamma + c0 + e, ag[e] + red[0][0][tx * 4 + e] + red[0][1][tx * 4 + e] + red[0][2][tx * 4 + e]);
+      atomicAdd(dbias + c0 + e, ab[e] + red[1][0][tx * 4 + e] + red[1][1][tx * 4 + e] + red[1][2][tx * 4 + e]);
+    }
+  }
 }
 extern "C" int x2_layerscale_bwd(const float* dx, const void* u, const float* gamma, void* du, float* dgamma, float* dbias, int M,
                                  int D, void* stream) {
   X2_REQUIRE(M > 0 && D > 0 && D % 4 == 0, "x2_layerscale_bwd: M=%d D=%d", M, D);
-  hipLaunchKernelGGL(layerscale_bwd_kernel, dim3((M + CS_ROWS - 1) / CS_ROWS, (D + 1023) / 1024), dim3(256), 0, (hipStream_t)stream, dx,
+  hipLaunchKernelGGL(layerscale_bwd_kernel, dim3((M + LS_ROWS - 1) / LS_ROWS, (D + 255) / 256), dim3(256), 0, (hipStream_t)stream, dx,
                      (const bf16_t*)u, gamma, (bf16_t*)du, dgamma, dbias, M, D);
   return x2_check_launch("x2_layerscale_bwd");
 }

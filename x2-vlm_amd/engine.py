@@ -1,0 +1,620 @@
+"""Stage-level execution of the X^2-VLM step on the HIP kernels.
+
+Each stage (vision encoder, a range of BERT layers, embeddings, MLM head) is ONE
+torch.autograd.Function whose forward and hand-written backward are fixed sequences of C-ABI
+kernel launches (kernels.py); autograd only connects the few stages.  Precision policy (the
+reference ran apex O1 fp16: fp32 weights, fp16 GEMM operands, fp32 LN/softmax/loss): fp32 master
+weights, bf16 GEMM/attention operands with fp32 MFMA accumulation, fp32 residual stream, LayerNorm
+statistics, softmax, losses and every reduction.
+
+Reference behaviour reproduced: beit2.py:125-209, 378-436 (vision), xbert.py:189-216, 322-625,
+652-767 (text/fusion layers), xbert.py:785-824, 1644-1661 (MLM head).
+"""
+import math
+
+import torch
+
+from . import kernels as K
+
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+# ----------------------------------------------------------------------------- bf16 weight copies
+
+class WeightBank:
+    """bf16 (and transposed bf16) copies of the fp32 master weights, rebuilt only when a
+    parameter's version counter moved (i.e. once per optimizer step)."""
+
+    def __init__(self):
+        self._c = {}
+
+    def _get(self, key, vers, build):
+        ent = self._c.get(key)
+        if ent is None or ent[0] != vers:
+            ent = (vers, build())
+            self._c[key] = ent
+        return ent[1]
+
+    def linear(self, *ws):
+        """(W [N,K] bf16, W^T [K,N] bf16) of one weight or of several stacked along N."""
+        key = tuple(id(w) for w in ws)
+        vers = tuple((w._version, w.data_ptr()) for w in ws)
+
+        def build():
+            w2 = [w.detach().reshape(w.shape[0], -1) for w in ws]
+            src = w2[0] if len(w2) == 1 else torch.cat(w2, 0)
+            return K.cast_transpose_bf16(src.contiguous())
+        return self._get(key, vers, build)
+
+    def vocab(self, w):
+        """word embeddings [V,Hd] -> (bf16 [Vp,Hd] zero-padded rows, bf16 [Hd,Vp]), Vp = V rounded to 64."""
+        def build():
+            V, Hd = w.shape
+            Vp = K.round_up(V, 64)
+            src = torch.zeros(Vp, Hd, device=w.device, dtype=F32)
+            src[:V] = w.detach()
+            return K.cast_transpose_bf16(src)
+        return self._get(("vocab", id(w)), (w._version, w.data_ptr()), build)
+
+    def invalidate(self):
+        """Forget every copy (bench.py does this each step: a real training step re-casts the weights
+        the optimizer just updated)."""
+        self._c.clear()
+
+
+BANK = WeightBank()
+
+
+class Grads:
+    """Gradient tensors of one layer (or stage), carved out of ONE flat fp32 arena so that data
+    parallelism can all-reduce a layer's gradients in place, as one message, the moment its
+    backward kernels are enqueued (accelerator.GradientBuckets).  Tensors the kernels accumulate into
+    with atomics sit at the front of the arena and are zeroed with a single memset; weight gradients
+    are written whole by the TN GEMM.
+
+    spec: list of (name, shape, zero_init); a name may be a fused block (e.g. q/k/v weights stacked)
+    that the caller later splits into views with `alias`."""
+
+    def __init__(self, device, spec, key=None):
+        spec = [s for s in spec if s[2]] + [s for s in spec if not s[2]]
+        offs, o = [], 0
+        for _, shape, _z in spec:
+            offs.append(o)
+            o += (int(torch.Size(shape).numel()) + 3) // 4 * 4
+        nzero = sum((int(torch.Size(sh).numel()) + 3) // 4 * 4 for _, sh, z in spec if z)
+        self.flat = torch.empty(o, device=device, dtype=F32)
+        if nzero:
+            self.flat[:nzero].zero_()
+        self.g = {n: self.flat[of:of + torch.Size(sh).numel()].view(sh) for (n, sh, _z), of in zip(spec, offs)}
+        self.key = key
+
+    def __getitem__(self, name):
+        return self.g[name]
+
+    def alias(self, name, view):
+        self.g[name] = view
+
+    def publish(self):
+        """Every kernel writing this arena has been enqueued on the current stream."""
+        if GRAD_READY_HOOK is not None:
+            GRAD_READY_HOOK(self.flat, self.key)
+
+    def take(self, names):
+        return [self.g.pop(n) for n in names]
+
+
+GRAD_READY_HOOK = None      # set by accelerator.GradientBuckets: f(flat_fp32_arena, key)
+STAGE_CALLS = {}            # key -> number of forward calls since the last reset (see GradientBuckets)
+
+
+def _count_call(key):
+    STAGE_CALLS[key] = STAGE_CALLS.get(key, 0) + 1
+
+
+def _mask_pad(add_mask, Lk):
+    """[S, Lk] additive fp32 mask -> [S, round_up(Lk,64)] contiguous (pad value irrelevant: kernels
+    mask keys >= Lk by index)."""
+    S = add_mask.shape[0]
+    out = torch.zeros(S, K.round_up(Lk, 64), device=add_mask.device, dtype=F32)
+    out[:, :Lk] = add_mask
+    return out
+
+
+# ----------------------------------------------------------------------------- vision encoder
+
+def vision_param_names(depth):
+    names = ["cls_token", "patch_embed.proj.weight", "patch_embed.proj.bias", "fc_norm.weight", "fc_norm.bias"]
+    for i in range(depth):
+        b = "blocks.%d." % i
+        names += [b + s for s in ("gamma_1", "gamma_2", "norm1.weight", "norm1.bias", "attn.q_bias", "attn.v_bias",
+                                  "attn.relative_position_bias_table", "attn.qkv.weight", "attn.proj.weight",
+                                  "attn.proj.bias", "norm2.weight", "norm2.bias", "mlp.fc1.weight", "mlp.fc1.bias",
+                                  "mlp.fc2.weight", "mlp.fc2.bias")]
+    return names
+
+
+class VisionEncoderFn(torch.autograd.Function):
+    """image (B,3,R,R) fp32 -> tokens (B,1+P,D) fp32: patch embed, pre-LN blocks with rel-pos-bias
+    attention and layer scale, fc_norm over patches, token 0 = (weighted) mean of patches.
+
+    meta: dict(depth, heads, patch, eps, rel_index[int64 (T,T)], pool_w [B,P] fp32 or None)."""
+
+    @staticmethod
+    def forward(ctx, image, meta, *params):
+        names = vision_param_names(meta["depth"])
+        p = dict(zip(names, params))
+        B, R, ps = image.shape[0], image.shape[-1], meta["patch"]
+        P_ = (R // ps) ** 2
+        T, H = P_ + 1, meta["heads"]
+        D = p["cls_token"].numel()
+        M = B * T
+        scale = (D // H) ** -0.5
+        cols = K.patchify(image.contiguous(), ps)
+        wpe, _ = BANK.linear(p["patch_embed.proj.weight"])
+        patch = K.gemm_nt(cols, wpe, bias=p["patch_embed.proj.bias"], out_dtype=F32)
+        x = K.assemble_tokens(patch, p["cls_token"].reshape(-1), B, P_).view(M, D)
+        saved = []
+        for i in range(meta["depth"]):
+            b = "blocks.%d." % i
+            h1, _, mean1, rstd1 = K.layernorm_fwd(x, p[b + "norm1.weight"], p[b + "norm1.bias"], meta["eps"])
+            wqkv, _ = BANK.linear(p[b + "attn.qkv.weight"])
+            qkv_bias = torch.cat([p[b + "attn.q_bias"].detach(), torch.zeros(D, device=x.device, dtype=F32),
+                                  p[b + "attn.v_bias"].detach()])          # no k bias: beit2.py:129
+            qkv = K.gemm_nt(h1, wqkv, bias=qkv_bias)
+            bias, biasT = K.relpos_bias(p[b + "attn.relative_position_bias_table"].detach(), meta["rel_index"])
+            att = torch.empty(M, D, device=x.device, dtype=BF16)
+            lse = torch.empty(B * H * T, device=x.device, dtype=F32)
+            K.attn_fwd(K.view3(qkv, B, T, 0), K.view3(qkv, B, T, D), K.view3(qkv, B, T, 2 * D), B, B, H, T, T, scale,
+                       K.view3(att, B, T), lse, bias=bias)
+            wproj, _ = BANK.linear(p[b + "attn.proj.weight"])
+            aux1 = torch.empty(M, D, device=x.device, dtype=BF16)
+            x1 = K.gemm_nt(att, wproj, bias=p[b + "attn.proj.bias"], gamma=p[b + "gamma_1"], resid=x, aux=aux1, out_dtype=F32)
+            h2, _, mean2, rstd2 = K.layernorm_fwd(x1, p[b + "norm2.weight"], p[b + "norm2.bias"], meta["eps"])
+            w1, _ = BANK.linear(p[b + "mlp.fc1.weight"])
+            w2, _ = BANK.linear(p[b + "mlp.fc2.weight"])
+            pre = torch.empty(M, w1.shape[0], device=x.device, dtype=BF16)
+            act = K.gemm_nt(h2, w1, bias=p[b + "mlp.fc1.bias"], aux=pre, act=1)
+            aux2 = torch.empty(M, D, device=x.device, dtype=BF16)
+            x2 = K.gemm_nt(act, w2, bias=p[b + "mlp.fc2.bias"], gamma=p[b + "gamma_2"], resid=x1, aux=aux2, out_dtype=F32)
+            saved.append((x, h1, mean1, rstd1, qkv, bias, biasT, att, lse, aux1, x1, h2, mean2, rstd2, pre, act, aux2))
+            x = x2
+        out = torch.empty(B, T, D, device=x.device, dtype=F32)
+        _, _, meanf, rstdf = K.layernorm_fwd(x, p["fc_norm.weight"], p["fc_norm.bias"], meta["eps"], rows=B * P_, period=P_,
+                                             want_bf16=False, y_f32=out.view(M, D))
+        K.pool_tokens(out, meta.get("pool_w"))
+        for i in range(meta["depth"]):
+            _count_call(("vit", id(p["blocks.%d.gamma_1" % i])))
+        _count_call(("vit-stem", id(params[0])))
+        ctx.meta, ctx.saved, ctx.final = meta, saved, (x, meanf, rstdf, cols)
+        ctx.params = params
+        ctx.dims = (B, P_, T, H, D, M, scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        meta, params = ctx.meta, ctx.params
+        names = vision_param_names(meta["depth"])
+        p = dict(zip(names, params))
+        B, P_, T, H, D, M, scale = ctx.dims
+        dev = dout.device
+        out = {}
+        x_last, meanf, rstdf, cols = ctx.final
+        Gt = Grads(dev, [(n, p[n].shape, True) for n in ("cls_token", "patch_embed.proj.weight", "patch_embed.proj.bias",
+                                                          "fc_norm.weight", "fc_norm.bias")], key=("vit-stem", id(params[0])))
+        g = dout.contiguous().clone()
+        K.pool_tokens(g, meta.get("pool_w"), bwd=True)
+        dx, _ = K.layernorm_bwd(g.view(M, D), x_last, meanf, rstdf, p["fc_norm.weight"], Gt["fc_norm.weight"], Gt["fc_norm.bias"],
+                                period=P_)
+        dS = torch.empty(B, H, T, K.round_up(T, 64), device=dev, dtype=BF16)
+        F4 = p["blocks.0.mlp.fc1.weight"].shape[0]
+        for i in reversed(range(meta["depth"])):
+            b = "blocks.%d." % i
+            (x, h1, mean1, rstd1, qkv, bias, biasT, att, lse, aux1, x1, h2, mean2, rstd2, pre, act, aux2) = ctx.saved[i]
+            ctx.saved[i] = None
+            G = Grads(dev, [("gamma_1", (D,), True), ("gamma_2", (D,), True), ("norm1.weight", (D,), True), ("norm1.bias", (D,), True),
+                            ("qkv_bias", (3 * D,), True), ("attn.relative_position_bias_table", p[b + "attn.relative_position_bias_table"].shape, True),
+                            ("attn.proj.bias", (D,), True), ("norm2.weight", (D,), True), ("norm2.bias", (D,), True),
+                            ("mlp.fc1.bias", (F4,), True), ("mlp.fc2.bias", (D,), True),
+                            ("attn.qkv.weight", (3 * D, D), False), ("attn.proj.weight", (D, D), False),
+                            ("mlp.fc1.weight", (F4, D), False), ("mlp.fc2.weight", (D, F4), False)], key=("vit", id(p[b + "gamma_1"])))
+            _, w2T = BANK.linear(p[b + "mlp.fc2.weight"])
+            _, w1T = BANK.linear(p[b + "mlp.fc1.weight"])
+            _, wprojT = BANK.linear(p[b + "attn.proj.weight"])
+            _, wqkvT = BANK.linear(p[b + "attn.qkv.weight"])
+            dy2 = K.layerscale_bwd(dx, aux2, p[b + "gamma_2"], G["gamma_2"], G["mlp.fc2.bias"])
+            dpre = K.gemm_nt(dy2, w2T, aux=pre, act=2)
+            K.colsum_bf16(dpre, G["mlp.fc1.bias"])
+            dh2 = K.gemm_nt(dpre, w1T, out_dtype=F32)
+            dx1, _ = K.layernorm_bwd(dh2, x1, mean2, rstd2, p[b + "norm2.weight"], G["norm2.weight"], G["norm2.bias"], dres=dx)
+            dy1 = K.layerscale_bwd(dx1, aux1, p[b + "gamma_1"], G["gamma_1"], G["attn.proj.bias"])
+            datt = K.gemm_nt(dy1, wprojT)
+            dqkv = torch.empty_like(qkv)
+            delta = torch.empty_like(lse)
+            K.attn_bwd(K.view3(qkv, B, T, 0), K.view3(qkv, B, T, D), K.view3(qkv, B, T, 2 * D), K.view3(att, B, T),
+                       K.view3(datt, B, T), B, B, H, T, T, scale, lse, delta, K.view3(dqkv, B, T, 0), K.view3(dqkv, B, T, D),
+                       K.view3(dqkv, B, T, 2 * D), dS=dS, bias=bias, biasT=biasT)
+            K.relpos_bias_bwd(dS, meta["rel_index"], G["attn.relative_position_bias_table"])
+            K.colsum_bf16(dqkv, G["qkv_bias"])
+            G.alias("attn.q_bias", G["qkv_bias"][:D])
+            G.alias("attn.v_bias", G["qkv_bias"][2 * D:])
+            dh1 = K.gemm_nt(dqkv, wqkvT, out_dtype=F32)
+            dxn, _ = K.layernorm_bwd(dh1, x, mean1, rstd1, p[b + "norm1.weight"], G["norm1.weight"], G["norm1.bias"], dres=dx1)
+            K.gemm_tn_grouped([(dy2, act, G["mlp.fc2.weight"]), (dpre, h2, G["mlp.fc1.weight"]),
+                               (dy1, att, G["attn.proj.weight"]), (dqkv, h1, G["attn.qkv.weight"])])
+            G.publish()
+            for n in names:
+                if n.startswith(b):
+                    out[n] = G.g[n[len(b):]]
+            dx = dxn
+        dpatch = K.assemble_tokens_bwd(dx.view(B, T, D), Gt["cls_token"].view(-1))
+        K.colsum_bf16(dpatch, Gt["patch_embed.proj.bias"])
+        # 36 output tiles only: split the 12k-long contraction over 8 workgroups per tile (fp32 atomics)
+        K.gemm_tn_grouped([(dpatch, cols, Gt["patch_embed.proj.weight"].view(D, -1))], accumulate=True,
+                          split=8 if B * P_ >= 4096 else 1)
+        Gt.publish()
+        out.update(Gt.g)
+        return (None, None) + tuple(out[n] for n in names)
+
+
+# ----------------------------------------------------------------------------- BERT layers
+
+_ATT = ("self.query.weight", "self.query.bias", "self.key.weight", "self.key.bias", "self.value.weight", "self.value.bias",
+        "output.dense.weight", "output.dense.bias", "output.LayerNorm.weight", "output.LayerNorm.bias")
+_FFN = ("intermediate.dense.weight", "intermediate.dense.bias", "output.dense.weight", "output.dense.bias",
+        "output.LayerNorm.weight", "output.LayerNorm.bias")
+
+
+def bert_layer_param_names(lo, hi, fusion_at, with_cross):
+    names = []
+    for i in range(lo, hi):
+        b = "layer.%d." % i
+        names += [b + "attention." + s for s in _ATT]
+        if with_cross and i >= fusion_at:
+            names += [b + "crossattention." + s for s in _ATT]
+        names += [b + s for s in _FFN]
+    return names
+
+
+class BertLayersFn(torch.autograd.Function):
+    """hidden (S,L,Hd) fp32 through BERT layers [lo,hi): self-attention, cross-attention to `enc`
+    (layers >= fusion_at, only when enc is given), FFN, all post-LN.
+
+    enc: (Bi,T,Dv) fp32 image tokens or None; sequence s attends image kv_idx[s] (several text rows
+    may share one image: K/V are projected once per image per layer).
+    meta: dict(lo, hi, fusion_at, heads, eps, self_mask [S,Lp] fp32 additive, enc_mask [S,Tp],
+               kv_idx/seq_off/seq_ids int32 or None)."""
+
+    @staticmethod
+    def forward(ctx, hidden, enc, meta, *params):
+        cross = enc is not None
+        names = bert_layer_param_names(meta["lo"], meta["hi"], meta["fusion_at"], cross)
+        p = dict(zip(names, params))
+        S, L, Hd = hidden.shape
+        H, eps = meta["heads"], meta["eps"]
+        M = S * L
+        scale = 1.0 / math.sqrt(Hd // H)
+        dev = hidden.device
+        h = hidden.contiguous().view(M, Hd)
+        hb = K.cast_bf16(h)
+        encb = None
+        if cross:
+            Bi, T, Dv = enc.shape
+            encb = K.cast_bf16(enc.contiguous().view(Bi * T, Dv))
+        saved = []
+        for i in range(meta["lo"], meta["hi"]):
+            b = "layer.%d." % i
+            a = b + "attention."
+            wqkv, _ = BANK.linear(p[a + "self.query.weight"], p[a + "self.key.weight"], p[a + "self.value.weight"])
+            bqkv = torch.cat([p[a + "self.query.bias"].detach(), p[a + "self.key.bias"].detach(), p[a + "self.value.bias"].detach()])
+            qkv = K.gemm_nt(hb, wqkv, bias=bqkv)
+            att = torch.empty(M, Hd, device=dev, dtype=BF16)
+            lse = torch.empty(S * H * L, device=dev, dtype=F32)
+            K.attn_fwd(K.view3(qkv, S, L, 0), K.view3(qkv, S, L, Hd), K.view3(qkv, S, L, 2 * Hd), S, S, H, L, L, scale,
+                       K.view3(att, S, L), lse, mask=meta["self_mask"])
+            wo, _ = BANK.linear(p[a + "output.dense.weight"])
+            s1 = K.gemm_nt(att, wo, bias=p[a + "output.dense.bias"], resid=h, out_dtype=F32)
+            h1b, h1, m1, r1 = K.layernorm_fwd(s1, p[a + "output.LayerNorm.weight"], p[a + "output.LayerNorm.bias"], eps, want_f32=True)
+            cr = None
+            h2b, h2 = h1b, h1
+            if cross and i >= meta["fusion_at"]:
+                c = b + "crossattention."
+                wq, _ = BANK.linear(p[c + "self.query.weight"])
+                wkv, _ = BANK.linear(p[c + "self.key.weight"], p[c + "self.value.weight"])
+                bkv = torch.cat([p[c + "self.key.bias"].detach(), p[c + "self.value.bias"].detach()])
+                q2 = K.gemm_nt(h1b, wq, bias=p[c + "self.query.bias"])
+                kv = K.gemm_nt(encb, wkv, bias=bkv)
+                att2 = torch.empty(M, Hd, device=dev, dtype=BF16)
+                lse2 = torch.empty(S * H * L, device=dev, dtype=F32)
+                K.attn_fwd(K.view3(q2, S, L), K.view3(kv, Bi, T, 0), K.view3(kv, Bi, T, Hd), S, Bi, H, L, T, scale,
+                           K.view3(att2, S, L), lse2, mask=meta["enc_mask"], kv_idx=meta["kv_idx"])
+                wo2, _ = BANK.linear(p[c + "output.dense.weight"])
+                s2 = K.gemm_nt(att2, wo2, bias=p[c + "output.dense.bias"], resid=h1, out_dtype=F32)
+                h2b, h2, m2, r2 = K.layernorm_fwd(s2, p[c + "output.LayerNorm.weight"], p[c + "output.LayerNorm.bias"], eps, want_f32=True)
+                cr = (q2, kv, att2, lse2, s2, m2, r2)
+            wi, _ = BANK.linear(p[b + "intermediate.dense.weight"])
+            wout, _ = BANK.linear(p[b + "output.dense.weight"])
+            pre = torch.empty(M, wi.shape[0], device=dev, dtype=BF16)
+            act = K.gemm_nt(h2b, wi, bias=p[b + "intermediate.dense.bias"], aux=pre, act=1)
+            s3 = K.gemm_nt(act, wout, bias=p[b + "output.dense.bias"], resid=h2, out_dtype=F32)
+            h3b, h3, m3, r3 = K.layernorm_fwd(s3, p[b + "output.LayerNorm.weight"], p[b + "output.LayerNorm.bias"], eps, want_f32=True)
+            saved.append((hb, qkv, att, lse, s1, m1, r1, h1b, cr, h2b, pre, act, s3, m3, r3))
+            h, hb = h3, h3b
+        for i in range(meta["lo"], meta["hi"]):
+            _count_call(("bert", id(p["layer.%d.attention.self.query.weight" % i])))
+        ctx.meta, ctx.saved, ctx.params, ctx.encb = meta, saved, params, encb
+        ctx.dims = (S, L, Hd, H, M, scale, cross, enc.shape if cross else None)
+        return h.view(S, L, Hd)
+
+    @staticmethod
+    def backward(ctx, dh_out):
+        meta, params, encb = ctx.meta, ctx.params, ctx.encb
+        S, L, Hd, H, M, scale, cross, enc_shape = ctx.dims
+        names = bert_layer_param_names(meta["lo"], meta["hi"], meta["fusion_at"], cross)
+        p = dict(zip(names, params))
+        dev = dh_out.device
+        dh = dh_out.contiguous().view(M, Hd)
+        denc = None
+        out = {}
+        if cross:
+            Bi, T, Dv = enc_shape
+        for li, i in reversed(list(enumerate(range(meta["lo"], meta["hi"])))):
+            b = "layer.%d." % i
+            a = b + "attention."
+            hb, qkv, att, lse, s1, m1, r1, h1b, cr, h2b, pre, act, s3, m3, r3 = ctx.saved[li]
+            ctx.saved[li] = None
+            Ff = p[b + "intermediate.dense.weight"].shape[0]
+            spec = [("a.qkv_bias", (3 * Hd,), True), ("attention.output.dense.bias", (Hd,), True),
+                    ("attention.output.LayerNorm.weight", (Hd,), True), ("attention.output.LayerNorm.bias", (Hd,), True),
+                    ("intermediate.dense.bias", (Ff,), True), ("output.dense.bias", (Hd,), True),
+                    ("output.LayerNorm.weight", (Hd,), True), ("output.LayerNorm.bias", (Hd,), True),
+                    ("a.qkv_weight", (3 * Hd, Hd), False), ("attention.output.dense.weight", (Hd, Hd), False),
+                    ("intermediate.dense.weight", (Ff, Hd), False), ("output.dense.weight", (Hd, Ff), False)]
+            if cr is not None:
+                spec += [("crossattention.self.query.bias", (Hd,), True), ("c.kv_bias", (2 * Hd,), True),
+                         ("crossattention.output.dense.bias", (Hd,), True), ("crossattention.output.LayerNorm.weight", (Hd,), True),
+                         ("crossattention.output.LayerNorm.bias", (Hd,), True), ("crossattention.self.query.weight", (Hd, Hd), False),
+                         ("c.kv_weight", (2 * Hd, Dv), False), ("crossattention.output.dense.weight", (Hd, Hd), False)]
+            G = Grads(dev, spec, key=("bert", id(p[a + "self.query.weight"])))
+            tn = []
+            ds3, ds3b = K.layernorm_bwd(dh, s3, m3, r3, p[b + "output.LayerNorm.weight"], G["output.LayerNorm.weight"],
+                                        G["output.LayerNorm.bias"], dcol=G["output.dense.bias"], want_bf16=True)
+            _, woutT = BANK.linear(p[b + "output.dense.weight"])
+            _, wiT = BANK.linear(p[b + "intermediate.dense.weight"])
+            dpre = K.gemm_nt(ds3b, woutT, aux=pre, act=2)
+            K.colsum_bf16(dpre, G["intermediate.dense.bias"])
+            dh2 = K.gemm_nt(dpre, wiT, resid=ds3, out_dtype=F32)
+            tn += [(ds3b, act, G["output.dense.weight"]), (dpre, h2b, G["intermediate.dense.weight"])]
+            if cr is not None:
+                c = b + "crossattention."
+                q2, kv, att2, lse2, s2, m2, r2 = cr
+                ds2, ds2b = K.layernorm_bwd(dh2, s2, m2, r2, p[c + "output.LayerNorm.weight"], G["crossattention.output.LayerNorm.weight"],
+                                            G["crossattention.output.LayerNorm.bias"], dcol=G["crossattention.output.dense.bias"],
+                                            want_bf16=True)
+                _, wo2T = BANK.linear(p[c + "output.dense.weight"])
+                datt2 = K.gemm_nt(ds2b, wo2T)
+                dq2 = torch.empty_like(q2)
+                dkv = torch.empty_like(kv)
+                delta2 = torch.empty_like(lse2)
+                K.attn_bwd(K.view3(q2, S, L), K.view3(kv, Bi, T, 0), K.view3(kv, Bi, T, Hd), K.view3(att2, S, L), K.view3(datt2, S, L),
+                           S, Bi, H, L, T, scale, lse2, delta2, K.view3(dq2, S, L), K.view3(dkv, Bi, T, 0), K.view3(dkv, Bi, T, Hd),
+                           mask=meta["enc_mask"], kv_idx=meta["kv_idx"], seq_off=meta["seq_off"], seq_ids=meta["seq_ids"])
+                K.colsum_bf16(dq2, G["crossattention.self.query.bias"])
+                K.colsum_bf16(dkv, G["c.kv_bias"])
+                G.alias("crossattention.self.key.bias", G["c.kv_bias"][:Hd])
+                G.alias("crossattention.self.value.bias", G["c.kv_bias"][Hd:])
+                G.alias("crossattention.self.key.weight", G["c.kv_weight"][:Hd])
+                G.alias("crossattention.self.value.weight", G["c.kv_weight"][Hd:])
+                _, wqT = BANK.linear(p[c + "self.query.weight"])
+                _, wkvT = BANK.linear(p[c + "self.key.weight"], p[c + "self.value.weight"])
+                dh1 = K.gemm_nt(dq2, wqT, resid=ds2, out_dtype=F32)
+                denc = K.gemm_nt(dkv, wkvT, resid=denc, out_dtype=F32)
+                tn += [(ds2b, att2, G["crossattention.output.dense.weight"]), (dq2, h1b, G["crossattention.self.query.weight"]),
+                       (dkv, encb, G["c.kv_weight"])]
+            else:
+                dh1 = dh2
+            ds1, ds1b = K.layernorm_bwd(dh1, s1, m1, r1, p[a + "output.LayerNorm.weight"], G["attention.output.LayerNorm.weight"],
+                                        G["attention.output.LayerNorm.bias"], dcol=G["attention.output.dense.bias"], want_bf16=True)
+            _, woT = BANK.linear(p[a + "output.dense.weight"])
+            datt = K.gemm_nt(ds1b, woT)
+            dqkv = torch.empty_like(qkv)
+            delta = torch.empty_like(lse)
+            K.attn_bwd(K.view3(qkv, S, L, 0), K.view3(qkv, S, L, Hd), K.view3(qkv, S, L, 2 * Hd), K.view3(att, S, L), K.view3(datt, S, L),
+                       S, S, H, L, L, scale, lse, delta, K.view3(dqkv, S, L, 0), K.view3(dqkv, S, L, Hd), K.view3(dqkv, S, L, 2 * Hd),
+                       mask=meta["self_mask"])
+            K.colsum_bf16(dqkv, G["a.qkv_bias"])
+            for k3, nm in enumerate(("query", "key", "value")):
+                G.alias("attention.self.%s.bias" % nm, G["a.qkv_bias"][k3 * Hd:(k3 + 1) * Hd])
+                G.alias("attention.self.%s.weight" % nm, G["a.qkv_weight"][k3 * Hd:(k3 + 1) * Hd])
+            _, wqkvT = BANK.linear(p[a + "self.query.weight"], p[a + "self.key.weight"], p[a + "self.value.weight"])
+            dh = K.gemm_nt(dqkv, wqkvT, resid=ds1, out_dtype=F32)
+            tn += [(ds1b, att, G["attention.output.dense.weight"]), (dqkv, hb, G["a.qkv_weight"])]
+            K.gemm_tn_grouped(tn)
+            G.publish()
+            for n in names:
+                if n.startswith(b):
+                    out[n] = G.g[n[len(b):]]
+        d_enc = denc.view(enc_shape) if denc is not None else None
+        return (dh.view(S, L, Hd), d_enc, None) + tuple(out[n] for n in names)
+
+
+# ----------------------------------------------------------------------------- embeddings
+
+class EmbeddingsFn(torch.autograd.Function):
+    """ids (S,L) -> LayerNorm(word + position + type0) (S,L,Hd) fp32.  xbert.py:189-216."""
+
+    @staticmethod
+    def forward(ctx, ids, eps, word, pos, typ, lnw, lnb):
+        S, L = ids.shape
+        ids = ids.contiguous()
+        e = K.embed_fwd(ids, word.detach(), pos.detach(), typ.detach())
+        _, y, mean, rstd = K.layernorm_fwd(e, lnw, lnb, eps, want_bf16=False, want_f32=True)
+        ctx.save_for_backward(ids, e, mean, rstd, word, pos, typ, lnw)
+        return y.view(S, L, -1)
+
+    @staticmethod
+    def backward(ctx, dy):
+        ids, e, mean, rstd, word, pos, typ, lnw = ctx.saved_tensors
+        small = torch.zeros(2 * lnw.numel(), device=dy.device, dtype=F32)
+        dw, db = small[:lnw.numel()], small[lnw.numel():]
+        de, _ = K.layernorm_bwd(dy.contiguous().view(e.shape), e, mean, rstd, lnw, dw, db)
+        dword, dpos, dtyp = torch.zeros_like(word), torch.zeros_like(pos), torch.zeros_like(typ)
+        K.embed_bwd(ids, de, dword, dpos, dtyp)
+        return None, None, dword, dpos, dtyp, dw, db
+
+
+# ----------------------------------------------------------------------------- MLM head + loss
+
+class MlmLossFn(torch.autograd.Function):
+    """rows (R,Hd) fp32 at the masked positions -> mean CE over labels != -100.
+    transform dense + GELU + LayerNorm, decoder tied to the word embeddings + bias
+    (xbert.py:785-824, 1653-1661).  Returns (loss, logits fp32 [R, Vp] detached view for inspection)."""
+
+    @staticmethod
+    def forward(ctx, rows, labels, eps, dw_, db_, lnw, lnb, dec_bias, word):
+        R, Hd = rows.shape
+        V = word.shape[0]
+        rb = K.cast_bf16(rows.contiguous())
+        wd, _ = BANK.linear(dw_)
+        t_pre = torch.empty(R, Hd, device=rows.device, dtype=BF16)
+        t_act = K.gemm_nt(rb, wd, bias=db_, aux=t_pre, act=1, out_dtype=F32)
+        tb, _, mean, rstd = K.layernorm_fwd(t_act, lnw, lnb, eps)
+        Eb, EbT = BANK.vocab(word)
+        Vp = Eb.shape[0]
+        bias_p = torch.zeros(Vp, device=rows.device, dtype=F32)
+        bias_p[:V] = dec_bias.detach()
+        logits = K.gemm_nt(tb, Eb, bias=bias_p, out_dtype=F32)
+        labels = labels.contiguous().view(-1)
+        stat, lse = K.ce_fwd(logits, labels, C_valid=V)
+        ctx.save_for_backward(rb, t_pre, t_act, mean, rstd, tb, logits, labels, lse, stat, dw_, lnw, word)
+        ctx.V = V
+        ctx.mark_non_differentiable(logits)
+        return stat[0].clone(), logits
+
+    @staticmethod
+    def backward(ctx, g, _gl):
+        rb, t_pre, t_act, mean, rstd, tb, logits, labels, lse, stat, dw_, lnw, word = ctx.saved_tensors
+        V = ctx.V
+        R, Hd = rb.shape
+        dev = rb.device
+        dl = K.ce_bwd(logits, labels, lse, g.reshape(1).to(F32).contiguous(), stat, C_valid=V, out_dtype=BF16)
+        Vp = dl.shape[1]
+        dbias = torch.zeros(Vp, device=dev, dtype=F32)
+        K.colsum_bf16(dl, dbias)
+        Eb, EbT = BANK.vocab(word)
+        dt = K.gemm_nt(dl, EbT, out_dtype=F32)                       # [R, Hd]
+        dword = torch.empty_like(word)
+        small = torch.zeros(3 * Hd, device=dev, dtype=F32)
+        dlnw, dlnb, dbd = small[:Hd], small[Hd:2 * Hd], small[2 * Hd:]
+        dact, _ = K.layernorm_bwd(dt, t_act, mean, rstd, lnw, dlnw, dlnb)
+        dpre = K.gelu_f32(t_pre.float(), dact)                        # small [R,Hd]: GELU' on the saved pre-activation
+        dpre_b = K.cast_bf16(dpre)
+        K.colsum_bf16(dpre_b, dbd)
+        _, wdT = BANK.linear(dw_)
+        drows = K.gemm_nt(dpre_b, wdT, out_dtype=F32)
+        ddw = torch.empty_like(dw_)
+        K.gemm_tn_grouped([(dl, tb, dword, Vp, Hd), (dpre_b, rb, ddw)])
+        return drows, None, None, ddw, dbd, dlnw, dlnb, dbias[:V], dword
+
+
+# ----------------------------------------------------------------------------- small differentiable ops (heads)
+
+class LinearF32Fn(torch.autograd.Function):
+    """y = x @ W^T + b in fp32 (projection heads, last layers of the MLP heads)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        ctx.has_b = b is not None
+        return K.linear_f32(x.contiguous(), w.detach().contiguous(), bias=b)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = K.linear_f32(dy, w, transB=True)                        # dy [M,N] @ W [N,K]
+        dw = K.linear_f32(dy, x, transA=True, transB=True)           # dy^T [N,M] @ x [M,K]
+        db = None
+        if ctx.has_b:
+            db = torch.zeros(w.shape[0], device=dy.device, dtype=F32)
+            K.colsum_f32(dy, db)
+        return dx, dw, db
+
+
+class LayerNormF32Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b, eps):
+        x = x.contiguous()
+        _, y, mean, rstd = K.layernorm_fwd(x, w, b, eps, want_bf16=False, want_f32=True)
+        ctx.save_for_backward(x, w, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, mean, rstd = ctx.saved_tensors
+        small = torch.zeros(2 * w.numel(), device=dy.device, dtype=F32)
+        dw, db = small[:w.numel()], small[w.numel():]
+        dx, _ = K.layernorm_bwd(dy.contiguous(), x, mean, rstd, w, dw, db)
+        return dx, dw, db, None
+
+
+class GeluF32Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        ctx.save_for_backward(x)
+        return K.gelu_f32(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        return K.gelu_f32(x, dy.contiguous())
+
+
+class L2NormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        ctx.save_for_backward(x)
+        return K.l2norm(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        return K.l2norm(x, dy.contiguous())
+
+
+class CrossEntropyFn(torch.autograd.Function):
+    """mean over rows with label >= 0 of -log softmax(logits)[label]; fp32 logits [R,C]."""
+
+    @staticmethod
+    def forward(ctx, logits, labels):
+        logits, labels = logits.contiguous(), labels.contiguous()
+        stat, lse = K.ce_fwd(logits, labels)
+        ctx.save_for_backward(logits, labels, lse, stat)
+        return stat[0].clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, labels, lse, stat = ctx.saved_tensors
+        return K.ce_bwd(logits, labels, lse, g.reshape(1).to(F32).contiguous(), stat), None
+
+
+class GatherRowsFn(torch.autograd.Function):
+    """out[r] = src[idx[r]] over the first dim (rows may be whole sequences); backward scatter-adds."""
+
+    @staticmethod
+    def forward(ctx, src, idx):
+        src = src.contiguous()
+        row_len = src[0].numel()
+        ctx.save_for_backward(idx)
+        ctx.shape = src.shape
+        out, _ = K.gather_rows(src.view(src.shape[0], row_len), idx, row_len)
+        return out.view((idx.numel(),) + src.shape[1:])
+
+    @staticmethod
+    def backward(ctx, dy):
+        (idx,) = ctx.saved_tensors
+        row_len = dy[0].numel()
+        dst = torch.zeros(ctx.shape, device=dy.device, dtype=F32)
+        K.scatter_add_rows(dy.contiguous().view(idx.numel(), row_len), idx, dst.view(ctx.shape[0], row_len), row_len)
+        return dst, None

@@ -11,6 +11,27 @@ from ._lib import AttnArgs, call, ptr
 BF16, F32 = torch.bfloat16, torch.float32
 
 
+GEMM_TIMER = None   # bench.py: list collecting (start_event, end_event, flops) per GEMM launch
+
+
+class _timed:
+    """HIP events around one launch on the current stream (only while bench.py's GEMM_TIMER is set)."""
+
+    def __init__(self, flops):
+        self.flops = flops
+
+    def __enter__(self):
+        if GEMM_TIMER is not None:
+            self.a = torch.cuda.Event(enable_timing=True)
+            self.b = torch.cuda.Event(enable_timing=True)
+            self.a.record()
+
+    def __exit__(self, *exc):
+        if GEMM_TIMER is not None:
+            self.b.record()
+            GEMM_TIMER.append((self.a, self.b, self.flops))
+
+
 def _rows(t):
     assert t.dim() == 2 and t.stride(1) == 1, "expected a row-major 2-D tensor (got strides %s)" % (t.stride(),)
     return t.stride(0)
@@ -35,9 +56,10 @@ def gemm_nt(A, B, *, bias=None, gamma=None, resid=None, aux=None, act=0, out=Non
         assert t is None or (t.dtype == F32 and t.numel() == N and t.is_contiguous())
     assert resid is None or (resid.dtype == F32 and resid.shape == (M, N))
     assert aux is None or (aux.dtype == BF16 and aux.shape == (M, N))
-    call("x2_gemm_nt", ptr(A), ptr(B), ptr(out), M, N, K, _rows(A), _rows(B), _rows(out), ptr(bias), ptr(gamma),
-         ptr(resid), _rows(resid) if resid is not None else 0, ptr(aux), _rows(aux) if aux is not None else 0,
-         act, 1 if out.dtype == F32 else 0)
+    with _timed(2.0 * M * N * K):
+        call("x2_gemm_nt", ptr(A), ptr(B), ptr(out), M, N, K, _rows(A), _rows(B), _rows(out), ptr(bias), ptr(gamma),
+             ptr(resid), _rows(resid) if resid is not None else 0, ptr(aux), _rows(aux) if aux is not None else 0,
+             act, 1 if out.dtype == F32 else 0)
     return out
 
 
@@ -56,7 +78,8 @@ def gemm_tn_grouped(problems, accumulate=False, split=1):
     for i in range(0, len(rows), 8):
         chunk = rows[i:i + 8]
         arr = (C.c_int64 * (11 * len(chunk)))(*[v for r in chunk for v in r])
-        call("x2_gemm_tn_grouped", arr, len(chunk), 1 if accumulate else 0, split)
+        with _timed(sum(2.0 * r[3] * r[4] * r[5] for r in chunk)):
+            call("x2_gemm_tn_grouped", arr, len(chunk), 1 if accumulate else 0, split)
 
 
 # ----------------------------------------------------------------------------- attention
@@ -133,7 +156,8 @@ def layernorm_fwd(x, w, b, eps, *, rows=None, period=0, want_bf16=True, want_f32
     return y_bf16, y_f32, mean, rstd
 
 
-def layernorm_bwd(dy, x, mean, rstd, w, dw, db, *, dres=None, period=0, want_f32=True, want_bf16=False, dx=None):
+def layernorm_bwd(dy, x, mean, rstd, w, dw, db, *, dres=None, dcol=None, period=0, want_f32=True, want_bf16=False, dx=None):
+    """dcol (fp32 [D], accumulated): column sums of the LN-input gradient = bias gradient of the producing linear."""
     assert dy.dtype == F32 and x.dtype == F32 and dy.is_contiguous() and x.is_contiguous()
     D = x.shape[-1]
     R = mean.numel()
@@ -141,7 +165,7 @@ def layernorm_bwd(dy, x, mean, rstd, w, dw, db, *, dres=None, period=0, want_f32
         dx = torch.empty_like(x) if period == 0 else torch.zeros_like(x)
     dxb = torch.empty(x.shape, device=x.device, dtype=BF16) if want_bf16 else None
     call("x2_layernorm_bwd", ptr(dy), ptr(x), ptr(mean), ptr(rstd), ptr(w), ptr(dres), ptr(dx), ptr(dxb), ptr(dw), ptr(db),
-         R, D, period)
+         ptr(dcol), R, D, period)
     return dx, dxb
 
 
