@@ -1,0 +1,133 @@
+/* x2vlm_hip.h — C ABI of libx2vlm_hip.so: the MI355X (gfx950) kernels of the X^2-VLM pre-training step.
+ *
+ * The reference (zengyan-97/X2-VLM) is 100 % Python and has no FFI layer: every entry point below replaces
+ * an implicit ATen / cuBLAS / cuDNN call made by the cited reference line (forward AND its autograd
+ * backward).  A maintainer binds them with ctypes (INTEGRATION.md shows the stub); x2-vlm_amd/_lib.py is
+ * that binding, x2-vlm_amd/kernels.py the tensor-level wrappers.
+ *
+ * Conventions
+ *   - extern "C", POD arguments only: device pointers as void* / typed pointers, sizes as int / long,
+ *     the HIP stream as void* (hipStream_t).  No torch types.
+ *   - returns 0 on success, < 0 on error (-1 bad argument, -2 launch failure); x2_last_error() gives the
+ *     message (thread-local).  Nothing is launched when an argument check fails.
+ *   - the caller owns all memory; kernels never allocate, never synchronise the host; every call is
+ *     asynchronous and ordered on the stream passed in; distinct streams may be used concurrently.
+ *   - bf16 tensors are raw uint16 bit patterns; "ld*" are leading dimensions in ELEMENTS.
+ *   - gradients documented as "+=" are accumulated with fp32 atomics into caller-initialised memory.
+ */
+#ifndef X2VLM_HIP_H
+#define X2VLM_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+const char* x2_last_error(void);
+int x2_abi_version(void);          /* == 1 */
+int x2_device_cus(void);           /* compute units of the current HIP device, 0 if none */
+int x2_tune(int key, int value);   /* A/B knobs for probes/bench_gemm.py (key 0: NT tile-raster GROUP_M) */
+
+/* ---- dense contractions (csrc/gemm.hip) -------------------------------------------------------------
+ * F.linear of beit2.py:131 (fused qkv), :160 (proj), :62/:66 (MLP); xbert.py:338-350 (Q/K/V, cross K/V from
+ * image tokens), :428 (attention output), :497 (intermediate), :512 (output), :798 (MLM transform),
+ * :822 (tied decoder); nn.Conv2d patch embedding beit2.py:225,231 (as a GEMM over patch rows).
+ *
+ * C[M,N] = epilogue(A[M,K] . B[N,K]^T), bf16 operands, fp32 MFMA accumulation.  K % 64 == 0, N % 4 == 0.
+ *   v = acc + bias[n]
+ *   act == 1: aux[m,n] = bf16(v); v = gelu(v)        (erf form)   -> fc1 / intermediate forward
+ *   act == 2: v *= gelu'(aux[m,n])                                 -> dgrad through the GELU
+ *   act == 0 and aux != NULL: aux[m,n] = bf16(v)                   -> value before layer scale (for dgamma)
+ *   v *= gamma[n]; v += resid[m,n]                                 -> x + gamma_1 * proj(...)  (beit2.py:206-207),
+ *                                                                     dense(x) + residual (xbert.py:430,514)
+ *   C = out_f32 ? float : bf16.  Forward linears pass B = W (N x K); input gradients pass B = W^T. */
+int x2_gemm_nt(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
+               const float* bias, const float* gamma, const float* resid, int ldr, void* aux, int ldaux,
+               int act, int out_f32, void* stream);
+
+/* Weight gradients of one layer in one launch: for each problem  dW[N,K] (+)= dY[Mc,N]^T . X[Mc,K]  (fp32 out).
+ * problems: count (<= 8) rows of 11 int64 {dY, X, dW, Mc, N, K, ld_dY, ld_X, ld_dW, n_ld, k_ld}; n_ld / k_ld are
+ * the readable widths of dY / X rows (>= N / K, multiples of 8).  accumulate: dW += instead of dW =.
+ * split > 1 splits the contraction over `split` workgroups per tile (fp32 atomics; requires accumulate). */
+int x2_gemm_tn_grouped(const int64_t* problems, int count, int accumulate, int split, void* stream);
+
+/* ---- fused attention, head dim 64 (csrc/attention.hip) ----------------------------------------------
+ * beit2.py:135-159 (q*scale, QK^T, + relative_position_bias, softmax, PV); xbert.py:364-409 (QK^T/sqrt(d),
+ * + additive mask, softmax, PV) for self-attention and for cross-attention to image tokens (xbert.py:345-348).
+ * Scores/probabilities never reach HBM.  kv_idx lets several query batches share one K/V batch.
+ * Field order is the ABI (mirrored by ctypes.Structure in x2-vlm_amd/_lib.py). */
+typedef struct X2AttnArgs {
+  const void *Q, *K, *V, *O, *dO;            /* bf16; O/dO: backward inputs                               */
+  void *Out, *dQ, *dK, *dV, *dS;             /* bf16 outputs; dS [B][H][Lq][ds_ld] optional (bias grad)   */
+  float *LSE, *Delta;                        /* [B][H][Lq] fp32: log2-domain logsumexp; rowsum(dO*O)      */
+  long q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs;            /* batch / row strides, elements        */
+  long dq_bs, dq_rs, dk_bs, dk_rs, dv_bs, dv_rs, do_bs, do_rs;
+  int B, Bkv, H, Lq, Lk;
+  float scale;
+  const float* bias;  int bias_ld;           /* [H][Lq][bias_ld]  additive, bias_ld % 64 == 0             */
+  const float* biasT; int biasT_ld;          /* [H][Lk][biasT_ld] transposed copy (backward)              */
+  const float* mask;  int mask_ld;           /* [B][mask_ld] additive per key, mask_ld % 64 == 0          */
+  const int* kv_idx;                         /* [B] query batch -> K/V batch, NULL = identity             */
+  const int* seq_off; const int* seq_ids;    /* CSR inverse of kv_idx (backward dK/dV), NULL = identity   */
+  int ds_ld;
+} X2AttnArgs;
+int x2_attn_fwd(const X2AttnArgs* args, void* stream);
+int x2_attn_bwd(const X2AttnArgs* args, void* stream);   /* dQ (+dS, Delta) then dK/dV; no atomics */
+
+/* ---- row-wise kernels (csrc/rowwise.hip) ------------------------------------------------------------
+ * nn.LayerNorm: beit2.py:175,181,411 (eps 1e-6); xbert.py:214,422,506,796 (1e-12); xvlm.py:166 (1e-5).
+ * period > 0: rows are the non-cls tokens of a (B, period+1, D) tensor (row r -> r + r/period + 1), used for
+ * fc_norm over patches (beit2.py:409-411). */
+int x2_layernorm_fwd(const float* x, const float* w, const float* b, void* y_bf16, float* y_f32, float* mean,
+                     float* rstd, int rows, int D, float eps, int period, void* stream);
+/* dx = dres + LN'(dy); dw += , db += ; dcol += column sums of LN'(dy) (bias gradient of the producing linear) */
+int x2_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* w,
+                     const float* dres, float* dx, void* dx_bf16, float* dw, float* db, float* dcol, int rows, int D,
+                     int period, void* stream);
+int x2_colsum_bf16(const void* y, float* out, int M, int N, int ld, void* stream);                 /* out[n] += sum_m y */
+/* backward of x + gamma * u (beit2.py:206-207): du = gamma*dx (bf16), dgamma += sum dx*u, dbias += sum du */
+int x2_layerscale_bwd(const float* dx, const void* u, const float* gamma, void* du, float* dgamma, float* dbias,
+                      int M, int D, void* stream);
+int x2_cast_bf16(const float* src, void* dst, long n, void* stream);
+int x2_cast_transpose_bf16(const float* src, void* dst, void* dstT, int R, int C, int ldt, void* stream);
+/* PatchEmbed input rows (beit2.py:225-232): image (B,3,R,R) -> bf16 [B*(R/ps)^2][3*ps*ps] */
+int x2_patchify(const float* image, void* cols, int B, int R, int ps, void* stream);
+/* torch.cat((cls_tokens, x), 1) (beit2.py:385-387) and its backward */
+int x2_assemble_tokens(const float* patch, const float* cls, float* x, int B, int P, int D, void* stream);
+int x2_assemble_tokens_bwd(const float* dx, void* dpatch_bf16, float* dcls, int B, int P, int D, void* stream);
+/* token 0 <- (weighted) mean of patch tokens: avgpool beit2.py:413-416, region pooling beit2.py:430-436 */
+int x2_pool_tokens(float* x, const float* w, int B, int P, int D, int bwd, void* stream);
+/* relative_position_bias_table[relative_position_index] -> [H][N][ld] (+ transposed), beit2.py:138-144 */
+int x2_relpos_bias(const float* table, const long* index, float* bias, float* biasT, int N, int H, int ld, int ldT,
+                   void* stream);
+int x2_relpos_bias_bwd(const void* dS, const long* index, float* dtable, int B, int N, int H, int ld, void* stream);
+
+/* ---- embeddings, heads, losses (csrc/heads.hip) -----------------------------------------------------
+ * BertEmbeddings xbert.py:205-213 (word + position + token-type 0); backward scatter-adds. */
+int x2_embed_fwd(const long* ids, const float* word, const float* pos, const float* type0, float* out, int R, int L,
+                 int D, void* stream);
+int x2_embed_bwd(const long* ids, const float* g, float* dword, float* dpos, float* dtype0, int R, int L, int D,
+                 void* stream);
+/* torch.gather of sequences / masked positions (xbert.py:1588-1589, xvlm.py:866-884) and its backward */
+int x2_gather_rows(const float* src, const int* idx, float* dst, void* dst_bf16, int R, long len, void* stream);
+int x2_scatter_add_rows(const float* src, const int* idx, float* dst, int R, long len, void* stream);
+/* small fp32 linear with arbitrary strides: vision_proj / text_proj (xvlm.py:785-792), similarity matrices
+ * (xvlm.py:807, 831-832), last layers of itm_head / bbox_head (xvlm.py:163-169) and their backward */
+int x2_linear_f32(const float* A, const float* B, float* C, const float* bias, const float* alpha_ptr, float alpha,
+                  int M, int N, int K, long sam, long sak, long sbn, long sbk, long ldc, int accumulate, void* stream);
+int x2_l2norm(const float* x, const float* dy, float* out, int R, int D, int bwd, void* stream);   /* F.normalize */
+/* F.cross_entropy / CrossEntropyLoss(ignore_index=-100): xvlm.py:812-813, 899; xbert.py:1660-1661.
+ * out2 = {mean loss, number of counted rows}; backward writes (softmax - onehot) * gscale * g / count. */
+int x2_ce_fwd(const float* logits, long ld, const long* labels, int R, int C, float* lse, float* loss_row, float* out2,
+              void* stream);
+int x2_ce_bwd(const float* logits, long ld, const long* labels, const float* lse, const float* g, const float* stat,
+              float gscale, int R, int C, float* dl_f32, void* dl_bf16, long ldd, void* stream);
+/* hard negatives, xvlm.py:828-857: softmax(sim)+1e-5 with the diagonal (or same-group entries) zeroed, one
+ * inverse-CDF draw per row from u[b] in [0,1); replaces 2*B torch.multinomial(...).item() host syncs */
+int x2_sample_negatives(const float* sim, int n, const long* group, const float* u, int* out, void* stream);
+int x2_gelu_f32(const float* x, const float* dy, float* out, long n, void* stream);               /* nn.GELU, xvlm.py:167 */
+int x2_colsum_f32(const float* x, float* out, int M, int N, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

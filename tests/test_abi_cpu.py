@@ -1,0 +1,98 @@
+"""CPU checks of the drop-in boundary: the C-ABI library loads, exports every symbol include/x2vlm_hip.h
+declares (and nothing is bound by the Python side that the header does not declare), argument checks
+fail cleanly without a GPU, the host mirror has the reference's state-dict keys."""
+import ctypes
+import importlib
+import os
+import re
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    src = open(os.path.join(ROOT, "include", "x2vlm_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(x2_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = importlib.import_module("x2-vlm_amd._lib")
+    assert os.path.exists(lib.LIB_PATH), "build first: python -c 'import __graft_entry__ as g; g.build()'"
+    h = ctypes.CDLL(lib.LIB_PATH)
+    declared = header_symbols()
+    assert len(declared) >= 30
+    for name in declared:
+        assert hasattr(h, name), "include/x2vlm_hip.h declares %s but libx2vlm_hip.so does not export it" % name
+    assert sorted(lib.EXPORTS) == declared, set(lib.EXPORTS) ^ set(declared)
+    assert lib.lib().x2_abi_version() == 1
+
+
+def test_attn_args_struct_matches_header_layout():
+    lib = importlib.import_module("x2-vlm_amd._lib")
+    # 12 pointers + 16 longs + 5 ints + float + 3 x (pointer, int, pad) + 3 pointers + int (+pad)
+    assert ctypes.sizeof(lib.AttnArgs) == 12 * 8 + 16 * 8 + 6 * 4 + 3 * 16 + 3 * 8 + 8
+    assert lib.AttnArgs.bias.offset == 248 and lib.AttnArgs.kv_idx.offset == 296 and lib.AttnArgs.ds_ld.offset == 320
+
+
+def test_argument_checks_fail_loudly_without_launching():
+    lib = importlib.import_module("x2-vlm_amd._lib")
+    h = lib.lib()
+    rc = h.x2_gemm_nt(None, None, None, 128, 128, 100, 100, 100, 128, None, None, None, 0, None, 0, 0, 0, None)
+    assert rc == -1 and b"multiple of 64" in h.x2_last_error()
+    rc = h.x2_layernorm_fwd(None, None, None, None, None, None, None, 4, 770, 1e-6, 0, None)
+    assert rc == -1 and b"x2_layernorm_fwd" in h.x2_last_error()
+    rc = h.x2_sample_negatives(None, 5000, None, None, None, None)
+    assert rc == -1
+
+
+def test_missing_library_raises(monkeypatch):
+    lib = importlib.import_module("x2-vlm_amd._lib")
+    monkeypatch.setattr(lib, "_lib", None)
+    monkeypatch.setattr(lib, "LIB_PATH", "/nonexistent/libx2vlm_hip.so")
+    with pytest.raises(lib.X2HipError):
+        lib.lib()
+
+
+def test_state_dict_keys_match_reference(synthetic):
+    """Key names + shapes of the host mirror == the reference's state dict (golden fixture lists every
+    parameter name the real reference model had)."""
+    from cases import CASES, model_config
+    mp = importlib.import_module("x2-vlm_amd.model_pretrain")
+    for case in ("tiny", "tiny_video", "base_shallow"):
+        model = mp.XVLM(config=model_config(case, tempfile.mkdtemp()), load_vision_params=False, load_text_params=False)
+        gold = np.load(os.path.join(ROOT, "tests", "golden", case + ".npz"))
+        ref = sorted(k[len("gradnorm/"):] for k in gold.files if k.startswith("gradnorm/"))
+        mine = sorted(n for n, _ in model.named_parameters())
+        assert mine == ref
+        sd = model.state_dict()
+        assert "text_encoder.cls.predictions.decoder.weight" in sd            # tied, still serialised like HF does
+        assert sd["text_encoder.cls.predictions.decoder.weight"].data_ptr() == \
+            sd["text_encoder.bert.embeddings.word_embeddings.weight"].data_ptr()
+        assert "vision_encoder.blocks.0.attn.relative_position_index" in sd and "text_encoder.bert.embeddings.position_ids" in sd
+        assert sorted(model.init_params) == sorted(n for n in mine if n.split(".")[0] in
+                                                    ("temp", "vision_proj", "text_proj", "itm_head", "bbox_head",
+                                                     "absolute_frame_pos_embed"))
+
+
+def test_relative_position_index_matches_oracle():
+    from oracle import x2vlm_oracle as O
+    beit2 = importlib.import_module("x2-vlm_amd.beit2")
+    for g in (2, 14, 24):
+        assert torch.equal(beit2.relative_position_index(g, g), O.relative_position_index(g))
+
+
+def test_synthetic_generators_are_deterministic(synthetic):
+    a = synthetic.synth_batch(5, 4, 12, 32, 512, 3, ragged=True)
+    b = synthetic.synth_batch(5, 4, 12, 32, 512, 3, ragged=True)
+    for k in a:
+        assert torch.equal(a[k], b[k])
+    assert (a["masked_ids"] == -100).any() and (a["text_atts"] == 0).any()
+    sel = a["masked_ids"] != -100
+    assert torch.equal(torch.gather(a["text_ids"], 1, a["masked_pos"])[sel], a["masked_ids"][sel])
+    ineg, tneg = synthetic.synth_negatives(3, 8)
+    assert all(i != j for j, i in enumerate(ineg)) and all(i != j for j, i in enumerate(tneg))
