@@ -37,12 +37,17 @@ int x2_tune(int key, int value);   /* A/B knobs for probes/bench_gemm.py (key 0:
  *   act == 1: aux[m,n] = bf16(v); v = gelu(v)        (erf form)   -> fc1 / intermediate forward
  *   act == 2: v *= gelu'(aux[m,n])                                 -> dgrad through the GELU
  *   act == 0 and aux != NULL: aux[m,n] = bf16(v)                   -> value before layer scale (for dgamma)
- *   v *= gamma[n]; v += resid[m,n]                                 -> x + gamma_1 * proj(...)  (beit2.py:206-207),
- *                                                                     dense(x) + residual (xbert.py:430,514)
+ *   v *= dropout(v)   (drop_thr16 != 0: hidden dropout, xbert.py:429, 513; counter-based, see below)
+ *   v *= gamma[n]; v *= rowscale[m]; v += resid[m,n]               -> x + drop_path(gamma_1 * proj(...)) (beit2.py:206-207),
+ *                                                                     dropout(dense(x)) + residual (xbert.py:430,514)
+ * Dropout everywhere in this ABI: element e of a site is dropped iff u16(hash(e >> 1 ^ seed), e & 1) < thr16
+ * (thr16 = round(p * 65536), 0 = off); survivors are multiplied by `scale`.  The backward regenerates the mask
+ * from the same (thr16, seed, scale); kernels.dropout_keep() is the host mirror.
  *   C = out_f32 ? float : bf16.  Forward linears pass B = W (N x K); input gradients pass B = W^T. */
 int x2_gemm_nt(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
                const float* bias, const float* gamma, const float* resid, int ldr, void* aux, int ldaux,
-               int act, int out_f32, void* stream);
+               int act, int out_f32, unsigned drop_thr16, unsigned drop_seed, float drop_scale, const float* rowscale,
+               void* stream);
 
 /* Weight gradients of one layer in one launch: for each problem  dW[N,K] (+)= dY[Mc,N]^T . X[Mc,K]  (fp32 out).
  * problems: count (<= 8) rows of 11 int64 {dY, X, dW, Mc, N, K, ld_dY, ld_X, ld_dW, n_ld, k_ld}; n_ld / k_ld are
@@ -69,6 +74,8 @@ typedef struct X2AttnArgs {
   const int* kv_idx;                         /* [B] query batch -> K/V batch, NULL = identity             */
   const int* seq_off; const int* seq_ids;    /* CSR inverse of kv_idx (backward dK/dV), NULL = identity   */
   int ds_ld;
+  unsigned drop_thr16, drop_seed; float drop_scale;   /* dropout on the probabilities (xbert.py:399);
+                                                          element = ((b*H + h)*Lq + q) * round_up(Lk,64) + key */
 } X2AttnArgs;
 int x2_attn_fwd(const X2AttnArgs* args, void* stream);
 int x2_attn_bwd(const X2AttnArgs* args, void* stream);   /* dQ (+dS, Delta) then dK/dV; no atomics */
@@ -78,15 +85,18 @@ int x2_attn_bwd(const X2AttnArgs* args, void* stream);   /* dQ (+dS, Delta) then
  * period > 0: rows are the non-cls tokens of a (B, period+1, D) tensor (row r -> r + r/period + 1), used for
  * fc_norm over patches (beit2.py:409-411). */
 int x2_layernorm_fwd(const float* x, const float* w, const float* b, void* y_bf16, float* y_f32, float* mean,
-                     float* rstd, int rows, int D, float eps, int period, void* stream);
-/* dx = dres + LN'(dy); dw += , db += ; dcol += column sums of LN'(dy) (bias gradient of the producing linear) */
+                     float* rstd, int rows, int D, float eps, int period, unsigned drop_thr16, unsigned drop_seed,
+                     float drop_scale, void* stream);                /* drop: dropout on the LN output (xbert.py:215) */
+/* g = LN'(mask_in(dy)); dx = dres + g (fp32); dx_bf16 = mask_out(g); dw += , db += ; dcol += column sums of mask_out(g)
+ * (= gradient and bias gradient of the linear whose dropped output was added to the residual before this LN) */
 int x2_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* w,
                      const float* dres, float* dx, void* dx_bf16, float* dw, float* db, float* dcol, int rows, int D,
-                     int period, void* stream);
+                     int period, unsigned in_thr16, unsigned in_seed, float in_scale, unsigned out_thr16,
+                     unsigned out_seed, float out_scale, void* stream);
 int x2_colsum_bf16(const void* y, float* out, int M, int N, int ld, void* stream);                 /* out[n] += sum_m y */
 /* backward of x + gamma * u (beit2.py:206-207): du = gamma*dx (bf16), dgamma += sum dx*u, dbias += sum du */
 int x2_layerscale_bwd(const float* dx, const void* u, const float* gamma, void* du, float* dgamma, float* dbias,
-                      int M, int D, void* stream);
+                      const float* rowscale, int M, int D, void* stream);      /* rowscale: DropPath factor per row */
 int x2_cast_bf16(const float* src, void* dst, long n, void* stream);
 int x2_cast_transpose_bf16(const float* src, void* dst, void* dstT, int R, int C, int ldt, void* stream);
 /* PatchEmbed input rows (beit2.py:225-232): image (B,3,R,R) -> bf16 [B*(R/ps)^2][3*ps*ps] */

@@ -163,12 +163,16 @@ def merge_heads(x):
     return x.permute(0, 2, 1, 3).reshape(B, N, H * d)
 
 
-def attention_core(q, k, v, scale, add):
-    """softmax(q k^T * scale + add) v over (B,H,Lq,d)/(B,H,Lk,d); `add` broadcastable or None."""
+def attention_core(q, k, v, scale, add, pmul=None):
+    """softmax(q k^T * scale + add) v over (B,H,Lq,d)/(B,H,Lk,d); `add` broadcastable or None.
+    pmul: training-mode dropout multiplier (0 or 1/(1-p)) on the probabilities (xbert.py:399)."""
     s = (q @ k.transpose(-1, -2)) * scale
     if add is not None:
         s = s + add
-    return torch.softmax(s, dim=-1) @ v
+    p = torch.softmax(s, dim=-1)
+    if pmul is not None:
+        p = p * pmul
+    return p @ v
 
 
 def cross_entropy(logits, labels, ignore_index=-100):
@@ -190,8 +194,9 @@ def patch_embed(sd, cfg, image):
     return linear(cols, w, sd["vision_encoder.patch_embed.proj.bias"])
 
 
-def vision_block(sd, cfg, i, x, rel_index):
-    """Pre-LN block with fused-QKV attention + rel-pos bias + layer scale. beit2.py:125-166, 191-209."""
+def vision_block(sd, cfg, i, x, rel_index, dp=None):
+    """Pre-LN block with fused-QKV attention + rel-pos bias + layer scale. beit2.py:125-166, 191-209.
+    dp: training-mode DropPath multipliers (m1, m2), each (B,1,1) with values 0 or 1/(1-p) (timm drop_path)."""
     p = "vision_encoder.blocks.%d." % i
     H = cfg.vision_heads
     D = cfg.vision_width
@@ -202,20 +207,21 @@ def vision_block(sd, cfg, i, x, rel_index):
     N = x.shape[1]
     bias = sd[p + "attn.relative_position_bias_table"][rel_index.reshape(-1)].view(N, N, H).permute(2, 0, 1)
     ctx = merge_heads(attention_core(q, k, v, (D // H) ** -0.5, bias.unsqueeze(0)))
-    x = x + sd[p + "gamma_1"] * linear(ctx, sd[p + "attn.proj.weight"], sd[p + "attn.proj.bias"])
+    m1, m2 = dp if dp is not None else (1.0, 1.0)
+    x = x + m1 * (sd[p + "gamma_1"] * linear(ctx, sd[p + "attn.proj.weight"], sd[p + "attn.proj.bias"]))
     h = layer_norm(x, sd[p + "norm2.weight"], sd[p + "norm2.bias"], 1e-6)
     h = gelu(linear(h, sd[p + "mlp.fc1.weight"], sd[p + "mlp.fc1.bias"]))
-    return x + sd[p + "gamma_2"] * linear(h, sd[p + "mlp.fc2.weight"], sd[p + "mlp.fc2.bias"])
+    return x + m2 * (sd[p + "gamma_2"] * linear(h, sd[p + "mlp.fc2.weight"], sd[p + "mlp.fc2.bias"]))
 
 
-def vision_encoder(sd, cfg, image, idx_to_group_img=None, image_atts=None):
+def vision_encoder(sd, cfg, image, idx_to_group_img=None, image_atts=None, drop_path=None):
     """beit2.py:378-436.  Returns (B,1+P,D); with idx_to_group_img also the region-pooled copy:
     (region_embeds, full_embeds) where full_embeds is still per image (not yet gathered)."""
     B = image.shape[0]
     x = torch.cat([sd["vision_encoder.cls_token"].expand(B, -1, -1), patch_embed(sd, cfg, image)], dim=1)
     rel_index = relative_position_index(image.shape[-1] // cfg.patch_size)
     for i in range(cfg.vision_layers):
-        x = vision_block(sd, cfg, i, x, rel_index)
+        x = vision_block(sd, cfg, i, x, rel_index, None if drop_path is None else drop_path[i])
     patches = layer_norm(x[:, 1:], sd["vision_encoder.fc_norm.weight"], sd["vision_encoder.fc_norm.bias"], 1e-6)
     full = torch.cat([patches.mean(dim=1, keepdim=True), patches], dim=1)
     if idx_to_group_img is None:
@@ -236,37 +242,44 @@ def frame_embeds(sd, cfg, frames):
 
 # --------------------------------------------------------------------------- text / fusion encoder
 
-def text_embeddings(sd, cfg, ids):
-    """word + type(0) + position, LayerNorm eps 1e-12 (dropout off). xbert.py:189-216."""
+def text_embeddings(sd, cfg, ids, drop=None):
+    """word + type(0) + position, LayerNorm eps 1e-12, dropout multiplier drop("emb") if given. xbert.py:189-216."""
     p = "text_encoder.bert.embeddings."
     L = ids.shape[1]
     e = sd[p + "word_embeddings.weight"][ids] + sd[p + "token_type_embeddings.weight"][0] \
         + sd[p + "position_embeddings.weight"][:L]
-    return layer_norm(e, sd[p + "LayerNorm.weight"], sd[p + "LayerNorm.bias"], 1e-12)
+    y = layer_norm(e, sd[p + "LayerNorm.weight"], sd[p + "LayerNorm.bias"], 1e-12)
+    return y * drop("emb") if drop is not None else y
 
 
-def bert_attention(sd, cfg, prefix, h, kv_src, add_mask):
-    """Self- or cross-attention sub-block with post-LN residual. xbert.py:322-431."""
+def bert_attention(sd, cfg, prefix, h, kv_src, add_mask, drop=None, site=""):
+    """Self- or cross-attention sub-block with post-LN residual. xbert.py:322-431.
+    drop(name) -> dropout multiplier tensor for site+".probs" / site+".out" (training mode) or None."""
     q = split_heads(linear(h, sd[prefix + "self.query.weight"], sd[prefix + "self.query.bias"]), cfg.heads)
     k = split_heads(linear(kv_src, sd[prefix + "self.key.weight"], sd[prefix + "self.key.bias"]), cfg.heads)
     v = split_heads(linear(kv_src, sd[prefix + "self.value.weight"], sd[prefix + "self.value.bias"]), cfg.heads)
-    ctx = merge_heads(attention_core(q, k, v, 1.0 / math.sqrt(cfg.hidden // cfg.heads), add_mask))
+    ctx = merge_heads(attention_core(q, k, v, 1.0 / math.sqrt(cfg.hidden // cfg.heads), add_mask,
+                                     drop(site + ".probs") if drop is not None else None))
     o = linear(ctx, sd[prefix + "output.dense.weight"], sd[prefix + "output.dense.bias"])
+    if drop is not None:
+        o = o * drop(site + ".out")
     return layer_norm(o + h, sd[prefix + "output.LayerNorm.weight"], sd[prefix + "output.LayerNorm.bias"], 1e-12)
 
 
-def bert_layer(sd, cfg, i, h, self_mask, enc, enc_mask):
+def bert_layer(sd, cfg, i, h, self_mask, enc, enc_mask, drop=None):
     """xbert.py:566-625: self-attn, [cross-attn iff i >= fusion_at and enc given], FFN."""
     p = "text_encoder.bert.encoder.layer.%d." % i
-    h = bert_attention(sd, cfg, p + "attention.", h, h, self_mask)
+    h = bert_attention(sd, cfg, p + "attention.", h, h, self_mask, drop, "L%d.self" % i)
     if i >= cfg.fusion_at and enc is not None:
-        h = bert_attention(sd, cfg, p + "crossattention.", h, enc, enc_mask)
+        h = bert_attention(sd, cfg, p + "crossattention.", h, enc, enc_mask, drop, "L%d.cross" % i)
     f = gelu(linear(h, sd[p + "intermediate.dense.weight"], sd[p + "intermediate.dense.bias"]))
     o = linear(f, sd[p + "output.dense.weight"], sd[p + "output.dense.bias"])
+    if drop is not None:
+        o = o * drop("L%d.ffn.out" % i)
     return layer_norm(o + h, sd[p + "output.LayerNorm.weight"], sd[p + "output.LayerNorm.bias"], 1e-12)
 
 
-def bert_encoder(sd, cfg, h, text_atts, enc=None, enc_atts=None, mode="multi_modal"):
+def bert_encoder(sd, cfg, h, text_atts, enc=None, enc_atts=None, mode="multi_modal", drop=None):
     """Layer range by mode (xbert.py:674-686); additive masks (xbert.py:1071-1072 and
     transformers 4.12.5 invert_attention_mask, fp32 branch)."""
     lo, hi = {"text": (0, cfg.fusion_at), "fusion": (cfg.fusion_at, cfg.text_layers),
@@ -276,7 +289,7 @@ def bert_encoder(sd, cfg, h, text_atts, enc=None, enc_atts=None, mode="multi_mod
     if enc is not None:
         enc_mask = (1.0 - enc_atts.to(h.dtype))[:, None, None, :] * -1e9
     for i in range(lo, hi):
-        h = bert_layer(sd, cfg, i, h, self_mask, enc, enc_mask)
+        h = bert_layer(sd, cfg, i, h, self_mask, enc, enc_mask, drop)
     return h
 
 

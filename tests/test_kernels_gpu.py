@@ -210,7 +210,7 @@ def test_layernorm(K, rows, D, period):
     dx, dxb = K.layernorm_bwd(dy.to(dev), x.to(dev), mean, rstd, w.to(dev), dw, db, dres=dres.to(dev), period=period,
                               want_bf16=True)
     assert relerr(dx[sel], xl.grad[sel] + dres[sel]) < 2e-5
-    assert relerr(dxb[sel], xl.grad[sel] + dres[sel]) < 6e-3
+    assert relerr(dxb[sel], xl.grad[sel]) < 6e-3          # bf16 copy = gradient of the LN input alone (feeds the producing linear)
     assert relerr(dw, wl.grad) < 2e-5 and relerr(db, bl.grad) < 2e-5
     dw2, db2, dcol = torch.zeros(D, device=dev), torch.zeros(D, device=dev), torch.zeros(D, device=dev)
     dx2, _ = K.layernorm_bwd(dy.to(dev), x.to(dev), mean, rstd, w.to(dev), dw2, db2, dcol=dcol, period=period)

@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libx2vlm_hip.so")
 
-P, I, L, F = C.c_void_p, C.c_int, C.c_long, C.c_float
+P, I, L, F, U = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_uint
 
 
 class AttnArgs(C.Structure):
@@ -22,19 +22,20 @@ class AttnArgs(C.Structure):
                                  "dq_bs", "dq_rs", "dk_bs", "dk_rs", "dv_bs", "dv_rs", "do_bs", "do_rs")] + \
                [(n, I) for n in ("B", "Bkv", "H", "Lq", "Lk")] + [("scale", F)] + \
                [("bias", P), ("bias_ld", I), ("biasT", P), ("biasT_ld", I), ("mask", P), ("mask_ld", I),
-                ("kv_idx", P), ("seq_off", P), ("seq_ids", P), ("ds_ld", I)]
+                ("kv_idx", P), ("seq_off", P), ("seq_ids", P), ("ds_ld", I),
+                ("drop_thr16", C.c_uint), ("drop_seed", C.c_uint), ("drop_scale", F)]
 
 
 # name -> argtypes (all return int: 0 ok, < 0 error; message via x2_last_error)
 _SIGS = {
-    "x2_gemm_nt": [P, P, P, I, I, I, I, I, I, P, P, P, I, P, I, I, I, P],
+    "x2_gemm_nt": [P, P, P, I, I, I, I, I, I, P, P, P, I, P, I, I, I, U, U, F, P, P],
     "x2_gemm_tn_grouped": [P, I, I, I, P],
     "x2_attn_fwd": [C.POINTER(AttnArgs), P],
     "x2_attn_bwd": [C.POINTER(AttnArgs), P],
-    "x2_layernorm_fwd": [P, P, P, P, P, P, P, I, I, F, I, P],
-    "x2_layernorm_bwd": [P, P, P, P, P, P, P, P, P, P, P, I, I, I, P],
+    "x2_layernorm_fwd": [P, P, P, P, P, P, P, I, I, F, I, U, U, F, P],
+    "x2_layernorm_bwd": [P, P, P, P, P, P, P, P, P, P, P, I, I, I, U, U, F, U, U, F, P],
     "x2_colsum_bf16": [P, P, I, I, I, P],
-    "x2_layerscale_bwd": [P, P, P, P, P, P, I, I, P],
+    "x2_layerscale_bwd": [P, P, P, P, P, P, P, I, I, P],
     "x2_cast_bf16": [P, P, L, P],
     "x2_cast_transpose_bf16": [P, P, P, I, I, I, P],
     "x2_patchify": [P, P, I, I, I, P],

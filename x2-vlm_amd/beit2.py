@@ -115,12 +115,24 @@ class VisionTransformer(nn.Module):
         sd = dict(self.named_parameters())
         return [sd[n] for n in vision_param_names(self.depth)]
 
+    def drop_path_scales(self, B, T, device, keep=None):
+        """Per-row keep/(1-p) factors of every block's two residual branches (timm drop_path: one Bernoulli per
+        sample and branch).  keep: optional (depth, 2, B) 0/1 tensor (tests); default draws it with torch.rand."""
+        rates = torch.tensor([b.drop_path_rate for b in self.blocks], device=device, dtype=torch.float32)
+        if keep is None:
+            keep = (torch.rand(self.depth, 2, B, device=device) >= rates.view(-1, 1, 1)).float()
+        scale = keep.to(device).float() / (1.0 - rates).view(-1, 1, 1)
+        rows = scale.repeat_interleave(T, dim=2)                       # (depth, 2, B*T)
+        return [(rows[i, 0].contiguous(), rows[i, 1].contiguous()) if float(self.blocks[i].drop_path_rate) > 0 else (None, None)
+                for i in range(self.depth)]
+
     def _run(self, x, pool_w=None):
+        dp = None
         if self.training and any(b.drop_path_rate > 0 for b in self.blocks):
-            raise NotImplementedError("stochastic depth (DropPath) is not implemented in the HIP path yet: "
-                                      "call .eval() or build with drop_path_rate=0")
+            T = self.patch_embed.num_patches + 1 if x.shape[-1] == self.patch_embed.img_size[0] else (x.shape[-1] // self.patch_embed.patch_size[0]) ** 2 + 1
+            dp = self.drop_path_scales(x.shape[0], T, x.device, getattr(self, "fixed_drop_path_keep", None))
         meta = dict(depth=self.depth, heads=self.num_heads, patch=self.patch_embed.patch_size[0], eps=self.eps,
-                    rel_index=self.blocks[0].attn.relative_position_index, pool_w=pool_w)
+                    rel_index=self.blocks[0].attn.relative_position_index, pool_w=pool_w, drop_path=dp)
         return VisionEncoderFn.apply(x.float(), meta, *self._params())
 
     def forward(self, x, idx_to_group_img=None, image_atts=None, output_attentions=None, output_hidden_states=None):

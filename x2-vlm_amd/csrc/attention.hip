@@ -32,6 +32,8 @@ struct AttnArgs {
   const int* kv_idx;                   // [B] query batch -> kv batch (null: identity)
   const int* seq_off; const int* seq_ids;   // CSR: kv batch -> query batches using it (null: identity)
   int ds_ld;                           // dS: [B][H][Lq][ds_ld]
+  DropSpec drop;                       // dropout on the attention probabilities (xbert.py:399), element index
+                                       // ((b*H + h)*Lq + q) * round_up(Lk,64) + key
 };
 
 // stage a [64 rows][64 d] bf16 tile (rows clamped to `nrows-1`) into LDS, chunk c of row r at c ^ (r & 7)
@@ -129,6 +131,15 @@ __global__ __launch_bounds__(64 * QW) void attn_fwd_kernel(AttnArgs a) {
       for (int r = 0; r < 4; ++r) { st[nt][r] = exp2f(st[nt][r] - m_new); rs += st[nt][r]; }
     l_i = l_i * alpha + group_sum(rs);
     m_i = m_new;
+    if (a.drop.thr16) {      // normalisation uses the undropped sum; only the P that multiplies V is dropped
+      const uint32_t e0 = (uint32_t)(((long)b * a.H + h) * a.Lq + q) * (uint32_t)((a.Lk + 63) & ~63) + (uint32_t)(kt * KT + g * 4);
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        float dm[4];
+        drop_mul4(a.drop, e0 + nt * 16, dm);
+        st[nt][0] *= dm[0]; st[nt][1] *= dm[1]; st[nt][2] *= dm[2]; st[nt][3] *= dm[3];
+      }
+    }
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) o[dt] *= alpha;
 #pragma unroll
@@ -199,6 +210,11 @@ __global__ __launch_bounds__(64 * QW) void attn_bwd_dq_kernel(AttnArgs a) {
       }
       const int key0 = kt * KT + nt * 16 + g * 4;
       s = add_bias_mask(s, a, h, b, q, key0, sc2);
+      if (a.drop.thr16) {
+        float dm[4];
+        drop_mul4(a.drop, (uint32_t)(((long)b * a.H + h) * a.Lq + q) * (uint32_t)((a.Lk + 63) & ~63) + (uint32_t)key0, dm);
+        dp[0] *= dm[0]; dp[1] *= dm[1]; dp[2] *= dm[2]; dp[3] *= dm[3];
+      }
 #pragma unroll
       for (int r = 0; r < 4; ++r) ds[nt][r] = exp2f(s[r] - lse) * (dp[r] - delta);
       if (a.dS && qvalid && key0 < a.ds_ld)
@@ -282,8 +298,11 @@ __global__ __launch_bounds__(64 * KW) void attn_bwd_dkv_kernel(AttnArgs a) {
         for (int r = 0; r < 4; ++r) {
           const bool ok = kvalid && (qq0 + r < a.Lq);
           const float pv = ok ? exp2f(s[r] * sc2 + bbv[r] * LOG2E + mk - lsv[r]) : 0.f;
-          p[t][r] = pv;
-          ds[t][r] = pv * (dp[r] - dlv[r]);
+          float dm = 1.f;
+          if (a.drop.thr16)
+            dm = drop_mul(a.drop, (uint32_t)(((long)b * a.H + h) * a.Lq + min(qq0 + r, a.Lq - 1)) * (uint32_t)((a.Lk + 63) & ~63) + (uint32_t)key);
+          p[t][r] = pv * dm;
+          ds[t][r] = pv * (dp[r] * dm - dlv[r]);
         }
       }
 #pragma unroll

@@ -29,6 +29,8 @@ struct GemmNT {
   int act;      // 0 none | 1 GELU (aux <- pre-activation) | 2 multiply by GELU'(aux)
   int out_f32;  // C is float (1) or bf16 (0)
   int group_m;  // tile raster: GROUP_M row-panels are walked column by column (L2 working set = GROUP_M A panels + a few B tiles)
+  DropSpec drop;            // hidden dropout on (acc + bias) before the residual add (xbert.py:429, 513)
+  const float* rowscale;    // [M] per-row factor before the residual add: DropPath keep/(1-p) per sample (beit2.py:206-207)
 };
 
 // logical tile id -> (row tile, col tile): XCD-contiguous chunks, inside a chunk groups of `gm` row panels
@@ -147,7 +149,13 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNT p) {
       } else if (p.aux) {
         *reinterpret_cast<u32x2*>(p.aux + (size_t)m * p.ldaux + n) = u32x2{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])};
       }
+      if (p.drop.thr16) {
+        float dm[4];
+        drop_mul4(p.drop, (uint32_t)m * (uint32_t)p.N + (uint32_t)n, dm);
+        v[0] *= dm[0]; v[1] *= dm[1]; v[2] *= dm[2]; v[3] *= dm[3];
+      }
       v[0] *= gg.x; v[1] *= gg.y; v[2] *= gg.z; v[3] *= gg.w;
+      if (p.rowscale) { const float rs_ = p.rowscale[m]; v[0] *= rs_; v[1] *= rs_; v[2] *= rs_; v[3] *= rs_; }
       if (p.resid) {
         const float4 rs = *reinterpret_cast<const float4*>(p.resid + (size_t)m * p.ldr + n);
         v[0] += rs.x; v[1] += rs.y; v[2] += rs.z; v[3] += rs.w;
@@ -171,15 +179,17 @@ extern "C" int x2_tune(int key, int value) {
 
 extern "C" int x2_gemm_nt(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
                           const float* bias, const float* gamma, const float* resid, int ldr, void* aux, int ldaux,
-                          int act, int out_f32, void* stream) {
+                          int act, int out_f32, unsigned drop_thr16, unsigned drop_seed, float drop_scale, const float* rowscale,
+                          void* stream) {
   X2_REQUIRE(M > 0 && N > 0 && K > 0, "x2_gemm_nt: empty problem M=%d N=%d K=%d", M, N, K);
+  X2_REQUIRE(drop_thr16 < 65536u, "x2_gemm_nt: drop_thr16=%u", drop_thr16);
   X2_REQUIRE(K % BK == 0, "x2_gemm_nt: K=%d must be a multiple of %d", K, BK);
   X2_REQUIRE(N % 4 == 0, "x2_gemm_nt: N=%d must be a multiple of 4", N);
   X2_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && ldc % 4 == 0, "x2_gemm_nt: leading dims must keep 16-byte rows");
   X2_REQUIRE(act == 0 || aux, "x2_gemm_nt: act=%d needs aux", act);
   X2_REQUIRE((!resid || ldr % 4 == 0) && (!aux || ldaux % 4 == 0), "x2_gemm_nt: ldr/ldaux alignment");
   GemmNT p{(const bf16_t*)A, (const bf16_t*)B, C, bias, gamma, resid, (bf16_t*)aux, M, N, K, lda, ldb, ldc, ldr, ldaux, act, out_f32,
-           g_tune[0] > 0 ? g_tune[0] : 8};
+           g_tune[0] > 0 ? g_tune[0] : 8, DropSpec{drop_thr16, drop_seed, drop_scale}, rowscale};
   const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
   hipLaunchKernelGGL(gemm_nt_kernel, dim3(tiles), dim3(256), GEMM_LDS_BYTES, (hipStream_t)stream, p);
   return x2_check_launch("x2_gemm_nt");

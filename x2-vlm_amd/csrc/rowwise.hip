@@ -16,7 +16,8 @@ __device__ __forceinline__ long remap_row(int r, int period) { return period > 0
 #define LN_MAXV 8   // float4 per lane: D <= 2048
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                             const float* __restrict__ bsh, bf16_t* yb, float* yf,
-                                                            float* mean, float* rstd, int rows, int D, float eps, int period) {
+                                                            float* mean, float* rstd, int rows, int D, float eps, int period,
+                                                            DropSpec drop) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= rows) return;
   const long gr = remap_row(row, period);
@@ -43,7 +44,12 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
     const int c = lane + i * 64;
     if (c < nv) {
       const float4 ww = *reinterpret_cast<const float4*>(w + c * 4), bb = *reinterpret_cast<const float4*>(bsh + c * 4);
-      const float4 o{(v[i].x - mu) * rs * ww.x + bb.x, (v[i].y - mu) * rs * ww.y + bb.y, (v[i].z - mu) * rs * ww.z + bb.z, (v[i].w - mu) * rs * ww.w + bb.w};
+      float4 o{(v[i].x - mu) * rs * ww.x + bb.x, (v[i].y - mu) * rs * ww.y + bb.y, (v[i].z - mu) * rs * ww.z + bb.z, (v[i].w - mu) * rs * ww.w + bb.w};
+      if (drop.thr16) {       // dropout on the LN output (BertEmbeddings, xbert.py:215)
+        float dm[4];
+        drop_mul4(drop, (uint32_t)gr * (uint32_t)D + (uint32_t)(c * 4), dm);
+        o.x *= dm[0]; o.y *= dm[1]; o.z *= dm[2]; o.w *= dm[3];
+      }
       if (yf) *reinterpret_cast<float4*>(yf + gr * D + c * 4) = o;
       if (yb) *reinterpret_cast<u32x2*>(yb + gr * D + c * 4) = u32x2{pack_bf16(o.x, o.y), pack_bf16(o.z, o.w)};
     }
@@ -51,10 +57,11 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
 }
 
 extern "C" int x2_layernorm_fwd(const float* x, const float* w, const float* b, void* y_bf16, float* y_f32, float* mean,
-                                float* rstd, int rows, int D, float eps, int period, void* stream) {
+                                float* rstd, int rows, int D, float eps, int period, unsigned drop_thr16, unsigned drop_seed,
+                                float drop_scale, void* stream) {
   X2_REQUIRE(rows > 0 && D > 0 && D % 4 == 0 && D <= 256 * LN_MAXV, "x2_layernorm_fwd: rows=%d D=%d (D%%4==0, D<=2048)", rows, D);
   hipLaunchKernelGGL(layernorm_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, w, b, (bf16_t*)y_bf16,
-                     y_f32, mean, rstd, rows, D, eps, period);
+                     y_f32, mean, rstd, rows, D, eps, period, DropSpec{drop_thr16, drop_seed, drop_scale});
   return x2_check_launch("x2_layernorm_fwd");
 }
 
@@ -67,7 +74,8 @@ extern "C" int x2_layernorm_fwd(const float* x, const float* w, const float* b, 
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
                                                             const float* __restrict__ w, const float* dres, float* dx, bf16_t* dxb,
-                                                            float* dw, float* db, float* dcol, int rows, int D, int period) {
+                                                            float* dw, float* db, float* dcol, int rows, int D, int period,
+                                                            DropSpec din, DropSpec dout) {
   extern __shared__ __attribute__((aligned(16))) float red[];      // [3][3 waves][D]
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int nv = D >> 2;
@@ -88,7 +96,13 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     for (int i = 0; i < LN_MAXV; ++i) {
       const int c = lane + i * 64;
       if (c < nv) {
-        const float4 d = *reinterpret_cast<const float4*>(dy + gr * D + c * 4), xv = *reinterpret_cast<const float4*>(x + gr * D + c * 4);
+        float4 d = *reinterpret_cast<const float4*>(dy + gr * D + c * 4);
+        const float4 xv = *reinterpret_cast<const float4*>(x + gr * D + c * 4);
+        if (din.thr16) {      // the forward dropped the LN OUTPUT: mask the incoming gradient the same way
+          float dm[4];
+          drop_mul4(din, (uint32_t)gr * (uint32_t)D + (uint32_t)(c * 4), dm);
+          d.x *= dm[0]; d.y *= dm[1]; d.z *= dm[2]; d.w *= dm[3];
+        }
         xh[i] = float4{(xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs};
         g[i] = float4{d.x * ww[i].x, d.y * ww[i].y, d.z * ww[i].z, d.w * ww[i].w};
         s1 += g[i].x + g[i].y + g[i].z + g[i].w;
@@ -103,10 +117,18 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
       const int c = lane + i * 64;
       if (c < nv) {
         float4 o{rs * (g[i].x - m1 - xh[i].x * m2), rs * (g[i].y - m1 - xh[i].y * m2), rs * (g[i].z - m1 - xh[i].z * m2), rs * (g[i].w - m1 - xh[i].w * m2)};
-        ac[i].x += o.x; ac[i].y += o.y; ac[i].z += o.z; ac[i].w += o.w;
+        // the producing linear's output was dropped before the residual add: its gradient (bf16 copy, bias sums)
+        // carries that mask, the residual branch (dx) does not
+        float4 om = o;
+        if (dout.thr16) {
+          float dm[4];
+          drop_mul4(dout, (uint32_t)gr * (uint32_t)D + (uint32_t)(c * 4), dm);
+          om.x *= dm[0]; om.y *= dm[1]; om.z *= dm[2]; om.w *= dm[3];
+        }
+        ac[i].x += om.x; ac[i].y += om.y; ac[i].z += om.z; ac[i].w += om.w;
         if (dres) { const float4 rr = *reinterpret_cast<const float4*>(dres + gr * D + c * 4); o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w; }
         if (dx) *reinterpret_cast<float4*>(dx + gr * D + c * 4) = o;
-        if (dxb) *reinterpret_cast<u32x2*>(dxb + gr * D + c * 4) = u32x2{pack_bf16(o.x, o.y), pack_bf16(o.z, o.w)};
+        if (dxb) *reinterpret_cast<u32x2*>(dxb + gr * D + c * 4) = u32x2{pack_bf16(om.x, om.y), pack_bf16(om.z, om.w)};
       }
     }
   }
@@ -146,12 +168,15 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
 
 extern "C" int x2_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* w,
                                 const float* dres, float* dx, void* dx_bf16, float* dw, float* db, float* dcol, int rows, int D,
-                                int period, void* stream) {
+                                int period, unsigned in_thr16, unsigned in_seed, float in_scale, unsigned out_thr16,
+                                unsigned out_seed, float out_scale, void* stream) {
   X2_REQUIRE(rows > 0 && D > 0 && D % 4 == 0 && D <= 256 * LN_MAXV, "x2_layernorm_bwd: rows=%d D=%d", rows, D);
   X2_REQUIRE(dw && db, "x2_layernorm_bwd: dw/db (accumulated with atomics) required");
   X2_REQUIRE(!(dcol && dres), "x2_layernorm_bwd: dcol sums the LN-input gradient, which excludes dres");
+  X2_REQUIRE(!(out_thr16 && dres), "x2_layernorm_bwd: an output mask applies to the bf16 copy, which excludes dres");
   hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((rows + LNB_ROWS - 1) / LNB_ROWS), dim3(256), 9 * D * sizeof(float), (hipStream_t)stream, dy,
-                     x, mean, rstd, w, dres, dx, (bf16_t*)dx_bf16, dw, db, dcol, rows, D, period);
+                     x, mean, rstd, w, dres, dx, (bf16_t*)dx_bf16, dw, db, dcol, rows, D, period, DropSpec{in_thr16, in_seed, in_scale},
+                     DropSpec{out_thr16, out_seed, out_scale});
   return x2_check_launch("x2_layernorm_bwd");
 }
 
@@ -199,7 +224,7 @@ extern "C" int x2_colsum_bf16(const void* y, float* out, int M, int N, int ld, v
 #define LS_ROWS 32
 __global__ __launch_bounds__(256) void layerscale_bwd_kernel(const float* __restrict__ dx, const bf16_t* __restrict__ u,
                                                              const float* __restrict__ gamma, bf16_t* du, float* dgamma,
-                                                             float* dbias, int M, int D) {
+                                                             float* dbias, const float* __restrict__ rowscale, int M, int D) {
   __shared__ float red[2][3][256];
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const int c0 = blockIdx.y * 256 + tx * 4;
@@ -208,7 +233,8 @@ __global__ __launch_bounds__(256) void layerscale_bwd_kernel(const float* __rest
   if (c0 < D) {
     const float4 gm = *reinterpret_cast<const float4*>(gamma + c0);
     for (int r = r0 + ty; r < r1; r += 4) {
-      const float4 d = *reinterpret_cast<const float4*>(dx + (long)r * D + c0);
+      float4 d = *reinterpret_cast<const float4*>(dx + (long)r * D + c0);
+      if (rowscale) { const float rs_ = rowscale[r]; d.x *= rs_; d.y *= rs_; d.z *= rs_; d.w *= rs_; }   // DropPath keep/(1-p)
       const u32x2 uu = *reinterpret_cast<const u32x2*>(u + (long)r * D + c0);
       const float o0 = d.x * gm.x, o1 = d.y * gm.y, o2 = d.z * gm.z, o3 = d.w * gm.w;
       *reinterpret_cast<u32x2*>(du + (long)r * D + c0) = u32x2{pack_bf16(o0, o1), pack_bf16(o2, o3)};
@@ -229,11 +255,11 @@ __global__ __launch_bounds__(256) void layerscale_bwd_kernel(const float* __rest
     }
   }
 }
-extern "C" int x2_layerscale_bwd(const float* dx, const void* u, const float* gamma, void* du, float* dgamma, float* dbias, int M,
-                                 int D, void* stream) {
+extern "C" int x2_layerscale_bwd(const float* dx, const void* u, const float* gamma, void* du, float* dgamma, float* dbias,
+                                 const float* rowscale, int M, int D, void* stream) {
   X2_REQUIRE(M > 0 && D > 0 && D % 4 == 0, "x2_layerscale_bwd: M=%d D=%d", M, D);
   hipLaunchKernelGGL(layerscale_bwd_kernel, dim3((M + LS_ROWS - 1) / LS_ROWS, (D + 255) / 256), dim3(256), 0, (hipStream_t)stream, dx,
-                     (const bf16_t*)u, gamma, (bf16_t*)du, dgamma, dbias, M, D);
+                     (const bf16_t*)u, gamma, (bf16_t*)du, dgamma, dbias, rowscale, M, D);
   return x2_check_launch("x2_layerscale_bwd");
 }
 

@@ -53,6 +53,29 @@ __device__ __forceinline__ float dgelu_f(float x) {
   return 0.5f * (1.0f + erf_from_exp(z, e)) + x * 0.3989422804014327f * e;
 }
 
+// ---- counter-based dropout: keep(element) is a pure function of (site seed, element index), so the backward
+// regenerates the forward's mask instead of storing it.  One 32-bit hash (lowbias32) yields two 16-bit uniforms:
+// elements 2k and 2k+1 share a hash.  Dropped when u16 < thr16 (thr16 = round(p * 65536)); thr16 == 0: off.
+// Mirrored bit-for-bit by kernels.dropout_keep() on the host for the parity tests.
+struct DropSpec { uint32_t thr16; uint32_t seed; float scale; };
+__device__ __forceinline__ uint32_t x2_hash(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+  return x;
+}
+__device__ __forceinline__ float drop_mul(const DropSpec& d, uint32_t e) {          // one element
+  const uint32_t h = x2_hash((e >> 1) ^ d.seed);
+  const uint32_t u = (e & 1u) ? (h >> 16) : (h & 0xffffu);
+  return u >= d.thr16 ? d.scale : 0.f;
+}
+// four consecutive elements e0..e0+3 (e0 % 4 == 0): two hashes
+__device__ __forceinline__ void drop_mul4(const DropSpec& d, uint32_t e0, float m[4]) {
+  const uint32_t h0 = x2_hash((e0 >> 1) ^ d.seed), h1 = x2_hash(((e0 >> 1) + 1u) ^ d.seed);
+  m[0] = (h0 & 0xffffu) >= d.thr16 ? d.scale : 0.f;
+  m[1] = (h0 >> 16) >= d.thr16 ? d.scale : 0.f;
+  m[2] = (h1 & 0xffffu) >= d.thr16 ? d.scale : 0.f;
+  m[3] = (h1 >> 16) >= d.thr16 ? d.scale : 0.f;
+}
+
 // ---- wave64 reductions ----
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -137,7 +137,9 @@ class VisionEncoderFn(torch.autograd.Function):
     """image (B,3,R,R) fp32 -> tokens (B,1+P,D) fp32: patch embed, pre-LN blocks with rel-pos-bias
     attention and layer scale, fc_norm over patches, token 0 = (weighted) mean of patches.
 
-    meta: dict(depth, heads, patch, eps, rel_index[int64 (T,T)], pool_w [B,P] fp32 or None)."""
+    meta: dict(depth, heads, patch, eps, rel_index[int64 (T,T)], pool_w [B,P] fp32 or None,
+               drop_path: None or list per block of (rs1, rs2): fp32 [B*T] per-row keep/(1-p) factors of the
+               attention / MLP branch (stochastic depth, beit2.py:205-207))."""
 
     @staticmethod
     def forward(ctx, image, meta, *params):
@@ -154,8 +156,10 @@ class VisionEncoderFn(torch.autograd.Function):
         patch = K.gemm_nt(cols, wpe, bias=p["patch_embed.proj.bias"], out_dtype=F32)
         x = K.assemble_tokens(patch, p["cls_token"].reshape(-1), B, P_).view(M, D)
         saved = []
+        dpath = meta.get("drop_path")
         for i in range(meta["depth"]):
             b = "blocks.%d." % i
+            rs1, rs2 = dpath[i] if dpath is not None else (None, None)
             h1, _, mean1, rstd1 = K.layernorm_fwd(x, p[b + "norm1.weight"], p[b + "norm1.bias"], meta["eps"])
             wqkv, _ = BANK.linear(p[b + "attn.qkv.weight"])
             qkv_bias = torch.cat([p[b + "attn.q_bias"].detach(), torch.zeros(D, device=x.device, dtype=F32),
@@ -168,14 +172,16 @@ class VisionEncoderFn(torch.autograd.Function):
                        K.view3(att, B, T), lse, bias=bias)
             wproj, _ = BANK.linear(p[b + "attn.proj.weight"])
             aux1 = torch.empty(M, D, device=x.device, dtype=BF16)
-            x1 = K.gemm_nt(att, wproj, bias=p[b + "attn.proj.bias"], gamma=p[b + "gamma_1"], resid=x, aux=aux1, out_dtype=F32)
+            x1 = K.gemm_nt(att, wproj, bias=p[b + "attn.proj.bias"], gamma=p[b + "gamma_1"], resid=x, aux=aux1, out_dtype=F32,
+                           rowscale=rs1)
             h2, _, mean2, rstd2 = K.layernorm_fwd(x1, p[b + "norm2.weight"], p[b + "norm2.bias"], meta["eps"])
             w1, _ = BANK.linear(p[b + "mlp.fc1.weight"])
             w2, _ = BANK.linear(p[b + "mlp.fc2.weight"])
             pre = torch.empty(M, w1.shape[0], device=x.device, dtype=BF16)
             act = K.gemm_nt(h2, w1, bias=p[b + "mlp.fc1.bias"], aux=pre, act=1)
             aux2 = torch.empty(M, D, device=x.device, dtype=BF16)
-            x2 = K.gemm_nt(act, w2, bias=p[b + "mlp.fc2.bias"], gamma=p[b + "gamma_2"], resid=x1, aux=aux2, out_dtype=F32)
+            x2 = K.gemm_nt(act, w2, bias=p[b + "mlp.fc2.bias"], gamma=p[b + "gamma_2"], resid=x1, aux=aux2, out_dtype=F32,
+                           rowscale=rs2)
             saved.append((x, h1, mean1, rstd1, qkv, bias, biasT, att, lse, aux1, x1, h2, mean2, rstd2, pre, act, aux2))
             x = x2
         out = torch.empty(B, T, D, device=x.device, dtype=F32)
@@ -207,8 +213,10 @@ class VisionEncoderFn(torch.autograd.Function):
                                 period=P_)
         dS = torch.empty(B, H, T, K.round_up(T, 64), device=dev, dtype=BF16)
         F4 = p["blocks.0.mlp.fc1.weight"].shape[0]
+        dpath = meta.get("drop_path")
         for i in reversed(range(meta["depth"])):
             b = "blocks.%d." % i
+            rs1, rs2 = dpath[i] if dpath is not None else (None, None)
             (x, h1, mean1, rstd1, qkv, bias, biasT, att, lse, aux1, x1, h2, mean2, rstd2, pre, act, aux2) = ctx.saved[i]
             ctx.saved[i] = None
             G = Grads(dev, [("gamma_1", (D,), True), ("gamma_2", (D,), True), ("norm1.weight", (D,), True), ("norm1.bias", (D,), True),
@@ -221,12 +229,12 @@ class VisionEncoderFn(torch.autograd.Function):
             _, w1T = BANK.linear(p[b + "mlp.fc1.weight"])
             _, wprojT = BANK.linear(p[b + "attn.proj.weight"])
             _, wqkvT = BANK.linear(p[b + "attn.qkv.weight"])
-            dy2 = K.layerscale_bwd(dx, aux2, p[b + "gamma_2"], G["gamma_2"], G["mlp.fc2.bias"])
+            dy2 = K.layerscale_bwd(dx, aux2, p[b + "gamma_2"], G["gamma_2"], G["mlp.fc2.bias"], rowscale=rs2)
             dpre = K.gemm_nt(dy2, w2T, aux=pre, act=2)
             K.colsum_bf16(dpre, G["mlp.fc1.bias"])
             dh2 = K.gemm_nt(dpre, w1T, out_dtype=F32)
             dx1, _ = K.layernorm_bwd(dh2, x1, mean2, rstd2, p[b + "norm2.weight"], G["norm2.weight"], G["norm2.bias"], dres=dx)
-            dy1 = K.layerscale_bwd(dx1, aux1, p[b + "gamma_1"], G["gamma_1"], G["attn.proj.bias"])
+            dy1 = K.layerscale_bwd(dx1, aux1, p[b + "gamma_1"], G["gamma_1"], G["attn.proj.bias"], rowscale=rs1)
             datt = K.gemm_nt(dy1, wprojT)
             dqkv = torch.empty_like(qkv)
             delta = torch.empty_like(lse)
@@ -282,7 +290,17 @@ class BertLayersFn(torch.autograd.Function):
     enc: (Bi,T,Dv) fp32 image tokens or None; sequence s attends image kv_idx[s] (several text rows
     may share one image: K/V are projected once per image per layer).
     meta: dict(lo, hi, fusion_at, heads, eps, self_mask [S,Lp] fp32 additive, enc_mask [S,Tp],
-               kv_idx/seq_off/seq_ids int32 or None)."""
+               kv_idx/seq_off/seq_ids int32 or None,
+               drop: None or dict(seed, p_hidden, p_attn): training-mode dropout (xbert.py:399, 429, 513), masks are
+               regenerated in the backward from (seed, site = 8*layer + {0 self probs, 1 self out, 2 cross probs,
+               3 cross out, 4 ffn out}, element index))."""
+
+    @staticmethod
+    def _drop(meta, layer, kind):
+        d = meta.get("drop")
+        if not d:
+            return K.NO_DROP
+        return K.dropout_spec(d["p_attn"] if kind in (0, 2) else d["p_hidden"], d["seed"], 8 * layer + kind)
 
     @staticmethod
     def forward(ctx, hidden, enc, meta, *params):
@@ -309,10 +327,11 @@ class BertLayersFn(torch.autograd.Function):
             qkv = K.gemm_nt(hb, wqkv, bias=bqkv)
             att = torch.empty(M, Hd, device=dev, dtype=BF16)
             lse = torch.empty(S * H * L, device=dev, dtype=F32)
+            dr = BertLayersFn._drop
             K.attn_fwd(K.view3(qkv, S, L, 0), K.view3(qkv, S, L, Hd), K.view3(qkv, S, L, 2 * Hd), S, S, H, L, L, scale,
-                       K.view3(att, S, L), lse, mask=meta["self_mask"])
+                       K.view3(att, S, L), lse, mask=meta["self_mask"], drop=dr(meta, i, 0))
             wo, _ = BANK.linear(p[a + "output.dense.weight"])
-            s1 = K.gemm_nt(att, wo, bias=p[a + "output.dense.bias"], resid=h, out_dtype=F32)
+            s1 = K.gemm_nt(att, wo, bias=p[a + "output.dense.bias"], resid=h, out_dtype=F32, drop=dr(meta, i, 1))
             h1b, h1, m1, r1 = K.layernorm_fwd(s1, p[a + "output.LayerNorm.weight"], p[a + "output.LayerNorm.bias"], eps, want_f32=True)
             cr = None
             h2b, h2 = h1b, h1
@@ -326,16 +345,16 @@ class BertLayersFn(torch.autograd.Function):
                 att2 = torch.empty(M, Hd, device=dev, dtype=BF16)
                 lse2 = torch.empty(S * H * L, device=dev, dtype=F32)
                 K.attn_fwd(K.view3(q2, S, L), K.view3(kv, Bi, T, 0), K.view3(kv, Bi, T, Hd), S, Bi, H, L, T, scale,
-                           K.view3(att2, S, L), lse2, mask=meta["enc_mask"], kv_idx=meta["kv_idx"])
+                           K.view3(att2, S, L), lse2, mask=meta["enc_mask"], kv_idx=meta["kv_idx"], drop=dr(meta, i, 2))
                 wo2, _ = BANK.linear(p[c + "output.dense.weight"])
-                s2 = K.gemm_nt(att2, wo2, bias=p[c + "output.dense.bias"], resid=h1, out_dtype=F32)
+                s2 = K.gemm_nt(att2, wo2, bias=p[c + "output.dense.bias"], resid=h1, out_dtype=F32, drop=dr(meta, i, 3))
                 h2b, h2, m2, r2 = K.layernorm_fwd(s2, p[c + "output.LayerNorm.weight"], p[c + "output.LayerNorm.bias"], eps, want_f32=True)
                 cr = (q2, kv, att2, lse2, s2, m2, r2)
             wi, _ = BANK.linear(p[b + "intermediate.dense.weight"])
             wout, _ = BANK.linear(p[b + "output.dense.weight"])
             pre = torch.empty(M, wi.shape[0], device=dev, dtype=BF16)
             act = K.gemm_nt(h2b, wi, bias=p[b + "intermediate.dense.bias"], aux=pre, act=1)
-            s3 = K.gemm_nt(act, wout, bias=p[b + "output.dense.bias"], resid=h2, out_dtype=F32)
+            s3 = K.gemm_nt(act, wout, bias=p[b + "output.dense.bias"], resid=h2, out_dtype=F32, drop=dr(meta, i, 4))
             h3b, h3, m3, r3 = K.layernorm_fwd(s3, p[b + "output.LayerNorm.weight"], p[b + "output.LayerNorm.bias"], eps, want_f32=True)
             saved.append((hb, qkv, att, lse, s1, m1, r1, h1b, cr, h2b, pre, act, s3, m3, r3))
             h, hb = h3, h3b
@@ -377,7 +396,8 @@ class BertLayersFn(torch.autograd.Function):
             G = Grads(dev, spec, key=("bert", id(p[a + "self.query.weight"])))
             tn = []
             ds3, ds3b = K.layernorm_bwd(dh, s3, m3, r3, p[b + "output.LayerNorm.weight"], G["output.LayerNorm.weight"],
-                                        G["output.LayerNorm.bias"], dcol=G["output.dense.bias"], want_bf16=True)
+                                        G["output.LayerNorm.bias"], dcol=G["output.dense.bias"], want_bf16=True,
+                                        drop_out=BertLayersFn._drop(meta, i, 4))
             _, woutT = BANK.linear(p[b + "output.dense.weight"])
             _, wiT = BANK.linear(p[b + "intermediate.dense.weight"])
             dpre = K.gemm_nt(ds3b, woutT, aux=pre, act=2)
@@ -389,7 +409,7 @@ class BertLayersFn(torch.autograd.Function):
                 q2, kv, att2, lse2, s2, m2, r2 = cr
                 ds2, ds2b = K.layernorm_bwd(dh2, s2, m2, r2, p[c + "output.LayerNorm.weight"], G["crossattention.output.LayerNorm.weight"],
                                             G["crossattention.output.LayerNorm.bias"], dcol=G["crossattention.output.dense.bias"],
-                                            want_bf16=True)
+                                            want_bf16=True, drop_out=BertLayersFn._drop(meta, i, 3))
                 _, wo2T = BANK.linear(p[c + "output.dense.weight"])
                 datt2 = K.gemm_nt(ds2b, wo2T)
                 dq2 = torch.empty_like(q2)
@@ -397,7 +417,8 @@ class BertLayersFn(torch.autograd.Function):
                 delta2 = torch.empty_like(lse2)
                 K.attn_bwd(K.view3(q2, S, L), K.view3(kv, Bi, T, 0), K.view3(kv, Bi, T, Hd), K.view3(att2, S, L), K.view3(datt2, S, L),
                            S, Bi, H, L, T, scale, lse2, delta2, K.view3(dq2, S, L), K.view3(dkv, Bi, T, 0), K.view3(dkv, Bi, T, Hd),
-                           mask=meta["enc_mask"], kv_idx=meta["kv_idx"], seq_off=meta["seq_off"], seq_ids=meta["seq_ids"])
+                           mask=meta["enc_mask"], kv_idx=meta["kv_idx"], seq_off=meta["seq_off"], seq_ids=meta["seq_ids"],
+                           drop=BertLayersFn._drop(meta, i, 2))
                 K.colsum_bf16(dq2, G["crossattention.self.query.bias"])
                 K.colsum_bf16(dkv, G["c.kv_bias"])
                 G.alias("crossattention.self.key.bias", G["c.kv_bias"][:Hd])
@@ -413,14 +434,15 @@ class BertLayersFn(torch.autograd.Function):
             else:
                 dh1 = dh2
             ds1, ds1b = K.layernorm_bwd(dh1, s1, m1, r1, p[a + "output.LayerNorm.weight"], G["attention.output.LayerNorm.weight"],
-                                        G["attention.output.LayerNorm.bias"], dcol=G["attention.output.dense.bias"], want_bf16=True)
+                                        G["attention.output.LayerNorm.bias"], dcol=G["attention.output.dense.bias"], want_bf16=True,
+                                        drop_out=BertLayersFn._drop(meta, i, 1))
             _, woT = BANK.linear(p[a + "output.dense.weight"])
             datt = K.gemm_nt(ds1b, woT)
             dqkv = torch.empty_like(qkv)
             delta = torch.empty_like(lse)
             K.attn_bwd(K.view3(qkv, S, L, 0), K.view3(qkv, S, L, Hd), K.view3(qkv, S, L, 2 * Hd), K.view3(att, S, L), K.view3(datt, S, L),
                        S, S, H, L, L, scale, lse, delta, K.view3(dqkv, S, L, 0), K.view3(dqkv, S, L, Hd), K.view3(dqkv, S, L, 2 * Hd),
-                       mask=meta["self_mask"])
+                       mask=meta["self_mask"], drop=BertLayersFn._drop(meta, i, 0))
             K.colsum_bf16(dqkv, G["a.qkv_bias"])
             for k3, nm in enumerate(("query", "key", "value")):
                 G.alias("attention.self.%s.bias" % nm, G["a.qkv_bias"][k3 * Hd:(k3 + 1) * Hd])
@@ -440,15 +462,17 @@ class BertLayersFn(torch.autograd.Function):
 # ----------------------------------------------------------------------------- embeddings
 
 class EmbeddingsFn(torch.autograd.Function):
-    """ids (S,L) -> LayerNorm(word + position + type0) (S,L,Hd) fp32.  xbert.py:189-216."""
+    """ids (S,L) -> dropout(LayerNorm(word + position + type0)) (S,L,Hd) fp32.  xbert.py:189-216.
+    drop: kernels.dropout_spec(...) triple or kernels.NO_DROP."""
 
     @staticmethod
-    def forward(ctx, ids, eps, word, pos, typ, lnw, lnb):
+    def forward(ctx, ids, eps, drop, word, pos, typ, lnw, lnb):
         S, L = ids.shape
         ids = ids.contiguous()
         e = K.embed_fwd(ids, word.detach(), pos.detach(), typ.detach())
-        _, y, mean, rstd = K.layernorm_fwd(e, lnw, lnb, eps, want_bf16=False, want_f32=True)
+        _, y, mean, rstd = K.layernorm_fwd(e, lnw, lnb, eps, want_bf16=False, want_f32=True, drop=drop)
         ctx.save_for_backward(ids, e, mean, rstd, word, pos, typ, lnw)
+        ctx.drop = drop
         return y.view(S, L, -1)
 
     @staticmethod
@@ -456,10 +480,10 @@ class EmbeddingsFn(torch.autograd.Function):
         ids, e, mean, rstd, word, pos, typ, lnw = ctx.saved_tensors
         small = torch.zeros(2 * lnw.numel(), device=dy.device, dtype=F32)
         dw, db = small[:lnw.numel()], small[lnw.numel():]
-        de, _ = K.layernorm_bwd(dy.contiguous().view(e.shape), e, mean, rstd, lnw, dw, db)
+        de, _ = K.layernorm_bwd(dy.contiguous().view(e.shape), e, mean, rstd, lnw, dw, db, drop_in=ctx.drop)
         dword, dpos, dtyp = torch.zeros_like(word), torch.zeros_like(pos), torch.zeros_like(typ)
         K.embed_bwd(ids, de, dword, dpos, dtyp)
-        return None, None, dword, dpos, dtyp, dw, db
+        return None, None, None, dword, dpos, dtyp, dw, db
 
 
 # ----------------------------------------------------------------------------- MLM head + loss

@@ -32,6 +32,38 @@ class _timed:
             GEMM_TIMER.append((self.a, self.b, self.flops))
 
 
+NO_DROP = (0, 0, 1.0)
+
+
+def dropout_spec(p, seed, site):
+    """(thr16, site seed, scale) for the kernels' counter-based dropout: element e is dropped iff the 16-bit
+    uniform hashed from (e, site seed) is < thr16 = round(p * 65536); survivors are scaled by 1/(1-p)."""
+    if p <= 0.0:
+        return NO_DROP
+    return (int(round(p * 65536.0)), _hash32_int((int(seed) * 0x9E3779B1 + int(site) * 0x85EBCA77 + 0x165667B1) & 0xFFFFFFFF),
+            1.0 / (1.0 - p))
+
+
+def _hash32_int(x):
+    x &= 0xFFFFFFFF
+    x ^= x >> 16; x = (x * 0x7feb352d) & 0xFFFFFFFF
+    x ^= x >> 15; x = (x * 0x846ca68b) & 0xFFFFFFFF
+    x ^= x >> 16
+    return x
+
+
+def dropout_keep(spec, index):
+    """Host mirror of csrc/x2_common.h drop_mul(): multiplier (0 or scale) for int64 element indices."""
+    thr, seed, scale = spec
+    e = index.to(torch.int64) & 0xFFFFFFFF
+    x = ((e >> 1) ^ seed) & 0xFFFFFFFF
+    x = x ^ (x >> 16); x = (x * 0x7feb352d) & 0xFFFFFFFF
+    x = x ^ (x >> 15); x = (x * 0x846ca68b) & 0xFFFFFFFF
+    x = x ^ (x >> 16)
+    u = torch.where((e & 1) == 1, x >> 16, x & 0xFFFF)
+    return (u >= thr).to(torch.float32) * scale
+
+
 def _rows(t):
     assert t.dim() == 2 and t.stride(1) == 1, "expected a row-major 2-D tensor (got strides %s)" % (t.stride(),)
     return t.stride(0)
@@ -43,9 +75,11 @@ def round_up(x, m):
 
 # ----------------------------------------------------------------------------- GEMMs
 
-def gemm_nt(A, B, *, bias=None, gamma=None, resid=None, aux=None, act=0, out=None, out_dtype=BF16):
+def gemm_nt(A, B, *, bias=None, gamma=None, resid=None, aux=None, act=0, out=None, out_dtype=BF16, drop=NO_DROP,
+            rowscale=None):
     """out[M,N] = epilogue(A[M,K] @ B[N,K]^T).  act: 0 none (aux, if given, receives acc+bias),
-    1 GELU (aux receives the pre-activation), 2 multiply by GELU'(aux).  Then *gamma, +resid."""
+    1 GELU (aux receives the pre-activation), 2 multiply by GELU'(aux).  Then dropout(drop), *gamma,
+    *rowscale[m], +resid."""
     assert A.dtype == BF16 and B.dtype == BF16 and A.shape[1] == B.shape[1]
     M, K = A.shape
     N = B.shape[0]
@@ -56,10 +90,11 @@ def gemm_nt(A, B, *, bias=None, gamma=None, resid=None, aux=None, act=0, out=Non
         assert t is None or (t.dtype == F32 and t.numel() == N and t.is_contiguous())
     assert resid is None or (resid.dtype == F32 and resid.shape == (M, N))
     assert aux is None or (aux.dtype == BF16 and aux.shape == (M, N))
+    assert rowscale is None or (rowscale.dtype == F32 and rowscale.numel() == M and rowscale.is_contiguous())
     with _timed(2.0 * M * N * K):
         call("x2_gemm_nt", ptr(A), ptr(B), ptr(out), M, N, K, _rows(A), _rows(B), _rows(out), ptr(bias), ptr(gamma),
              ptr(resid), _rows(resid) if resid is not None else 0, ptr(aux), _rows(aux) if aux is not None else 0,
-             act, 1 if out.dtype == F32 else 0)
+             act, 1 if out.dtype == F32 else 0, drop[0], drop[1], drop[2], ptr(rowscale))
     return out
 
 
@@ -85,13 +120,14 @@ def gemm_tn_grouped(problems, accumulate=False, split=1):
 # ----------------------------------------------------------------------------- attention
 
 def _attn_args(q, k, v, B, Bkv, H, Lq, Lk, scale, bias=None, biasT=None, mask=None, kv_idx=None, seq_off=None,
-               seq_ids=None):
+               seq_ids=None, drop=NO_DROP):
     """q/k/v: (tensor, batch_stride, row_stride) views in elements; data pointer already at head 0."""
     a = AttnArgs()
     a.Q, a.q_bs, a.q_rs = q
     a.K, a.k_bs, a.k_rs = k
     a.V, a.v_bs, a.v_rs = v
     a.B, a.Bkv, a.H, a.Lq, a.Lk, a.scale = B, Bkv, H, Lq, Lk, scale
+    a.drop_thr16, a.drop_seed, a.drop_scale = drop
     if bias is not None:
         assert bias.dtype == F32 and bias.dim() == 3 and bias.is_contiguous()
         a.bias, a.bias_ld = bias.data_ptr(), bias.shape[2]
@@ -140,7 +176,8 @@ def attn_bwd(q, k, v, o, do, B, Bkv, H, Lq, Lk, scale, lse, delta, dq, dk, dv, d
 
 # ----------------------------------------------------------------------------- row-wise
 
-def layernorm_fwd(x, w, b, eps, *, rows=None, period=0, want_bf16=True, want_f32=False, y_bf16=None, y_f32=None):
+def layernorm_fwd(x, w, b, eps, *, rows=None, period=0, want_bf16=True, want_f32=False, y_bf16=None, y_f32=None,
+                  drop=NO_DROP):
     """x fp32 [R_total, D]; with period>0 only rows r + r//period + 1 (token 0 of each sample skipped)."""
     assert x.dtype == F32 and x.is_contiguous()
     D = x.shape[-1]
@@ -152,11 +189,13 @@ def layernorm_fwd(x, w, b, eps, *, rows=None, period=0, want_bf16=True, want_f32
         y_f32 = torch.empty_like(x2)
     mean = torch.empty(R, device=x.device, dtype=F32)
     rstd = torch.empty(R, device=x.device, dtype=F32)
-    call("x2_layernorm_fwd", ptr(x2), ptr(w), ptr(b), ptr(y_bf16), ptr(y_f32), ptr(mean), ptr(rstd), R, D, eps, period)
+    call("x2_layernorm_fwd", ptr(x2), ptr(w), ptr(b), ptr(y_bf16), ptr(y_f32), ptr(mean), ptr(rstd), R, D, eps, period,
+         drop[0], drop[1], drop[2])
     return y_bf16, y_f32, mean, rstd
 
 
-def layernorm_bwd(dy, x, mean, rstd, w, dw, db, *, dres=None, dcol=None, period=0, want_f32=True, want_bf16=False, dx=None):
+def layernorm_bwd(dy, x, mean, rstd, w, dw, db, *, dres=None, dcol=None, period=0, want_f32=True, want_bf16=False, dx=None,
+                  drop_in=NO_DROP, drop_out=NO_DROP):
     """dcol (fp32 [D], accumulated): column sums of the LN-input gradient = bias gradient of the producing linear."""
     assert dy.dtype == F32 and x.dtype == F32 and dy.is_contiguous() and x.is_contiguous()
     D = x.shape[-1]
@@ -165,7 +204,7 @@ def layernorm_bwd(dy, x, mean, rstd, w, dw, db, *, dres=None, dcol=None, period=
         dx = torch.empty_like(x) if period == 0 else torch.zeros_like(x)
     dxb = torch.empty(x.shape, device=x.device, dtype=BF16) if want_bf16 else None
     call("x2_layernorm_bwd", ptr(dy), ptr(x), ptr(mean), ptr(rstd), ptr(w), ptr(dres), ptr(dx), ptr(dxb), ptr(dw), ptr(db),
-         ptr(dcol), R, D, period)
+         ptr(dcol), R, D, period, drop_in[0], drop_in[1], drop_in[2], drop_out[0], drop_out[1], drop_out[2])
     return dx, dxb
 
 
@@ -173,9 +212,9 @@ def colsum_bf16(y, out):
     call("x2_colsum_bf16", ptr(y), ptr(out), y.shape[0], y.shape[1], _rows(y))
 
 
-def layerscale_bwd(dx, u, gamma, dgamma, dbias):
+def layerscale_bwd(dx, u, gamma, dgamma, dbias, rowscale=None):
     du = torch.empty_like(u)
-    call("x2_layerscale_bwd", ptr(dx), ptr(u), ptr(gamma), ptr(du), ptr(dgamma), ptr(dbias), u.shape[0], u.shape[1])
+    call("x2_layerscale_bwd", ptr(dx), ptr(u), ptr(gamma), ptr(du), ptr(dgamma), ptr(dbias), ptr(rowscale), u.shape[0], u.shape[1])
     return du
 
 

@@ -15,6 +15,17 @@ from . import ops
 from .engine import BertLayersFn, EmbeddingsFn, MlmLossFn, _mask_pad, bert_layer_param_names
 
 
+_FIXED_SEEDS = []
+
+
+def next_dropout_seed():
+    """Per-call dropout seed from the host RNG (torch.manual_seed governs it; no device sync).
+    Tests push explicit seeds onto _FIXED_SEEDS."""
+    if _FIXED_SEEDS:
+        return _FIXED_SEEDS.pop(0)
+    return int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
+
+
 class BertConfig:
     """The handful of fields of HF's BertConfig this path reads (config.json of the text encoder dir)."""
     _defaults = dict(vocab_size=30522, hidden_size=768, num_hidden_layers=12, num_attention_heads=12,
@@ -41,9 +52,13 @@ class BertEmbeddings(nn.Module):
         self.LayerNorm = nn.LayerNorm(config.hidden_size, eps=config.layer_norm_eps)
         self.register_buffer("position_ids", torch.arange(config.max_position_embeddings).expand((1, -1)))
         self.eps = config.layer_norm_eps
+        self.config = config
 
     def forward(self, input_ids):
-        return EmbeddingsFn.apply(input_ids, self.eps, self.word_embeddings.weight, self.position_embeddings.weight,
+        drop = K.NO_DROP
+        if self.training and self.config.hidden_dropout_prob > 0:
+            drop = K.dropout_spec(self.config.hidden_dropout_prob, next_dropout_seed(), 1000)
+        return EmbeddingsFn.apply(input_ids, self.eps, drop, self.word_embeddings.weight, self.position_embeddings.weight,
                                   self.token_type_embeddings.weight, self.LayerNorm.weight, self.LayerNorm.bias)
 
 
@@ -106,13 +121,13 @@ class BertEncoder(nn.Module):
         cfg = self.config
         lo, hi = {"text": (0, cfg.fusion_layer), "fusion": (cfg.fusion_layer, cfg.num_hidden_layers),
                   "multi_modal": (0, cfg.num_hidden_layers)}[mode]
-        if self.training and (cfg.hidden_dropout_prob > 0 or cfg.attention_probs_dropout_prob > 0):
-            raise NotImplementedError("dropout is not implemented in the HIP path yet: call .eval() or set the "
-                                      "dropout probabilities to 0")
         S, L, _ = hidden.shape
+        drop = None
+        if self.training and (cfg.hidden_dropout_prob > 0 or cfg.attention_probs_dropout_prob > 0):
+            drop = dict(seed=next_dropout_seed(), p_hidden=cfg.hidden_dropout_prob, p_attn=cfg.attention_probs_dropout_prob)
         meta = dict(lo=lo, hi=hi, fusion_at=cfg.fusion_layer, heads=cfg.num_attention_heads, eps=cfg.layer_norm_eps,
                     self_mask=_mask_pad((1.0 - text_atts.float()) * -10000.0, L), enc_mask=None, kv_idx=None,
-                    seq_off=None, seq_ids=None)
+                    seq_off=None, seq_ids=None, drop=drop)
         cross = enc is not None and hi > cfg.fusion_layer
         if cross:
             Bi, T = enc.shape[0], enc.shape[1]
