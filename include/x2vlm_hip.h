@@ -47,7 +47,7 @@ int x2_tune(int key, int value);   /* A/B knobs for probes/bench_gemm.py (key 0:
 int x2_gemm_nt(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
                const float* bias, const float* gamma, const float* resid, int ldr, void* aux, int ldaux,
                int act, int out_f32, unsigned drop_thr16, unsigned drop_seed, float drop_scale, const float* rowscale,
-               void* stream);
+               float* colsum, void* stream);      /* colsum[n] += sum_m C[m,n] (fused bias gradient), NULL = off */
 
 /* Weight gradients of one layer in one launch: for each problem  dW[N,K] (+)= dY[Mc,N]^T . X[Mc,K]  (fp32 out).
  * problems: count (<= 8) rows of 11 int64 {dY, X, dW, Mc, N, K, ld_dY, ld_X, ld_dW, n_ld, k_ld}; n_ld / k_ld are
@@ -92,11 +92,13 @@ int x2_layernorm_fwd(const float* x, const float* w, const float* b, void* y_bf1
 int x2_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* w,
                      const float* dres, float* dx, void* dx_bf16, float* dw, float* db, float* dcol, int rows, int D,
                      int period, unsigned in_thr16, unsigned in_seed, float in_scale, unsigned out_thr16,
-                     unsigned out_seed, float out_scale, void* stream);
-int x2_colsum_bf16(const void* y, float* out, int M, int N, int ld, void* stream);                 /* out[n] += sum_m y */
+                     unsigned out_seed, float out_scale, float* ws /* [ceil(rows/16)][3][D] */, void* stream);
+/* Column reductions are two-stage (per-workgroup partial rows in the caller's workspace `ws`, then a deterministic
+ * add): fp32 atomics measured ~43 G adds/s on MI355X, slower than the HBM traffic of these kernels. */
+int x2_colsum_bf16(const void* y, float* out, int M, int N, int ld, float* ws /* [ceil(M/64)][N] */, void* stream);
 /* backward of x + gamma * u (beit2.py:206-207): du = gamma*dx (bf16), dgamma += sum dx*u, dbias += sum du */
 int x2_layerscale_bwd(const float* dx, const void* u, const float* gamma, void* du, float* dgamma, float* dbias,
-                      const float* rowscale, int M, int D, void* stream);      /* rowscale: DropPath factor per row */
+                      const float* rowscale, int M, int D, float* ws /* [ceil(M/32)][2][D] */, void* stream);
 int x2_cast_bf16(const float* src, void* dst, long n, void* stream);
 int x2_cast_transpose_bf16(const float* src, void* dst, void* dstT, int R, int C, int ldt, void* stream);
 /* PatchEmbed input rows (beit2.py:225-232): image (B,3,R,R) -> bf16 [B*(R/ps)^2][3*ps*ps] */

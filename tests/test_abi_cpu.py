@@ -42,9 +42,9 @@ def test_attn_args_struct_matches_header_layout():
 def test_argument_checks_fail_loudly_without_launching():
     lib = importlib.import_module("x2-vlm_amd._lib")
     h = lib.lib()
-    rc = h.x2_gemm_nt(None, None, None, 128, 128, 100, 100, 100, 128, None, None, None, 0, None, 0, 0, 0, None)
+    rc = h.x2_gemm_nt(None, None, None, 128, 128, 100, 100, 100, 128, None, None, None, 0, None, 0, 0, 0, 0, 0, 1.0, None, None, None)
     assert rc == -1 and b"multiple of 64" in h.x2_last_error()
-    rc = h.x2_layernorm_fwd(None, None, None, None, None, None, None, 4, 770, 1e-6, 0, None)
+    rc = h.x2_layernorm_fwd(None, None, None, None, None, None, None, 4, 770, 1e-6, 0, 0, 0, 1.0, None)
     assert rc == -1 and b"x2_layernorm_fwd" in h.x2_last_error()
     rc = h.x2_sample_negatives(None, 5000, None, None, None, None)
     assert rc == -1

@@ -55,10 +55,12 @@ def test_gemm_nt_plain_and_epilogues(K, M, N, K_):
     assert relerr(aux, ref + bias) < 6e-3
     # GELU' epilogue reads the saved pre-activation
     pre = bf(rnd(M, N, seed=6))
-    out = K.gemm_nt(A.to(dev), B.to(dev), aux=pre.to(dev), act=2, out_dtype=torch.float32)
+    cs = torch.zeros(N, device=dev)
+    out = K.gemm_nt(A.to(dev), B.to(dev), aux=pre.to(dev), act=2, out_dtype=torch.float32, colsum=cs)
     x = pre.float().requires_grad_(True)
     O.gelu(x).sum().backward()
     assert relerr(out, ref * x.grad) < 1e-5
+    assert relerr(cs, (ref * x.grad).sum(0)) < 2e-5         # fused bias-gradient column sums
     # layer-scale + residual (aux receives acc + bias)
     aux = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
     out = K.gemm_nt(A.to(dev), B.to(dev), bias=bias.to(dev), gamma=gamma.to(dev), resid=resid.to(dev), aux=aux,

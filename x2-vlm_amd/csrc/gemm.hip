@@ -31,6 +31,7 @@ struct GemmNT {
   int group_m;  // tile raster: GROUP_M row-panels are walked column by column (L2 working set = GROUP_M A panels + a few B tiles)
   DropSpec drop;            // hidden dropout on (acc + bias) before the residual add (xbert.py:429, 513)
   const float* rowscale;    // [M] per-row factor before the residual add: DropPath keep/(1-p) per sample (beit2.py:206-207)
+  float* colsum;            // [N] += column sums of the stored C (bias gradient of the layer below, fused)
 };
 
 // logical tile id -> (row tile, col tile): XCD-contiguous chunks, inside a chunk groups of `gm` row panels
@@ -123,6 +124,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNT p) {
   const bool nok = n < p.N;
   if (nok && p.bias) bb = *reinterpret_cast<const float4*>(p.bias + n);
   if (nok && p.gamma) gg = *reinterpret_cast<const float4*>(p.gamma + n);
+  float cs[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
 #pragma unroll
@@ -160,11 +162,20 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNT p) {
         const float4 rs = *reinterpret_cast<const float4*>(p.resid + (size_t)m * p.ldr + n);
         v[0] += rs.x; v[1] += rs.y; v[2] += rs.z; v[3] += rs.w;
       }
+      cs[0] += v[0]; cs[1] += v[1]; cs[2] += v[2]; cs[3] += v[3];
       if (p.out_f32)
         *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n) = float4{v[0], v[1], v[2], v[3]};
       else
         *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(p.C) + (size_t)m * p.ldc + n) =
             u32x2{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])};
+    }
+  }
+  if (p.colsum) {     // lanes sharing (lane & 15) hold the same 4 columns for different rows: fold 4 -> 1, one atomic per column
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { cs[e] += __shfl_xor(cs[e], 16, 64); cs[e] += __shfl_xor(cs[e], 32, 64); }
+    if (er == 0 && nok) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) atomicAdd(p.colsum + n + e, cs[e]);
     }
   }
 }
@@ -180,7 +191,7 @@ extern "C" int x2_tune(int key, int value) {
 extern "C" int x2_gemm_nt(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
                           const float* bias, const float* gamma, const float* resid, int ldr, void* aux, int ldaux,
                           int act, int out_f32, unsigned drop_thr16, unsigned drop_seed, float drop_scale, const float* rowscale,
-                          void* stream) {
+                          float* colsum, void* stream) {
   X2_REQUIRE(M > 0 && N > 0 && K > 0, "x2_gemm_nt: empty problem M=%d N=%d K=%d", M, N, K);
   X2_REQUIRE(drop_thr16 < 65536u, "x2_gemm_nt: drop_thr16=%u", drop_thr16);
   X2_REQUIRE(K % BK == 0, "x2_gemm_nt: K=%d must be a multiple of %d", K, BK);
@@ -189,7 +200,7 @@ extern "C" int x2_gemm_nt(const void* A, const void* B, void* C, int M, int N, i
   X2_REQUIRE(act == 0 || aux, "x2_gemm_nt: act=%d needs aux", act);
   X2_REQUIRE((!resid || ldr % 4 == 0) && (!aux || ldaux % 4 == 0), "x2_gemm_nt: ldr/ldaux alignment");
   GemmNT p{(const bf16_t*)A, (const bf16_t*)B, C, bias, gamma, resid, (bf16_t*)aux, M, N, K, lda, ldb, ldc, ldr, ldaux, act, out_f32,
-           g_tune[0] > 0 ? g_tune[0] : 8, DropSpec{drop_thr16, drop_seed, drop_scale}, rowscale};
+           g_tune[0] > 0 ? g_tune[0] : 8, DropSpec{drop_thr16, drop_seed, drop_scale}, rowscale, colsum};
   const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
   hipLaunchKernelGGL(gemm_nt_kernel, dim3(tiles), dim3(256), GEMM_LDS_BYTES, (hipStream_t)stream, p);
   return x2_check_launch("x2_gemm_nt");

@@ -14,6 +14,11 @@ __device__ __forceinline__ long remap_row(int r, int period) { return period > 0
 // ---------------------------------------------------------------------------------- LayerNorm fwd
 // x fp32 [rows][D] -> y_bf16 / y_f32 (either may be null), mean/rstd saved for the backward.
 #define LN_MAXV 8   // float4 per lane: D <= 2048
+// NV = float4 per lane actually used (ceil(D / 256)): keeps the register footprint (hence occupancy) tied to D
+#define LN_DISPATCH(D, CALL) do { const int nv_ = ((D) + 255) / 256; \
+  if (nv_ <= 1) { CALL(1); } else if (nv_ == 2) { CALL(2); } else if (nv_ == 3) { CALL(3); } else if (nv_ == 4) { CALL(4); } \
+  else if (nv_ <= 6) { CALL(6); } else { CALL(8); } } while (0)
+template <int NV>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                             const float* __restrict__ bsh, bf16_t* yb, float* yf,
                                                             float* mean, float* rstd, int rows, int D, float eps, int period,
@@ -22,25 +27,25 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
   if (row >= rows) return;
   const long gr = remap_row(row, period);
   const float* xr = x + gr * D;
-  float4 v[LN_MAXV];
+  float4 v[NV];
   float s = 0.f;
   const int nv = D >> 2;
 #pragma unroll
-  for (int i = 0; i < LN_MAXV; ++i) {
+  for (int i = 0; i < NV; ++i) {
     const int c = lane + i * 64;
     if (c < nv) { v[i] = *reinterpret_cast<const float4*>(xr + c * 4); s += v[i].x + v[i].y + v[i].z + v[i].w; }
   }
   const float mu = wave_sum(s) / D;
   float q = 0.f;
 #pragma unroll
-  for (int i = 0; i < LN_MAXV; ++i) {
+  for (int i = 0; i < NV; ++i) {
     const int c = lane + i * 64;
     if (c < nv) { const float a = v[i].x - mu, b = v[i].y - mu, cc = v[i].z - mu, d = v[i].w - mu; q += a * a + b * b + cc * cc + d * d; }
   }
   const float rs = rsqrtf(wave_sum(q) / D + eps);
   if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
 #pragma unroll
-  for (int i = 0; i < LN_MAXV; ++i) {
+  for (int i = 0; i < NV; ++i) {
     const int c = lane + i * 64;
     if (c < nv) {
       const float4 ww = *reinterpret_cast<const float4*>(w + c * 4), bb = *reinterpret_cast<const float4*>(bsh + c * 4);
@@ -60,28 +65,56 @@ extern "C" int x2_layernorm_fwd(const float* x, const float* w, const float* b, 
                                 float* rstd, int rows, int D, float eps, int period, unsigned drop_thr16, unsigned drop_seed,
                                 float drop_scale, void* stream) {
   X2_REQUIRE(rows > 0 && D > 0 && D % 4 == 0 && D <= 256 * LN_MAXV, "x2_layernorm_fwd: rows=%d D=%d (D%%4==0, D<=2048)", rows, D);
-  hipLaunchKernelGGL(layernorm_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, w, b, (bf16_t*)y_bf16,
-                     y_f32, mean, rstd, rows, D, eps, period, DropSpec{drop_thr16, drop_seed, drop_scale});
+#define X2_LNF(NV) hipLaunchKernelGGL(layernorm_fwd_kernel<NV>, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, w, b, \
+                     (bf16_t*)y_bf16, y_f32, mean, rstd, rows, D, eps, period, DropSpec{drop_thr16, drop_seed, drop_scale})
+  LN_DISPATCH(D, X2_LNF);
   return x2_check_launch("x2_layernorm_fwd");
+}
+
+// ---------------------------------------------------------------------------------- partial-sum reducer
+// Column reductions over many rows are done in two deterministic stages instead of fp32 atomics (measured
+// on MI355X: ~43 G atomic-adds/s, i.e. 1.8 M atomics of a 12608-row LayerNorm backward cost more than its
+// HBM traffic): stage 1 writes per-workgroup partial rows part[blk][k][width], this kernel adds them up:
+// out_k[c] += sum_blk part[blk][k][c].
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ part, int nblk, int nk, int width,
+                                                              float* o0, float* o1, float* o2) {
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), k = blockIdx.y, sl = threadIdx.x >> 6;
+  __shared__ float red[3][64];
+  float s = 0.f;
+  if (c < width) {
+#pragma unroll 4
+    for (int b = sl; b < nblk; b += 4) s += part[((long)b * nk + k) * width + c];
+  }
+  if (sl > 0) red[sl - 1][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (sl == 0 && c < width) {
+    float* o = k == 0 ? o0 : (k == 1 ? o1 : o2);
+    if (o) o[c] += s + red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x];
+  }
+}
+static void launch_reduce(const float* part, int nblk, int nk, int width, float* o0, float* o1, float* o2, hipStream_t st) {
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((width + 63) / 64, nk), dim3(256), 0, st, part, nblk, nk, width, o0, o1, o2);
 }
 
 // ---------------------------------------------------------------------------------- LayerNorm bwd
 // dx = dres + rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * w ; dw += sum dy*xhat ; db += sum dy ;
 // optionally dcol += sum_rows dx (the bias gradient of the linear layer that produced the LN input).
 // A workgroup (4 waves) walks LNB_ROWS rows; each wave keeps its dw/db/dcol partials in registers, the
-// four waves are combined through LDS and the workgroup issues ONE atomic per column.
-#define LNB_ROWS 32
+// four waves are combined through LDS and written as one partial row per workgroup (ws[blk][3][D]);
+// reduce_partials_kernel then adds the partial rows into dw/db/dcol.
+#define LNB_ROWS 16
+template <int NV>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
                                                             const float* __restrict__ w, const float* dres, float* dx, bf16_t* dxb,
-                                                            float* dw, float* db, float* dcol, int rows, int D, int period,
+                                                            float* ws, int rows, int D, int period,
                                                             DropSpec din, DropSpec dout) {
   extern __shared__ __attribute__((aligned(16))) float red[];      // [3][3 waves][D]
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int nv = D >> 2;
-  float4 ww[LN_MAXV], aw[LN_MAXV], ab[LN_MAXV], ac[LN_MAXV];
+  float4 ww[NV], aw[NV], ab[NV], ac[NV];
 #pragma unroll
-  for (int i = 0; i < LN_MAXV; ++i) {
+  for (int i = 0; i < NV; ++i) {
     const int c = lane + i * 64;
     ww[i] = c < nv ? *reinterpret_cast<const float4*>(w + c * 4) : float4{0.f, 0.f, 0.f, 0.f};
     aw[i] = float4{0.f, 0.f, 0.f, 0.f}; ab[i] = float4{0.f, 0.f, 0.f, 0.f}; ac[i] = float4{0.f, 0.f, 0.f, 0.f};
@@ -90,10 +123,10 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
   for (int row = r0 + wv; row < r1; row += 4) {
     const long gr = remap_row(row, period);
     const float mu = mean[row], rs = rstd[row];
-    float4 g[LN_MAXV], xh[LN_MAXV];
+    float4 g[NV], xh[NV];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
+    for (int i = 0; i < NV; ++i) {
       const int c = lane + i * 64;
       if (c < nv) {
         float4 d = *reinterpret_cast<const float4*>(dy + gr * D + c * 4);
@@ -113,7 +146,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     }
     const float m1 = wave_sum(s1) / D, m2 = wave_sum(s2) / D;
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
+    for (int i = 0; i < NV; ++i) {
       const int c = lane + i * 64;
       if (c < nv) {
         float4 o{rs * (g[i].x - m1 - xh[i].x * m2), rs * (g[i].y - m1 - xh[i].y * m2), rs * (g[i].z - m1 - xh[i].z * m2), rs * (g[i].w - m1 - xh[i].w * m2)};
@@ -135,7 +168,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
   // combine the 4 waves: waves 1..3 park their partials in LDS, wave 0 adds them and issues the atomics
   if (wv > 0) {
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
+    for (int i = 0; i < NV; ++i) {
       const int c = lane + i * 64;
       if (c < nv) {
         *reinterpret_cast<float4*>(red + ((0 * 3 + wv - 1) * D) + c * 4) = aw[i];
@@ -147,7 +180,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
   __syncthreads();
   if (wv == 0) {
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
+    for (int i = 0; i < NV; ++i) {
       const int c = lane + i * 64;
       if (c < nv) {
 #pragma unroll
@@ -158,9 +191,10 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
           ab[i].x += b.x; ab[i].y += b.y; ab[i].z += b.z; ab[i].w += b.w;
           ac[i].x += cc.x; ac[i].y += cc.y; ac[i].z += cc.z; ac[i].w += cc.w;
         }
-        atomicAdd(dw + c * 4 + 0, aw[i].x); atomicAdd(dw + c * 4 + 1, aw[i].y); atomicAdd(dw + c * 4 + 2, aw[i].z); atomicAdd(dw + c * 4 + 3, aw[i].w);
-        atomicAdd(db + c * 4 + 0, ab[i].x); atomicAdd(db + c * 4 + 1, ab[i].y); atomicAdd(db + c * 4 + 2, ab[i].z); atomicAdd(db + c * 4 + 3, ab[i].w);
-        if (dcol) { atomicAdd(dcol + c * 4 + 0, ac[i].x); atomicAdd(dcol + c * 4 + 1, ac[i].y); atomicAdd(dcol + c * 4 + 2, ac[i].z); atomicAdd(dcol + c * 4 + 3, ac[i].w); }
+        float* wp = ws + (long)blockIdx.x * 3 * D + c * 4;
+        *reinterpret_cast<float4*>(wp) = aw[i];
+        *reinterpret_cast<float4*>(wp + D) = ab[i];
+        *reinterpret_cast<float4*>(wp + 2 * D) = ac[i];
       }
     }
   }
@@ -169,28 +203,31 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
 extern "C" int x2_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* w,
                                 const float* dres, float* dx, void* dx_bf16, float* dw, float* db, float* dcol, int rows, int D,
                                 int period, unsigned in_thr16, unsigned in_seed, float in_scale, unsigned out_thr16,
-                                unsigned out_seed, float out_scale, void* stream) {
+                                unsigned out_seed, float out_scale, float* ws, void* stream) {
   X2_REQUIRE(rows > 0 && D > 0 && D % 4 == 0 && D <= 256 * LN_MAXV, "x2_layernorm_bwd: rows=%d D=%d", rows, D);
-  X2_REQUIRE(dw && db, "x2_layernorm_bwd: dw/db (accumulated with atomics) required");
+  X2_REQUIRE(dw && db && ws, "x2_layernorm_bwd: dw/db and the workspace ws[ceil(rows/%d)*3*D] are required", LNB_ROWS);
   X2_REQUIRE(!(dcol && dres), "x2_layernorm_bwd: dcol sums the LN-input gradient, which excludes dres");
   X2_REQUIRE(!(out_thr16 && dres), "x2_layernorm_bwd: an output mask applies to the bf16 copy, which excludes dres");
-  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((rows + LNB_ROWS - 1) / LNB_ROWS), dim3(256), 9 * D * sizeof(float), (hipStream_t)stream, dy,
-                     x, mean, rstd, w, dres, dx, (bf16_t*)dx_bf16, dw, db, dcol, rows, D, period, DropSpec{in_thr16, in_seed, in_scale},
-                     DropSpec{out_thr16, out_seed, out_scale});
+#define X2_LNB(NV) hipLaunchKernelGGL(layernorm_bwd_kernel<NV>, dim3((rows + LNB_ROWS - 1) / LNB_ROWS), dim3(256), 9 * D * sizeof(float), \
+                     (hipStream_t)stream, dy, x, mean, rstd, w, dres, dx, (bf16_t*)dx_bf16, ws, rows, D, period,                \
+                     DropSpec{in_thr16, in_seed, in_scale}, DropSpec{out_thr16, out_seed, out_scale})
+  LN_DISPATCH(D, X2_LNB);
+  launch_reduce(ws, (rows + LNB_ROWS - 1) / LNB_ROWS, 3, D, dw, db, dcol, (hipStream_t)stream);
   return x2_check_launch("x2_layernorm_bwd");
 }
 
 // ---------------------------------------------------------------------------------- column sums
 // out[n] += sum_m Y[m][n]  (bias gradients).  Workgroup = 512 columns x CS_ROWS rows: 64 lanes x 16 B
-// across, 4 waves down; waves combined through LDS, one atomic per column per workgroup.
+// across, 4 waves down; waves combined through LDS into one partial row ws[rowblk][N], then reduced.
 #define CS_ROWS 64
-__global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16_t* __restrict__ y, float* out, int M, int N, int ld) {
+__global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16_t* __restrict__ y, float* ws, int M, int N, int ld) {
   __shared__ float red[3][512];
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const int c0 = blockIdx.y * 512 + tx * 8;
   const int r0 = blockIdx.x * CS_ROWS, r1 = min(M, r0 + CS_ROWS);
   float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (c0 < N) {
+#pragma unroll 4
     for (int r = r0 + ty; r < r1; r += 4) {
       const u32x4 v = *reinterpret_cast<const u32x4*>(y + (long)r * ld + c0);
 #pragma unroll
@@ -206,14 +243,16 @@ __global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16_t* __restri
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const float v = acc[e] + red[0][tx * 8 + e] + red[1][tx * 8 + e] + red[2][tx * 8 + e];
-      if (c0 + e < N) atomicAdd(out + c0 + e, v);
+      if (c0 + e < N) ws[(long)blockIdx.x * N + c0 + e] = v;
     }
   }
 }
-extern "C" int x2_colsum_bf16(const void* y, float* out, int M, int N, int ld, void* stream) {
+extern "C" int x2_colsum_bf16(const void* y, float* out, int M, int N, int ld, float* ws, void* stream) {
   X2_REQUIRE(M > 0 && N > 0 && N % 8 == 0 && ld % 8 == 0, "x2_colsum_bf16: M=%d N=%d ld=%d (N, ld multiples of 8)", M, N, ld);
+  X2_REQUIRE(ws, "x2_colsum_bf16: workspace ws[ceil(M/%d)*N] required", CS_ROWS);
   hipLaunchKernelGGL(colsum_bf16_kernel, dim3((M + CS_ROWS - 1) / CS_ROWS, (N + 511) / 512), dim3(256), 0, (hipStream_t)stream,
-                     (const bf16_t*)y, out, M, N, ld);
+                     (const bf16_t*)y, ws, M, N, ld);
+  launch_reduce(ws, (M + CS_ROWS - 1) / CS_ROWS, 1, N, out, nullptr, nullptr, (hipStream_t)stream);
   return x2_check_launch("x2_colsum_bf16");
 }
 
@@ -223,8 +262,8 @@ extern "C" int x2_colsum_bf16(const void* y, float* out, int M, int N, int ld, v
 // columns, 4 waves down), waves combined through LDS, one atomic per column per workgroup.
 #define LS_ROWS 32
 __global__ __launch_bounds__(256) void layerscale_bwd_kernel(const float* __restrict__ dx, const bf16_t* __restrict__ u,
-                                                             const float* __restrict__ gamma, bf16_t* du, float* dgamma,
-                                                             float* dbias, const float* __restrict__ rowscale, int M, int D) {
+                                                             const float* __restrict__ gamma, bf16_t* du, float* ws,
+                                                             const float* __restrict__ rowscale, int M, int D) {
   __shared__ float red[2][3][256];
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const int c0 = blockIdx.y * 256 + tx * 4;
@@ -250,16 +289,17 @@ __global__ __launch_bounds__(256) void layerscale_bwd_kernel(const float* __rest
   if (ty == 0 && c0 < D) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      atomicAdd(dgamma + c0 + e, ag[e] + red[0][0][tx * 4 + e] + red[0][1][tx * 4 + e] + red[0][2][tx * 4 + e]);
-      atomicAdd(dbias + c0 + e, ab[e] + red[1][0][tx * 4 + e] + red[1][1][tx * 4 + e] + red[1][2][tx * 4 + e]);
+      ws[((long)blockIdx.x * 2 + 0) * D + c0 + e] = ag[e] + red[0][0][tx * 4 + e] + red[0][1][tx * 4 + e] + red[0][2][tx * 4 + e];
+      ws[((long)blockIdx.x * 2 + 1) * D + c0 + e] = ab[e] + red[1][0][tx * 4 + e] + red[1][1][tx * 4 + e] + red[1][2][tx * 4 + e];
     }
   }
 }
 extern "C" int x2_layerscale_bwd(const float* dx, const void* u, const float* gamma, void* du, float* dgamma, float* dbias,
-                                 const float* rowscale, int M, int D, void* stream) {
-  X2_REQUIRE(M > 0 && D > 0 && D % 4 == 0, "x2_layerscale_bwd: M=%d D=%d", M, D);
+                                 const float* rowscale, int M, int D, float* ws, void* stream) {
+  X2_REQUIRE(M > 0 && D > 0 && D % 4 == 0 && ws, "x2_layerscale_bwd: M=%d D=%d (workspace ws[ceil(M/%d)*2*D] required)", M, D, LS_ROWS);
   hipLaunchKernelGGL(layerscale_bwd_kernel, dim3((M + LS_ROWS - 1) / LS_ROWS, (D + 255) / 256), dim3(256), 0, (hipStream_t)stream, dx,
-                     (const bf16_t*)u, gamma, (bf16_t*)du, dgamma, dbias, rowscale, M, D);
+                     (const bf16_t*)u, gamma, (bf16_t*)du, ws, rowscale, M, D);
+  launch_reduce(ws, (M + LS_ROWS - 1) / LS_ROWS, 2, D, dgamma, dbias, nullptr, (hipStream_t)stream);
   return x2_check_launch("x2_layerscale_bwd");
 }
 
@@ -281,21 +321,42 @@ extern "C" int x2_cast_bf16(const float* src, void* dst, long n, void* stream) {
 }
 
 // fp32 [R][C] -> bf16 [R][C] (optional) and bf16 transposed [C][ldt] (ldt >= R; columns R..ldt-1 left untouched).
-// 64x64 tiles through LDS (padded), coalesced on both sides.
+// 64x64 tiles through LDS; 16-byte loads, 8-byte stores on both sides when R, C, ldt are multiples of 4.
 __global__ __launch_bounds__(256) void cast_transpose_kernel(const float* __restrict__ s, bf16_t* d, bf16_t* dT, int R, int C, int ldt) {
   __shared__ float tile[64][65];
   const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-  for (int i = ty; i < 64; i += 4) {
-    const int r = r0 + i, c = c0 + tx;
-    float v = 0.f;
-    if (r < R && c < C) { v = s[(long)r * C + c]; if (d) d[(long)r * C + c] = f2bf(v); }
-    tile[i][tx] = v;
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;       // 16 x 16 threads, 4 columns each
+  const bool vec = ((C | ldt | R) & 3) == 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = r0 + ty + 16 * i, c = c0 + tx * 4;
+    float4 v{0.f, 0.f, 0.f, 0.f};
+    if (r < R) {
+      if (vec && c + 3 < C) {
+        v = *reinterpret_cast<const float4*>(s + (long)r * C + c);
+        if (d) *reinterpret_cast<u32x2*>(d + (long)r * C + c) = u32x2{pack_bf16(v.x, v.y), pack_bf16(v.z, v.w)};
+      } else {
+        float t[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int e = 0; e < 4; ++e) if (c + e < C) { t[e] = s[(long)r * C + c + e]; if (d) d[(long)r * C + c + e] = f2bf(t[e]); }
+        v = float4{t[0], t[1], t[2], t[3]};
+      }
+    }
+    tile[ty + 16 * i][tx * 4 + 0] = v.x; tile[ty + 16 * i][tx * 4 + 1] = v.y;
+    tile[ty + 16 * i][tx * 4 + 2] = v.z; tile[ty + 16 * i][tx * 4 + 3] = v.w;
   }
   __syncthreads();
-  for (int i = ty; i < 64; i += 4) {
-    const int c = c0 + i, r = r0 + tx;
-    if (c < C && r < R) dT[(long)c * ldt + r] = f2bf(tile[tx][i]);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = c0 + ty + 16 * i, r = r0 + tx * 4;               // output row = source column
+    if (c >= C) continue;
+    const float a0 = tile[tx * 4 + 0][ty + 16 * i], a1 = tile[tx * 4 + 1][ty + 16 * i],
+                a2 = tile[tx * 4 + 2][ty + 16 * i], a3 = tile[tx * 4 + 3][ty + 16 * i];
+    if (vec && r + 3 < R) {
+      *reinterpret_cast<u32x2*>(dT + (long)c * ldt + r) = u32x2{pack_bf16(a0, a1), pack_bf16(a2, a3)};
+    } else {
+      const float t[4] = {a0, a1, a2, a3};
+      for (int e = 0; e < 4; ++e) if (r + e < R) dT[(long)c * ldt + r + e] = f2bf(t[e]);
+    }
   }
 }
 extern "C" int x2_cast_transpose_bf16(const float* src, void* dst, void* dstT, int R, int C, int ldt, void* stream) {

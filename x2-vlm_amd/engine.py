@@ -230,8 +230,7 @@ class VisionEncoderFn(torch.autograd.Function):
             _, wprojT = BANK.linear(p[b + "attn.proj.weight"])
             _, wqkvT = BANK.linear(p[b + "attn.qkv.weight"])
             dy2 = K.layerscale_bwd(dx, aux2, p[b + "gamma_2"], G["gamma_2"], G["mlp.fc2.bias"], rowscale=rs2)
-            dpre = K.gemm_nt(dy2, w2T, aux=pre, act=2)
-            K.colsum_bf16(dpre, G["mlp.fc1.bias"])
+            dpre = K.gemm_nt(dy2, w2T, aux=pre, act=2, colsum=G["mlp.fc1.bias"])
             dh2 = K.gemm_nt(dpre, w1T, out_dtype=F32)
             dx1, _ = K.layernorm_bwd(dh2, x1, mean2, rstd2, p[b + "norm2.weight"], G["norm2.weight"], G["norm2.bias"], dres=dx)
             dy1 = K.layerscale_bwd(dx1, aux1, p[b + "gamma_1"], G["gamma_1"], G["attn.proj.bias"], rowscale=rs1)
@@ -400,8 +399,7 @@ class BertLayersFn(torch.autograd.Function):
                                         drop_out=BertLayersFn._drop(meta, i, 4))
             _, woutT = BANK.linear(p[b + "output.dense.weight"])
             _, wiT = BANK.linear(p[b + "intermediate.dense.weight"])
-            dpre = K.gemm_nt(ds3b, woutT, aux=pre, act=2)
-            K.colsum_bf16(dpre, G["intermediate.dense.bias"])
+            dpre = K.gemm_nt(ds3b, woutT, aux=pre, act=2, colsum=G["intermediate.dense.bias"])
             dh2 = K.gemm_nt(dpre, wiT, resid=ds3, out_dtype=F32)
             tn += [(ds3b, act, G["output.dense.weight"]), (dpre, h2b, G["intermediate.dense.weight"])]
             if cr is not None:
@@ -561,6 +559,30 @@ class LinearF32Fn(torch.autograd.Function):
         if ctx.has_b:
             db = torch.zeros(w.shape[0], device=dy.device, dtype=F32)
             K.colsum_f32(dy, db)
+        return dx, dw, db
+
+
+class LinearBf16Fn(torch.autograd.Function):
+    """y = x @ W^T + b on the bf16 MFMA GEMM (fp32 in/out rows, bf16 operands): first layers of the MLP heads
+    (768 -> 1536 on 3B rows).  K % 64 == 0, N % 4 == 0."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        xb = K.cast_bf16(x.contiguous())
+        wb, _ = BANK.linear(w)
+        ctx.save_for_backward(xb, w)
+        return K.gemm_nt(xb, wb, bias=b, out_dtype=F32)
+
+    @staticmethod
+    def backward(ctx, dy):
+        xb, w = ctx.saved_tensors
+        dyb = K.cast_bf16(dy.contiguous())
+        _, wT = BANK.linear(w)
+        dx = K.gemm_nt(dyb, wT, out_dtype=F32)
+        dw = torch.empty_like(w)
+        K.gemm_tn_grouped([(dyb, xb, dw)])
+        db = torch.zeros(w.shape[0], device=dy.device, dtype=F32)
+        K.colsum_bf16(dyb, db)
         return dx, dw, db
 
 

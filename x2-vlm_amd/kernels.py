@@ -64,6 +64,19 @@ def dropout_keep(spec, index):
     return (u >= thr).to(torch.float32) * scale
 
 
+_WS = {}
+
+
+def workspace(device, nfloats):
+    """Scratch for the two-stage column reductions: one growing fp32 buffer per device; kernels on one stream use
+    it strictly in order (stage 1 writes, stage 2 reads, next kernel overwrites)."""
+    buf = _WS.get(device)
+    if buf is None or buf.numel() < nfloats:
+        buf = torch.empty(max(nfloats, 1 << 22), device=device, dtype=F32)
+        _WS[device] = buf
+    return buf
+
+
 def _rows(t):
     assert t.dim() == 2 and t.stride(1) == 1, "expected a row-major 2-D tensor (got strides %s)" % (t.stride(),)
     return t.stride(0)
@@ -76,10 +89,10 @@ def round_up(x, m):
 # ----------------------------------------------------------------------------- GEMMs
 
 def gemm_nt(A, B, *, bias=None, gamma=None, resid=None, aux=None, act=0, out=None, out_dtype=BF16, drop=NO_DROP,
-            rowscale=None):
+            rowscale=None, colsum=None):
     """out[M,N] = epilogue(A[M,K] @ B[N,K]^T).  act: 0 none (aux, if given, receives acc+bias),
     1 GELU (aux receives the pre-activation), 2 multiply by GELU'(aux).  Then dropout(drop), *gamma,
-    *rowscale[m], +resid."""
+    *rowscale[m], +resid.  colsum (fp32 [N], accumulated): column sums of the stored result."""
     assert A.dtype == BF16 and B.dtype == BF16 and A.shape[1] == B.shape[1]
     M, K = A.shape
     N = B.shape[0]
@@ -94,7 +107,7 @@ def gemm_nt(A, B, *, bias=None, gamma=None, resid=None, aux=None, act=0, out=Non
     with _timed(2.0 * M * N * K):
         call("x2_gemm_nt", ptr(A), ptr(B), ptr(out), M, N, K, _rows(A), _rows(B), _rows(out), ptr(bias), ptr(gamma),
              ptr(resid), _rows(resid) if resid is not None else 0, ptr(aux), _rows(aux) if aux is not None else 0,
-             act, 1 if out.dtype == F32 else 0, drop[0], drop[1], drop[2], ptr(rowscale))
+             act, 1 if out.dtype == F32 else 0, drop[0], drop[1], drop[2], ptr(rowscale), ptr(colsum))
     return out
 
 
@@ -204,17 +217,20 @@ def layernorm_bwd(dy, x, mean, rstd, w, dw, db, *, dres=None, dcol=None, period=
         dx = torch.empty_like(x) if period == 0 else torch.zeros_like(x)
     dxb = torch.empty(x.shape, device=x.device, dtype=BF16) if want_bf16 else None
     call("x2_layernorm_bwd", ptr(dy), ptr(x), ptr(mean), ptr(rstd), ptr(w), ptr(dres), ptr(dx), ptr(dxb), ptr(dw), ptr(db),
-         ptr(dcol), R, D, period, drop_in[0], drop_in[1], drop_in[2], drop_out[0], drop_out[1], drop_out[2])
+         ptr(dcol), R, D, period, drop_in[0], drop_in[1], drop_in[2], drop_out[0], drop_out[1], drop_out[2],
+         ptr(workspace(x.device, ((R + 15) // 16) * 3 * D)))
     return dx, dxb
 
 
 def colsum_bf16(y, out):
-    call("x2_colsum_bf16", ptr(y), ptr(out), y.shape[0], y.shape[1], _rows(y))
+    call("x2_colsum_bf16", ptr(y), ptr(out), y.shape[0], y.shape[1], _rows(y),
+         ptr(workspace(y.device, ((y.shape[0] + 63) // 64) * y.shape[1])))
 
 
 def layerscale_bwd(dx, u, gamma, dgamma, dbias, rowscale=None):
     du = torch.empty_like(u)
-    call("x2_layerscale_bwd", ptr(dx), ptr(u), ptr(gamma), ptr(du), ptr(dgamma), ptr(dbias), ptr(rowscale), u.shape[0], u.shape[1])
+    call("x2_layerscale_bwd", ptr(dx), ptr(u), ptr(gamma), ptr(du), ptr(dgamma), ptr(dbias), ptr(rowscale), u.shape[0], u.shape[1],
+         ptr(workspace(u.device, ((u.shape[0] + 31) // 32) * 2 * u.shape[1])))
     return du
 
 

@@ -3,7 +3,7 @@
 import torch
 
 from . import kernels as K
-from .engine import (CrossEntropyFn, GatherRowsFn, GeluF32Fn, L2NormFn, LayerNormF32Fn, LinearF32Fn)
+from .engine import (CrossEntropyFn, GatherRowsFn, GeluF32Fn, L2NormFn, LayerNormF32Fn, LinearBf16Fn, LinearF32Fn)
 
 
 def linear(x, w, b=None):
@@ -32,7 +32,11 @@ def gather_rows(src, idx):
 
 def mlp_head(seq, x):
     """nn.Sequential(Linear, LayerNorm(1e-5), GELU, Linear) of xvlm.py:163-169 on fp32 rows."""
-    h = linear(x, seq[0].weight, seq[0].bias)
+    w0 = seq[0].weight
+    if w0.shape[1] % 64 == 0 and w0.shape[0] % 8 == 0 and x.numel() % 4 == 0:
+        h = LinearBf16Fn.apply(x, w0, seq[0].bias)          # 768 -> 1536: MFMA GEMM
+    else:
+        h = linear(x, w0, seq[0].bias)
     h = gelu(layer_norm(h, seq[1].weight, seq[1].bias, seq[1].eps))
     return linear(h, seq[3].weight, seq[3].bias)
 
