@@ -37,7 +37,7 @@ class GradientBuckets:
         if dist.get_backend(self.pg) != "nccl":
             flat.div_(self.world)
 
-    def _on_arena(self, flat, key):
+    def _on_arena(self, flat, key, also_after=None):
         # a parameter set used by several forward calls receives several gradients that autograd sums
         # later: only single-use layers may be reduced early
         if engine.STAGE_CALLS.get(key, 0) != 1:
@@ -48,6 +48,8 @@ class GradientBuckets:
             ev = torch.cuda.Event()
             ev.record()
             self.side.wait_event(ev)
+            if also_after is not None:
+                self.side.wait_event(also_after)      # the layer's weight-gradient GEMMs run on engine.SIDE
             with torch.cuda.stream(self.side):
                 self._all_reduce(flat)
             flat.record_stream(self.side)

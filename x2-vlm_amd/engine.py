@@ -94,14 +94,51 @@ class Grads:
     def alias(self, name, view):
         self.g[name] = view
 
-    def publish(self):
-        """Every kernel writing this arena has been enqueued on the current stream."""
+    def publish(self, also_after=None):
+        """Every kernel writing this arena has been enqueued: on the current stream and, for the weight-gradient
+        GEMMs, on the side stream up to the event `also_after`."""
         if GRAD_READY_HOOK is not None:
-            GRAD_READY_HOOK(self.flat, self.key)
+            GRAD_READY_HOOK(self.flat, self.key, also_after)
 
     def take(self, names):
         return [self.g.pop(n) for n in names]
 
+
+class SideStream:
+    """Weight-gradient GEMMs need only (dY, X) of their layer, not the rest of the backward chain: they are
+    launched on a second HIP stream so that their workgroups fill the CUs the dgrad / attention / LayerNorm kernels
+    of the main stream leave idle at their tails (594-tile GEMMs on 512 workgroup slots, HBM-bound row kernels)."""
+
+    def __init__(self):
+        self.stream = None
+        self.enabled = True
+
+    def launch(self, fn, tensors):
+        """Run fn() on the side stream after everything enqueued so far on the current stream; returns an event
+        recorded behind it (None when running inline)."""
+        if not self.enabled or not torch.cuda.is_available():
+            fn()
+            return None
+        if self.stream is None:
+            self.stream = torch.cuda.Stream()
+        ev = torch.cuda.Event()
+        ev.record()
+        self.stream.wait_event(ev)
+        done = torch.cuda.Event()
+        with torch.cuda.stream(self.stream):
+            fn()
+            done.record()
+        for t in tensors:
+            t.record_stream(self.stream)
+        return done
+
+    def join(self):
+        """Make the current stream wait for the side stream (call before gradients leave the stage)."""
+        if self.stream is not None and self.enabled:
+            torch.cuda.current_stream().wait_stream(self.stream)
+
+
+SIDE = SideStream()
 
 GRAD_READY_HOOK = None      # set by accelerator.GradientBuckets: f(flat_fp32_arena, key)
 STAGE_CALLS = {}            # key -> number of forward calls since the last reset (see GradientBuckets)
@@ -246,9 +283,9 @@ class VisionEncoderFn(torch.autograd.Function):
             G.alias("attn.v_bias", G["qkv_bias"][2 * D:])
             dh1 = K.gemm_nt(dqkv, wqkvT, out_dtype=F32)
             dxn, _ = K.layernorm_bwd(dh1, x, mean1, rstd1, p[b + "norm1.weight"], G["norm1.weight"], G["norm1.bias"], dres=dx1)
-            K.gemm_tn_grouped([(dy2, act, G["mlp.fc2.weight"]), (dpre, h2, G["mlp.fc1.weight"]),
-                               (dy1, att, G["attn.proj.weight"]), (dqkv, h1, G["attn.qkv.weight"])])
-            G.publish()
+            tn = [(dy2, act, G["mlp.fc2.weight"]), (dpre, h2, G["mlp.fc1.weight"]),
+                  (dy1, att, G["attn.proj.weight"]), (dqkv, h1, G["attn.qkv.weight"])]
+            G.publish(SIDE.launch(lambda tn=tn: K.gemm_tn_grouped(tn), [t for pr in tn for t in pr[:2]] + [G.flat]))
             for n in names:
                 if n.startswith(b):
                     out[n] = G.g[n[len(b):]]
@@ -258,6 +295,7 @@ class VisionEncoderFn(torch.autograd.Function):
         # 36 output tiles only: split the 12k-long contraction over 8 workgroups per tile (fp32 atomics)
         K.gemm_tn_grouped([(dpatch, cols, Gt["patch_embed.proj.weight"].view(D, -1))], accumulate=True,
                           split=8 if B * P_ >= 4096 else 1)
+        SIDE.join()
         Gt.publish()
         out.update(Gt.g)
         return (None, None) + tuple(out[n] for n in names)
@@ -448,11 +486,11 @@ class BertLayersFn(torch.autograd.Function):
             _, wqkvT = BANK.linear(p[a + "self.query.weight"], p[a + "self.key.weight"], p[a + "self.value.weight"])
             dh = K.gemm_nt(dqkv, wqkvT, resid=ds1, out_dtype=F32)
             tn += [(ds1b, att, G["attention.output.dense.weight"]), (dqkv, hb, G["a.qkv_weight"])]
-            K.gemm_tn_grouped(tn)
-            G.publish()
+            G.publish(SIDE.launch(lambda tn=tn: K.gemm_tn_grouped(tn), [t for pr in tn for t in pr[:2]] + [G.flat]))
             for n in names:
                 if n.startswith(b):
                     out[n] = G.g[n[len(b):]]
+        SIDE.join()
         d_enc = denc.view(enc_shape) if denc is not None else None
         return (dh.view(S, L, Hd), d_enc, None) + tuple(out[n] for n in names)
 
