@@ -32,7 +32,7 @@ int x2_tune(int key, int value);   /* A/B knobs for probes/bench_gemm.py (key 0:
  * image tokens), :428 (attention output), :497 (intermediate), :512 (output), :798 (MLM transform),
  * :822 (tied decoder); nn.Conv2d patch embedding beit2.py:225,231 (as a GEMM over patch rows).
  *
- * C[M,N] = epilogue(A[M,K] . B[N,K]^T), bf16 operands, fp32 MFMA accumulation.  K % 64 == 0, N % 4 == 0.
+ * C[M,N] = epilogue(A[M,K] . B[N,K]^T), bf16 operands, fp32 MFMA accumulation.  K % 64 == 0, N % 8 == 0.
  *   v = acc + bias[n]
  *   act == 1: aux[m,n] = bf16(v); v = gelu(v)        (erf form)   -> fc1 / intermediate forward
  *   act == 2: v *= gelu'(aux[m,n])                                 -> dgrad through the GELU

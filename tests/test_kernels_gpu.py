@@ -37,8 +37,16 @@ def relerr(got, ref):
     return float((got - ref).abs().max() / ref.abs().max().clamp_min(1e-12))
 
 
+@pytest.fixture(params=[1, 2], ids=["tile128x128", "tile256x128"])
+def nt_tile(request):
+    lib = importlib.import_module("x2-vlm_amd._lib").lib()
+    lib.x2_tune(1, request.param)
+    yield request.param
+    lib.x2_tune(1, 0)
+
+
 @pytest.mark.parametrize("M,N,K_", [(256, 256, 128), (300, 200, 192), (788, 2304, 768), (12608, 768, 768), (100, 30528, 64)])
-def test_gemm_nt_plain_and_epilogues(K, M, N, K_):
+def test_gemm_nt_plain_and_epilogues(K, M, N, K_, nt_tile):
     A, B = bf(rnd(M, K_, seed=1)), bf(rnd(N, K_, seed=2, scale=K_ ** -0.5))
     ref = A.float() @ B.float().t()
     out = K.gemm_nt(A.to(dev), B.to(dev), out_dtype=torch.float32)

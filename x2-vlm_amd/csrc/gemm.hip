@@ -32,6 +32,7 @@ struct GemmNT {
   DropSpec drop;            // hidden dropout on (acc + bias) before the residual add (xbert.py:429, 513)
   const float* rowscale;    // [M] per-row factor before the residual add: DropPath keep/(1-p) per sample (beit2.py:206-207)
   float* colsum;            // [N] += column sums of the stored C (bias gradient of the layer below, fused)
+  int dbg;                  // ablation switches for probes/bench_gemm.py: 1 = no operand loads in the K loop, 2 = no MFMA, 4 = no epilogue
 };
 
 // logical tile id -> (row tile, col tile): XCD-contiguous chunks, inside a chunk groups of `gm` row panels
@@ -40,6 +41,94 @@ __device__ __forceinline__ void tile_coords(int t, int tiles_m, int tiles_n, int
   const int rows = min(gm, tiles_m - first), r = t - g * gsz;
   tm = first + r % rows;
   tn = r / rows;
+}
+
+// ---- epilogue shared by the NT kernels ------------------------------------------------------------------
+// The accumulators hold C^T fragments (lane = one row m, 4 consecutive n per 16x16 tile), which would store
+// as 16 scattered 32-byte pieces per instruction.  Each wave instead parks its 64x64 fp32 sub-tile in LDS
+// (two 32-row halves, rows padded to 68 floats: conflict-free both ways) and re-reads it row-major, so that
+// 16 lanes cover one 256-byte row segment: full-line loads of the residual / saved pre-activation and
+// full-line stores of C and aux.  bias / GELU / GELU' / dropout / layer-scale / DropPath / residual are applied
+// on the way out; optional column sums (bias gradient of the layer below) leave as one atomic per column.
+// Caller guarantees (barrier) that no wave still reads operand tiles from `smem`.
+__device__ __forceinline__ void nt_epilogue(const GemmNT& p, f32x4 (&acc)[4][4], char* smem, int wave, int lane, int mw0, int nw0) {
+  const int frow = lane & 15, fg = lane >> 4;
+  float* stg = reinterpret_cast<float*>(smem) + wave * (32 * 68);
+  // read-back: 8 lanes x 8 columns cover one 64-column row (32-byte fp32 reads, 16-byte bf16 / 2 x 16-byte fp32 stores),
+  // 8 rows per instruction: half the store instructions of a 4-column mapping (the tail is store-issue bound)
+  const int er = lane >> 3, ec = (lane & 7) * 8;
+  const int n = nw0 + ec;
+  const bool nok = n < p.N;           // N % 8 == 0 is required by the host wrapper when this path is used
+  float bb[8], gg[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { bb[e] = 0.f; gg[e] = 1.f; }
+  if (nok && p.bias) { const float4 b0 = *reinterpret_cast<const float4*>(p.bias + n), b1 = *reinterpret_cast<const float4*>(p.bias + n + 4);
+    bb[0] = b0.x; bb[1] = b0.y; bb[2] = b0.z; bb[3] = b0.w; bb[4] = b1.x; bb[5] = b1.y; bb[6] = b1.z; bb[7] = b1.w; }
+  if (nok && p.gamma) { const float4 g0 = *reinterpret_cast<const float4*>(p.gamma + n), g1 = *reinterpret_cast<const float4*>(p.gamma + n + 4);
+    gg[0] = g0.x; gg[1] = g0.y; gg[2] = g0.z; gg[3] = g0.w; gg[4] = g1.x; gg[5] = g1.y; gg[6] = g1.z; gg[7] = g1.w; }
+  float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        *reinterpret_cast<f32x4*>(stg + (ii * 16 + frow) * 68 + j * 16 + fg * 4) = acc[half * 2 + ii][j];
+    // same-wave LDS traffic only: no barrier, the compiler's lgkmcnt wait orders write -> read
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const int row = rr * 8 + er;
+      const int m = mw0 + half * 32 + row;
+      const float4 a0 = *reinterpret_cast<const float4*>(stg + row * 68 + ec), a1 = *reinterpret_cast<const float4*>(stg + row * 68 + ec + 4);
+      if (m >= p.M || !nok) continue;
+      float v[8] = {a0.x + bb[0], a0.y + bb[1], a0.z + bb[2], a0.w + bb[3], a1.x + bb[4], a1.y + bb[5], a1.z + bb[6], a1.w + bb[7]};
+      if (p.act == 1) {
+        *reinterpret_cast<u32x4*>(p.aux + (size_t)m * p.ldaux + n) =
+            u32x4{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7])};
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] = gelu_f(v[r]);
+      } else if (p.act == 2) {
+        const u32x4 pre = *reinterpret_cast<const u32x4*>(p.aux + (size_t)m * p.ldaux + n);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { v[2 * r] *= dgelu_f(bf_lo(pre[r])); v[2 * r + 1] *= dgelu_f(bf_hi(pre[r])); }
+      } else if (p.aux) {
+        *reinterpret_cast<u32x4*>(p.aux + (size_t)m * p.ldaux + n) =
+            u32x4{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7])};
+      }
+      if (p.drop.thr16) {
+        float dm[4];
+        drop_mul4(p.drop, (uint32_t)m * (uint32_t)p.N + (uint32_t)n, dm);
+        v[0] *= dm[0]; v[1] *= dm[1]; v[2] *= dm[2]; v[3] *= dm[3];
+        drop_mul4(p.drop, (uint32_t)m * (uint32_t)p.N + (uint32_t)n + 4u, dm);
+        v[4] *= dm[0]; v[5] *= dm[1]; v[6] *= dm[2]; v[7] *= dm[3];
+      }
+      const float rs_ = p.rowscale ? p.rowscale[m] : 1.f;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) v[r] *= gg[r] * rs_;
+      if (p.resid) {
+        const float4 r0 = *reinterpret_cast<const float4*>(p.resid + (size_t)m * p.ldr + n), r1 = *reinterpret_cast<const float4*>(p.resid + (size_t)m * p.ldr + n + 4);
+        v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w; v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
+      }
+#pragma unroll
+      for (int r = 0; r < 8; ++r) cs[r] += v[r];
+      if (p.out_f32) {
+        float* c = reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n;
+        *reinterpret_cast<float4*>(c) = float4{v[0], v[1], v[2], v[3]};
+        *reinterpret_cast<float4*>(c + 4) = float4{v[4], v[5], v[6], v[7]};
+      } else {
+        *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.C) + (size_t)m * p.ldc + n) =
+            u32x4{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7])};
+      }
+    }
+  }
+  if (p.colsum) {     // lanes sharing (lane & 7) hold the same 8 columns for different rows: fold 8 -> 1, one atomic per column
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { cs[e] += __shfl_xor(cs[e], 8, 64); cs[e] += __shfl_xor(cs[e], 16, 64); cs[e] += __shfl_xor(cs[e], 32, 64); }
+    if (er == 0 && nok) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) atomicAdd(p.colsum + n + e, cs[e]);
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -91,8 +180,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNT p) {
   for (int kt = 0; kt < nk; ++kt) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
+    if (kt + 1 < nk && !(p.dbg & 1)) stage(kt + 1, (kt + 1) & 1);
     const uint32_t sb = lds0 + (kt & 1) * STAGE_BYTES;
+    if (p.dbg & 2) continue;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const uint32_t cs = (uint32_t)(((ks * 4 + fg) ^ fsw) << 4);
@@ -110,77 +200,93 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNT p) {
     }
   }
 
-  // ---- epilogue ----
-  // The accumulators hold C^T fragments (lane = one row m, 4 consecutive n per 16x16 tile), which would store
-  // as 16 scattered 32-byte pieces per instruction.  Each wave instead parks its 64x64 fp32 sub-tile in LDS
-  // (two 32-row halves, rows padded to 68 floats: conflict-free both ways) and re-reads it row-major, so that
-  // 16 lanes cover one 256-byte row segment: full-line loads of the residual / saved pre-activation and
-  // full-line stores of C and aux.  bias / GELU / GELU' / layer-scale / residual are applied on the way out.
   __syncthreads();                                   // every wave is done reading the last operand tiles
-  float* stg = reinterpret_cast<float*>(smem) + wave * (32 * 68);
-  const int er = lane >> 4, ec = (lane & 15) * 4;    // read-back: row offset within a group of 4, column
-  const int n = n0 + wn * 64 + ec;
-  float4 bb{0.f, 0.f, 0.f, 0.f}, gg{1.f, 1.f, 1.f, 1.f};
-  const bool nok = n < p.N;
-  if (nok && p.bias) bb = *reinterpret_cast<const float4*>(p.bias + n);
-  if (nok && p.gamma) gg = *reinterpret_cast<const float4*>(p.gamma + n);
-  float cs[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int half = 0; half < 2; ++half) {
-#pragma unroll
-    for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        *reinterpret_cast<f32x4*>(stg + (ii * 16 + frow) * 68 + j * 16 + fg * 4) = acc[half * 2 + ii][j];
-    // same-wave LDS traffic only: no barrier, the compiler's lgkmcnt wait orders write -> read
-#pragma unroll
-    for (int rr = 0; rr < 8; ++rr) {
-      const int row = rr * 4 + er;
-      const int m = m0 + wm * 64 + half * 32 + row;
-      const float4 a4 = *reinterpret_cast<const float4*>(stg + row * 68 + ec);
-      if (m >= p.M || !nok) continue;
-      float v[4] = {a4.x + bb.x, a4.y + bb.y, a4.z + bb.z, a4.w + bb.w};
-      if (p.act == 1) {
-        *reinterpret_cast<u32x2*>(p.aux + (size_t)m * p.ldaux + n) = u32x2{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])};
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = gelu_f(v[r]);
-      } else if (p.act == 2) {
-        const u32x2 pre = *reinterpret_cast<const u32x2*>(p.aux + (size_t)m * p.ldaux + n);
-        v[0] *= dgelu_f(bf_lo(pre[0])); v[1] *= dgelu_f(bf_hi(pre[0]));
-        v[2] *= dgelu_f(bf_lo(pre[1])); v[3] *= dgelu_f(bf_hi(pre[1]));
-      } else if (p.aux) {
-        *reinterpret_cast<u32x2*>(p.aux + (size_t)m * p.ldaux + n) = u32x2{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])};
-      }
-      if (p.drop.thr16) {
-        float dm[4];
-        drop_mul4(p.drop, (uint32_t)m * (uint32_t)p.N + (uint32_t)n, dm);
-        v[0] *= dm[0]; v[1] *= dm[1]; v[2] *= dm[2]; v[3] *= dm[3];
-      }
-      v[0] *= gg.x; v[1] *= gg.y; v[2] *= gg.z; v[3] *= gg.w;
-      if (p.rowscale) { const float rs_ = p.rowscale[m]; v[0] *= rs_; v[1] *= rs_; v[2] *= rs_; v[3] *= rs_; }
-      if (p.resid) {
-        const float4 rs = *reinterpret_cast<const float4*>(p.resid + (size_t)m * p.ldr + n);
-        v[0] += rs.x; v[1] += rs.y; v[2] += rs.z; v[3] += rs.w;
-      }
-      cs[0] += v[0]; cs[1] += v[1]; cs[2] += v[2]; cs[3] += v[3];
-      if (p.out_f32)
-        *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n) = float4{v[0], v[1], v[2], v[3]};
-      else
-        *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(p.C) + (size_t)m * p.ldc + n) =
-            u32x2{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])};
-    }
-  }
-  if (p.colsum) {     // lanes sharing (lane & 15) hold the same 4 columns for different rows: fold 4 -> 1, one atomic per column
-#pragma unroll
-    for (int e = 0; e < 4; ++e) { cs[e] += __shfl_xor(cs[e], 16, 64); cs[e] += __shfl_xor(cs[e], 32, 64); }
-    if (er == 0 && nok) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) atomicAdd(p.colsum + n + e, cs[e]);
-    }
-  }
+  if (p.dbg & 4) { if (acc[0][0][0] == 12345.678f) reinterpret_cast<float*>(p.C)[0] = acc[1][1][1] + acc[2][2][2] + acc[3][3][3]; return; }
+  nt_epilogue(p, acc, smem, wave, lane, m0 + wm * 64, n0 + wn * 64);
 }
 
-// tuning knobs for A/B measurements (probes/bench_gemm.py): [0] GROUP_M of the NT raster, [1] TN raster group
+// ---------------------------------------------------------------------------------------------
+// NT, large tile: 256x128 output tile, 512 threads (8 waves as 4x2, same 64x64 per-wave code), 3-deep LDS ring
+// (3 x 48 KB): tile kt+2 is requested while tile kt is multiplied, the wait in front of each barrier is a
+// COUNTED s_waitcnt vmcnt(6) (the six LDS-DMA instructions of tile kt+1 stay in flight across the barrier), so
+// the prefetch distance is two K-steps instead of one.  25 % less operand traffic per FLOP than 128x128.
+// ---------------------------------------------------------------------------------------------
+#define W8_STAGE_BYTES (48 * 1024)
+#define W8_LDS_BYTES (3 * W8_STAGE_BYTES)
+__global__ __launch_bounds__(512, 2) void gemm_nt_w8_kernel(GemmNT p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tiles_n = (p.N + 127) / 128, tiles_m = (p.M + 255) / 256;
+  int tm, tn;
+  tile_coords(xcd_remap(blockIdx.x, gridDim.x), tiles_m, tiles_n, p.group_m, tm, tn);
+  const int m0 = tm * 256, n0 = tn * 128;
+
+  const bf16_t* srcA[4]; const bf16_t* srcB[2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int q = i * 512 + tid, row = q >> 3, c = (q & 7) ^ (row & 7);
+    int ra = m0 + row; ra = ra < p.M ? ra : p.M - 1;
+    srcA[i] = p.A + (size_t)ra * p.lda + c * 8;
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int q = i * 512 + tid, row = q >> 3, c = (q & 7) ^ (row & 7);
+    int rb = n0 + row; rb = rb < p.N ? rb : p.N - 1;
+    srcB[i] = p.B + (size_t)rb * p.ldb + c * 8;
+  }
+  auto stage = [&](int kt, int buf) {
+    char* base = smem + buf * W8_STAGE_BYTES;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) glds16(srcA[i] + (size_t)kt * BK, base + (i * 512 + wave * 64) * 16);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) glds16(srcB[i] + (size_t)kt * BK, base + 32768 + (i * 512 + wave * 64) * 16);
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const uint32_t lds0 = lds_addr(smem);
+  const int frow = lane & 15, fg = lane >> 4, fsw = lane & 7;
+  const uint32_t offA = (uint32_t)((wm * 64 + frow) * 128);
+  const uint32_t offB = (uint32_t)(32768 + (wn * 64 + frow) * 128);
+
+  const int nk = p.K / BK;
+  stage(0, 0);
+  if (nk > 1) stage(1, 1);
+  int buf = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    // tile kt must have landed; tile kt+1 (6 LDS-DMA instructions per thread) may stay in flight
+    if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    // every wave has passed the barrier => compute(kt-1) is finished => ring slot (kt+2) % 3 is free
+    if (kt + 2 < nk) stage(kt + 2, buf >= 1 ? buf - 1 : 2);
+    const uint32_t sb = lds0 + buf * W8_STAGE_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const uint32_t cs = (uint32_t)(((ks * 4 + fg) ^ fsw) << 4);
+      bf16x8 a[4], b[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = lds_read_b128(sb + offA + i * 2048 + cs);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b[j] = lds_read_b128(sb + offB + j * 2048 + cs);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+    }
+    buf = buf == 2 ? 0 : buf + 1;
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // every wave is done reading operand tiles
+  nt_epilogue(p, acc, smem, wave, lane, m0 + wm * 64, n0 + wn * 64);
+}
+
+// tuning knobs for A/B measurements (probes/bench_gemm.py): [0] GROUP_M of the NT raster, [1] NT tile choice
 static int g_tune[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 extern "C" int x2_tune(int key, int value) {
   if (key < 0 || key >= 8) return X2_ERR_ARG;
@@ -195,14 +301,26 @@ extern "C" int x2_gemm_nt(const void* A, const void* B, void* C, int M, int N, i
   X2_REQUIRE(M > 0 && N > 0 && K > 0, "x2_gemm_nt: empty problem M=%d N=%d K=%d", M, N, K);
   X2_REQUIRE(drop_thr16 < 65536u, "x2_gemm_nt: drop_thr16=%u", drop_thr16);
   X2_REQUIRE(K % BK == 0, "x2_gemm_nt: K=%d must be a multiple of %d", K, BK);
-  X2_REQUIRE(N % 4 == 0, "x2_gemm_nt: N=%d must be a multiple of 4", N);
-  X2_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && ldc % 4 == 0, "x2_gemm_nt: leading dims must keep 16-byte rows");
+  X2_REQUIRE(N % 8 == 0, "x2_gemm_nt: N=%d must be a multiple of 8", N);
+  X2_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && ldc % 8 == 0, "x2_gemm_nt: leading dims must keep 16-byte rows");
   X2_REQUIRE(act == 0 || aux, "x2_gemm_nt: act=%d needs aux", act);
-  X2_REQUIRE((!resid || ldr % 4 == 0) && (!aux || ldaux % 4 == 0), "x2_gemm_nt: ldr/ldaux alignment");
+  X2_REQUIRE((!resid || ldr % 4 == 0) && (!aux || ldaux % 8 == 0), "x2_gemm_nt: ldr/ldaux alignment");
   GemmNT p{(const bf16_t*)A, (const bf16_t*)B, C, bias, gamma, resid, (bf16_t*)aux, M, N, K, lda, ldb, ldc, ldr, ldaux, act, out_f32,
-           g_tune[0] > 0 ? g_tune[0] : 8, DropSpec{drop_thr16, drop_seed, drop_scale}, rowscale, colsum};
-  const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
-  hipLaunchKernelGGL(gemm_nt_kernel, dim3(tiles), dim3(256), GEMM_LDS_BYTES, (hipStream_t)stream, p);
+           g_tune[0] > 0 ? g_tune[0] : 8, DropSpec{drop_thr16, drop_seed, drop_scale}, rowscale, colsum, g_tune[2]};
+  // tile choice: [1] = 0 auto, 1 force 128x128 (4 waves), 2 force 256x128 (8 waves, 3-deep ring)
+  const int tiles8 = ((M + 255) / 256) * ((N + 127) / 128);
+  const bool big = g_tune[1] == 2 || (g_tune[1] == 0 && tiles8 >= 2 * 256);
+  if (big) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_w8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, W8_LDS_BYTES);
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(gemm_nt_w8_kernel, dim3(tiles8), dim3(512), W8_LDS_BYTES, (hipStream_t)stream, p);
+  } else {
+    const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+    hipLaunchKernelGGL(gemm_nt_kernel, dim3(tiles), dim3(256), GEMM_LDS_BYTES, (hipStream_t)stream, p);
+  }
   return x2_check_launch("x2_gemm_nt");
 }
 

@@ -496,18 +496,32 @@ extern "C" int x2_relpos_bias(const float* table, const long* index, float* bias
                      biasT, N, H, ld, ldT);
   return x2_check_launch("x2_relpos_bias");
 }
-// dtable[index[i][j]][h] += sum_b dS[b][h][i][j]   (dS bf16 [B][H][N][ld])
+// dtable[index[i][j]][h] += sum_b dS[b][h][i][j]   (dS bf16 [B][H][N][ld], ld % 8 == 0).
+// One thread = 8 consecutive j of one (h, i): 16-byte loads down the batch, then 8 scatter-adds.
 __global__ __launch_bounds__(256) void relpos_bias_bwd_kernel(const bf16_t* __restrict__ dS, const long* __restrict__ index,
                                                               float* dtable, int B, int N, int H, int ld) {
-  const int h = blockIdx.y, i = blockIdx.x;
-  for (int j = threadIdx.x; j < N; j += 256) {
-    float acc = 0.f;
-    for (int b = 0; b < B; ++b) acc += bf2f(dS[(((long)b * H + h) * N + i) * ld + j]);
-    atomicAdd(dtable + index[(long)i * N + j] * H + h, acc);
+  const int per_row = ld >> 3;
+  const long t = blockIdx.x * 256L + threadIdx.x;
+  if (t >= (long)H * N * per_row) return;
+  const int j0 = (int)(t % per_row) * 8, i = (int)((t / per_row) % N), h = (int)(t / ((long)per_row * N));
+  if (j0 >= N) return;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const bf16_t* p = dS + ((long)h * N + i) * ld + j0;
+  const long bstride = (long)H * N * ld;
+#pragma unroll 4
+  for (int b = 0; b < B; ++b) {
+    const u32x4 v = *reinterpret_cast<const u32x4*>(p + b * bstride);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { acc[2 * e] += bf_lo(v[e]); acc[2 * e + 1] += bf_hi(v[e]); }
   }
+#pragma unroll
+  for (int e = 0; e < 8; ++e)
+    if (j0 + e < N) atomicAdd(dtable + index[(long)i * N + j0 + e] * H + h, acc[e]);
 }
 extern "C" int x2_relpos_bias_bwd(const void* dS, const long* index, float* dtable, int B, int N, int H, int ld, void* stream) {
-  X2_REQUIRE(B > 0 && N > 0 && H > 0 && ld >= N, "x2_relpos_bias_bwd: B=%d N=%d H=%d ld=%d", B, N, H, ld);
-  hipLaunchKernelGGL(relpos_bias_bwd_kernel, dim3(N, H), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dS, index, dtable, B, N, H, ld);
+  X2_REQUIRE(B > 0 && N > 0 && H > 0 && ld >= N && ld % 8 == 0, "x2_relpos_bias_bwd: B=%d N=%d H=%d ld=%d", B, N, H, ld);
+  const long threads = (long)H * N * (ld >> 3);
+  hipLaunchKernelGGL(relpos_bias_bwd_kernel, dim3((int)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dS, index,
+                     dtable, B, N, H, ld);
   return x2_check_launch("x2_relpos_bias_bwd");
 }

@@ -110,8 +110,15 @@ class SideStream:
     of the main stream leave idle at their tails (594-tile GEMMs on 512 workgroup slots, HBM-bound row kernels)."""
 
     def __init__(self):
-        self.stream = None
+        self.streams = {}          # one side stream per launching stream (vision and text stages run concurrently)
         self.enabled = True
+
+    @property
+    def stream(self):
+        key = torch.cuda.current_stream().cuda_stream
+        if key not in self.streams:
+            self.streams[key] = torch.cuda.Stream()
+        return self.streams[key]
 
     def launch(self, fn, tensors):
         """Run fn() on the side stream after everything enqueued so far on the current stream; returns an event
@@ -119,23 +126,24 @@ class SideStream:
         if not self.enabled or not torch.cuda.is_available():
             fn()
             return None
-        if self.stream is None:
-            self.stream = torch.cuda.Stream()
+        side = self.stream
         ev = torch.cuda.Event()
         ev.record()
-        self.stream.wait_event(ev)
+        side.wait_event(ev)
         done = torch.cuda.Event()
-        with torch.cuda.stream(self.stream):
+        with torch.cuda.stream(side):
             fn()
             done.record()
         for t in tensors:
-            t.record_stream(self.stream)
+            t.record_stream(side)
         return done
 
     def join(self):
         """Make the current stream wait for the side stream (call before gradients leave the stage)."""
-        if self.stream is not None and self.enabled:
-            torch.cuda.current_stream().wait_stream(self.stream)
+        if self.enabled and torch.cuda.is_available():
+            key = torch.cuda.current_stream().cuda_stream
+            if key in self.streams:
+                torch.cuda.current_stream().wait_stream(self.streams[key])
 
 
 SIDE = SideStream()

@@ -68,12 +68,13 @@ _WS = {}
 
 
 def workspace(device, nfloats):
-    """Scratch for the two-stage column reductions: one growing fp32 buffer per device; kernels on one stream use
-    it strictly in order (stage 1 writes, stage 2 reads, next kernel overwrites)."""
-    buf = _WS.get(device)
+    """Scratch for the two-stage column reductions: one growing fp32 buffer per (device, stream); kernels on one
+    stream use it strictly in order (stage 1 writes, stage 2 reads, next kernel overwrites)."""
+    key = (device, torch.cuda.current_stream().cuda_stream)
+    buf = _WS.get(key)
     if buf is None or buf.numel() < nfloats:
         buf = torch.empty(max(nfloats, 1 << 22), device=device, dtype=F32)
-        _WS[device] = buf
+        _WS[key] = buf
     return buf
 
 
