@@ -44,16 +44,17 @@ def nt_case(M, N, Kd, epi):
 
 def main():
     knobs = [int(x) for x in (sys.argv[1].split(",") if len(sys.argv) > 1 else ["1", "2"])]
-    print("NT GEMM, knob1 (1 = 128x128 4-wave 2-stage, 2 = 256x128 8-wave 3-stage ring) in", knobs)
+    print("NT GEMM, knob3 (1 = 128x128 tile, 2 = 192x128 tile; both 4 waves, 2 workgroups / CU) in", knobs)
+    lib.x2_tune(1, 1)
     for name, M, N, Kd, epi in NT:
         fn = nt_case(M, N, Kd, epi)
         res = []
         for g in knobs:
-            lib.x2_tune(1, g)
+            lib.x2_tune(3, g)
             res.append(timeit(fn))
         fl = 2.0 * M * N * Kd
         print("  %-11s M=%5d N=%5d K=%4d %-5s " % (name, M, N, Kd, epi) + "  ".join("g%-2d %6.1fus %5.0fTF" % (g, t, fl / t / 1e6) for g, t in zip(knobs, res)))
-    lib.x2_tune(1, 1)
+    lib.x2_tune(3, 1)
     print("ablation on the 128x128 kernel (knob2: 0 full, 1 no loads in loop, 2 no MFMA, 4 no epilogue, 5 = 1+4, 6 = 2+4, 3 = 1+2)")
     for name, M, N, Kd, epi in NT[:5]:
         fn = nt_case(M, N, Kd, epi)
@@ -63,7 +64,7 @@ def main():
             res.append((g, timeit(fn)))
         lib.x2_tune(2, 0)
         print("  %-11s " % name + "  ".join("d%d %6.1fus" % r for r in res))
-    lib.x2_tune(1, 0)
+    lib.x2_tune(1, 0); lib.x2_tune(3, 0)
     print("TN grouped (weight grads)")
     for name, Mc, probs in [("vit block", 12608, [(768, 3072), (3072, 768), (768, 768), (2304, 768)]),
                             ("text layer", 3840, [(768, 3072), (3072, 768), (768, 768), (2304, 768)]),

@@ -51,7 +51,8 @@ __device__ __forceinline__ void tile_coords(int t, int tiles_m, int tiles_n, int
 // full-line stores of C and aux.  bias / GELU / GELU' / dropout / layer-scale / DropPath / residual are applied
 // on the way out; optional column sums (bias gradient of the layer below) leave as one atomic per column.
 // Caller guarantees (barrier) that no wave still reads operand tiles from `smem`.
-__device__ __forceinline__ void nt_epilogue(const GemmNT& p, f32x4 (&acc)[4][4], char* smem, int wave, int lane, int mw0, int nw0) {
+template <int TM>
+__device__ __forceinline__ void nt_epilogue(const GemmNT& p, f32x4 (&acc)[TM][4], char* smem, int wave, int lane, int mw0, int nw0) {
   const int frow = lane & 15, fg = lane >> 4;
   float* stg = reinterpret_cast<float*>(smem) + wave * (32 * 68);
   // read-back: 8 lanes x 8 columns cover one 64-column row (32-byte fp32 reads, 16-byte bf16 / 2 x 16-byte fp32 stores),
@@ -68,7 +69,7 @@ __device__ __forceinline__ void nt_epilogue(const GemmNT& p, f32x4 (&acc)[4][4],
     gg[0] = g0.x; gg[1] = g0.y; gg[2] = g0.z; gg[3] = g0.w; gg[4] = g1.x; gg[5] = g1.y; gg[6] = g1.z; gg[7] = g1.w; }
   float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int half = 0; half < 2; ++half) {
+  for (int half = 0; half < TM / 2; ++half) {
 #pragma unroll
     for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
@@ -135,45 +136,51 @@ __device__ __forceinline__ void nt_epilogue(const GemmNT& p, f32x4 (&acc)[4][4],
 // NT: both operands K-contiguous.  LDS image per operand: [128 rows][8 chunks of 16 B], chunk c of
 // row r stored at chunk position c ^ (r & 7)  -> conflict-free ds_read_b128 fragment reads.
 // ---------------------------------------------------------------------------------------------
+template <int TM>   // 16-row MFMA tiles per wave along M: 4 -> 128x128 block tile, 6 -> 192x128 (2 x 80 KB LDS = exactly 2 blocks / CU)
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNT p) {
+  constexpr int BMT = 32 * TM;                       // block rows (2 waves along M)
+  constexpr int A_BYTES = BMT * 128, STG = A_BYTES + TILE_BYTES;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
-  const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
+  const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BMT - 1) / BMT;
   int tm, tn;
   tile_coords(xcd_remap(blockIdx.x, gridDim.x), tiles_m, tiles_n, p.group_m, tm, tn);
-  const int m0 = tm * BM, n0 = tn * BN;
+  const int m0 = tm * BMT, n0 = tn * BN;
 
-  // per-thread global sources for the 4+4 chunks this thread stages per K-step
-  const bf16_t* srcA[4]; const bf16_t* srcB[4];
+  // per-thread global sources for the TM+4 chunks this thread stages per K-step
+  const bf16_t* srcA[TM]; const bf16_t* srcB[4];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int q = i * 256 + tid, row = q >> 3, c = (q & 7) ^ (row & 7);
+    int ra = m0 + row; ra = ra < p.M ? ra : p.M - 1;
+    srcA[i] = p.A + (size_t)ra * p.lda + c * 8;
+  }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int q = i * 256 + tid, row = q >> 3, c = (q & 7) ^ (row & 7);
-    int ra = m0 + row; ra = ra < p.M ? ra : p.M - 1;
     int rb = n0 + row; rb = rb < p.N ? rb : p.N - 1;
-    srcA[i] = p.A + (size_t)ra * p.lda + c * 8;
     srcB[i] = p.B + (size_t)rb * p.ldb + c * 8;
   }
   auto stage = [&](int kt, int buf) {
-    char* base = smem + buf * STAGE_BYTES;
+    char* base = smem + buf * STG;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      glds16(srcA[i] + (size_t)kt * BK, base + (i * 256 + wave * 64) * 16);
-      glds16(srcB[i] + (size_t)kt * BK, base + TILE_BYTES + (i * 256 + wave * 64) * 16);
-    }
+    for (int i = 0; i < TM; ++i) glds16(srcA[i] + (size_t)kt * BK, base + (i * 256 + wave * 64) * 16);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) glds16(srcB[i] + (size_t)kt * BK, base + A_BYTES + (i * 256 + wave * 64) * 16);
   };
 
-  f32x4 acc[4][4];
+  f32x4 acc[TM][4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const uint32_t lds0 = lds_addr(smem);
   const int frow = lane & 15, fg = lane >> 4, fsw = lane & 7;
-  const uint32_t offA = (uint32_t)((wm * 64 + frow) * 128);
-  const uint32_t offB = (uint32_t)(TILE_BYTES + (wn * 64 + frow) * 128);
+  const uint32_t offA = (uint32_t)((wm * 16 * TM + frow) * 128);
+  const uint32_t offB = (uint32_t)(A_BYTES + (wn * 64 + frow) * 128);
 
   const int nk = p.K / BK;
   stage(0, 0);
@@ -181,18 +188,18 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNT p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (kt + 1 < nk && !(p.dbg & 1)) stage(kt + 1, (kt + 1) & 1);
-    const uint32_t sb = lds0 + (kt & 1) * STAGE_BYTES;
+    const uint32_t sb = lds0 + (kt & 1) * STG;
     if (p.dbg & 2) continue;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const uint32_t cs = (uint32_t)(((ks * 4 + fg) ^ fsw) << 4);
-      bf16x8 a[4], b[4];
+      bf16x8 a[TM], b[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) a[i] = lds_read_b128(sb + offA + i * 2048 + cs);
+      for (int i = 0; i < TM; ++i) a[i] = lds_read_b128(sb + offA + i * 2048 + cs);
 #pragma unroll
       for (int j = 0; j < 4; ++j) b[j] = lds_read_b128(sb + offB + j * 2048 + cs);
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           // operands swapped: accumulator tile = C^T, i.e. lane holds (m = frow, 4 consecutive n)
@@ -202,7 +209,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNT p) {
 
   __syncthreads();                                   // every wave is done reading the last operand tiles
   if (p.dbg & 4) { if (acc[0][0][0] == 12345.678f) reinterpret_cast<float*>(p.C)[0] = acc[1][1][1] + acc[2][2][2] + acc[3][3][3]; return; }
-  nt_epilogue(p, acc, smem, wave, lane, m0 + wm * 64, n0 + wn * 64);
+  nt_epilogue<TM>(p, acc, smem, wave, lane, m0 + wm * 16 * TM, n0 + wn * 64);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -283,7 +290,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_w8_kernel(GemmNT p) {
     buf = buf == 2 ? 0 : buf + 1;
   }
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // every wave is done reading operand tiles
-  nt_epilogue(p, acc, smem, wave, lane, m0 + wm * 64, n0 + wn * 64);
+  nt_epilogue<4>(p, acc, smem, wave, lane, m0 + wm * 64, n0 + wn * 64);
 }
 
 // tuning knobs for A/B measurements (probes/bench_gemm.py): [0] GROUP_M of the NT raster, [1] NT tile choice
@@ -309,7 +316,9 @@ extern "C" int x2_gemm_nt(const void* A, const void* B, void* C, int M, int N, i
            g_tune[0] > 0 ? g_tune[0] : 8, DropSpec{drop_thr16, drop_seed, drop_scale}, rowscale, colsum, g_tune[2]};
   // tile choice: [1] = 0 auto, 1 force 128x128 (4 waves), 2 force 256x128 (8 waves, 3-deep ring)
   const int tiles8 = ((M + 255) / 256) * ((N + 127) / 128);
-  const bool big = g_tune[1] == 2 || (g_tune[1] == 0 && tiles8 >= 2 * 256);
+  // measured (probes/bench_gemm.py): two independent 4-wave workgroups per CU beat one 8-wave workgroup with a
+  // 3-deep ring on every shape of this model (676 vs 583 TFLOP/s on 12608x2304x768), so auto = 128x128
+  const bool big = g_tune[1] == 2;
   if (big) {
     static bool attr_set = false;
     if (!attr_set) {
@@ -318,8 +327,17 @@ extern "C" int x2_gemm_nt(const void* A, const void* B, void* C, int M, int N, i
     }
     hipLaunchKernelGGL(gemm_nt_w8_kernel, dim3(tiles8), dim3(512), W8_LDS_BYTES, (hipStream_t)stream, p);
   } else {
-    const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
-    hipLaunchKernelGGL(gemm_nt_kernel, dim3(tiles), dim3(256), GEMM_LDS_BYTES, (hipStream_t)stream, p);
+    // 192x128 tiles when that gives a single resident round (<= 2 workgroups per CU) where 128x128 needs a second,
+    // nearly empty one: the N = 768 outputs of this model (66 x 6 = 396 tiles vs 99 x 6 = 594 on 512 slots)
+    const int t128 = ((M + 127) / 128) * ((N + BN - 1) / BN), t192 = ((M + 191) / 192) * ((N + BN - 1) / BN);
+    const bool use192 = g_tune[3] == 2 || (g_tune[3] == 0 && t128 > 512 && t192 <= 512);
+    if (use192) {
+      static bool attr192 = false;
+      if (!attr192) { hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<6>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (192 * 128 + TILE_BYTES)); attr192 = true; }
+      hipLaunchKernelGGL(gemm_nt_kernel<6>, dim3(t192), dim3(256), 2 * (192 * 128 + TILE_BYTES), (hipStream_t)stream, p);
+    } else {
+      hipLaunchKernelGGL(gemm_nt_kernel<4>, dim3(t128), dim3(256), GEMM_LDS_BYTES, (hipStream_t)stream, p);
+    }
   }
   return x2_check_launch("x2_gemm_nt");
 }

@@ -473,8 +473,9 @@ class BertLayersFn(torch.autograd.Function):
                 _, wkvT = BANK.linear(p[c + "self.key.weight"], p[c + "self.value.weight"])
                 dh1 = K.gemm_nt(dq2, wqT, resid=ds2, out_dtype=F32)
                 denc = K.gemm_nt(dkv, wkvT, resid=denc, out_dtype=F32)
-                tn += [(ds2b, att2, G["crossattention.output.dense.weight"]), (dq2, h1b, G["crossattention.self.query.weight"]),
-                       (dkv, encb, G["c.kv_weight"])]
+                # longest contraction (image tokens) first: its tiles start in the first round of the grouped launch
+                tn = [(dkv, encb, G["c.kv_weight"])] + tn + [(ds2b, att2, G["crossattention.output.dense.weight"]),
+                                                            (dq2, h1b, G["crossattention.self.query.weight"])]
             else:
                 dh1 = dh2
             ds1, ds1b = K.layernorm_bwd(dh1, s1, m1, r1, p[a + "output.LayerNorm.weight"], G["attention.output.LayerNorm.weight"],
