@@ -86,10 +86,14 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world)
+    # X2_BENCH_BACKEND=gloo lets the N>1 code path (bucketed gradient reduction, ITC all-gather) be exercised on a
+    # 1-GPU box: all ranks share GPU 0 and exchange through gloo.  The driver's multi-GPU runs use RCCL ("nccl").
+    backend = os.environ.get("X2_BENCH_BACKEND", "nccl")
+    local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
 
     K = importlib.import_module("x2-vlm_amd.kernels")
     mp = importlib.import_module("x2-vlm_amd.model_pretrain")

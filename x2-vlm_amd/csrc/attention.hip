@@ -36,15 +36,27 @@ struct AttnArgs {
                                        // ((b*H + h)*Lq + q) * round_up(Lk,64) + key
 };
 
-// stage a [64 rows][64 d] bf16 tile (rows clamped to `nrows-1`) into LDS, chunk c of row r at c ^ (r & 7)
+// Staging of a [64 rows][64 d] bf16 tile (rows clamped to `nrows-1`) HBM -> registers -> LDS in two halves, so the
+// global loads of tile t+1 are in flight while tile t is multiplied (issue early / write late).  LDS image:
+// chunk c (16 B) of row r at c ^ (r & 7).
+template <int NT> struct TileRegs { u32x4 v[(512 + NT - 1) / NT]; };
 template <int NT>
-__device__ __forceinline__ void load_tile(char* lds, const bf16_t* src, long rs, int row0, int nrows, int tid) {
+__device__ __forceinline__ void tile_load(TileRegs<NT>& t, const bf16_t* src, long rs, int row0, int nrows, int tid) {
 #pragma unroll
-  for (int c = tid; c < 512; c += NT) {
-    const int r = c >> 3, ch = c & 7;
-    int gr = row0 + r; gr = gr < nrows ? gr : nrows - 1;
-    const u32x4 v = *reinterpret_cast<const u32x4*>(src + (long)gr * rs + ch * 8);
-    *reinterpret_cast<u32x4*>(lds + r * 128 + ((ch ^ (r & 7)) << 4)) = v;
+  for (int i = 0; i < (512 + NT - 1) / NT; ++i) {
+    const int c = tid + i * NT;
+    if (c < 512) {
+      int gr = row0 + (c >> 3); gr = gr < nrows ? gr : nrows - 1;
+      t.v[i] = *reinterpret_cast<const u32x4*>(src + (long)gr * rs + (c & 7) * 8);
+    }
+  }
+}
+template <int NT>
+__device__ __forceinline__ void tile_store(const TileRegs<NT>& t, char* lds, int tid) {
+#pragma unroll
+  for (int i = 0; i < (512 + NT - 1) / NT; ++i) {
+    const int c = tid + i * NT;
+    if (c < 512) { const int r = c >> 3, ch = c & 7; *reinterpret_cast<u32x4*>(lds + r * 128 + ((ch ^ (r & 7)) << 4)) = t.v[i]; }
   }
 }
 
@@ -82,249 +94,396 @@ __device__ __forceinline__ f32x4 add_bias_mask(f32x4 s, const AttnArgs& a, int h
 }
 
 // ------------------------------------------------------------------------------------------ forward
-template <int QW>
+// QW waves per workgroup, QG groups of 16 queries per wave (K / V^T fragments read from LDS once serve QG MFMAs).
+// RES: all K / V tiles of the (batch, head) are resident in LDS (Lk <= 256): one load phase and one barrier per
+// workgroup instead of one per key tile - these kernels are latency-bound, not MFMA-bound, at N = 197 / 30.
+template <int QW, int QG, bool RES>
 __global__ __launch_bounds__(64 * QW) void attn_fwd_kernel(AttnArgs a) {
-  __shared__ __attribute__((aligned(16))) char smem[2 * KT * 128];
+  constexpr int NT = 64 * QW;
+  __shared__ __attribute__((aligned(16))) char smem[RES ? 4 : 2][2 * KT * 128];   // {K tile, V tile} per slot
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fi = lane & 15, g = lane >> 4;
   const int h = blockIdx.y, b = blockIdx.z, bk = a.kv_idx ? a.kv_idx[b] : b;
-  const int q0 = blockIdx.x * 16 * QW + wave * 16;
-  const int q = min(q0 + fi, a.Lq - 1);
-  const uint32_t ktile = lds_addr(smem), vtile = ktile + KT * 128;
   const bf16_t* Kp = a.K + bk * a.k_bs + h * HD;
   const bf16_t* Vp = a.V + bk * a.v_bs + h * HD;
   const float sc2 = a.scale * LOG2E;
+  const int lkp = (a.Lk + 63) & ~63;
 
-  bf16x8 qf[2];
+  int q[QG]; bool qok[QG];
+  bf16x8 qf[QG][2];
+  f32x4 o[QG][4];
+  float m_i[QG], l_i[QG];
 #pragma unroll
-  for (int ks = 0; ks < 2; ++ks)
-    qf[ks] = *reinterpret_cast<const bf16x8*>(a.Q + b * a.q_bs + (long)q * a.q_rs + h * HD + ks * 32 + g * 8);
-  f32x4 o[4];
+  for (int gq = 0; gq < QG; ++gq) {
+    const int q0 = (blockIdx.x * QW * QG + wave * QG + gq) * 16;
+    qok[gq] = q0 + fi < a.Lq;
+    q[gq] = min(q0 + fi, a.Lq - 1);
 #pragma unroll
-  for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float m_i = NEG_BIG, l_i = 0.f;
+    for (int ks = 0; ks < 2; ++ks)
+      qf[gq][ks] = *reinterpret_cast<const bf16x8*>(a.Q + b * a.q_bs + (long)q[gq] * a.q_rs + h * HD + ks * 32 + g * 8);
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) o[gq][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    m_i[gq] = NEG_BIG; l_i[gq] = 0.f;
+  }
 
   const int nkt = (a.Lk + KT - 1) / KT;
-  for (int kt = 0; kt < nkt; ++kt) {
-    __syncthreads();
-    load_tile<64 * QW>(smem, Kp, a.k_rs, kt * KT, a.Lk, tid);
-    load_tile<64 * QW>(smem + KT * 128, Vp, a.v_rs, kt * KT, a.Lk, tid);
-    __syncthreads();
-    f32x4 st[4];
-    float mx = NEG_BIG;
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-      f32x4 acc{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(ktile, nt * 16 + fi, ks * 4 + g), qf[ks], acc, 0, 0, 0);
-      st[nt] = add_bias_mask(acc, a, h, b, q, kt * KT + nt * 16 + g * 4, sc2);
-      mx = fmaxf(fmaxf(mx, fmaxf(st[nt][0], st[nt][1])), fmaxf(st[nt][2], st[nt][3]));
+  TileRegs<NT> rk, rv;
+  if (RES) {
+    for (int kt = 0; kt < nkt; ++kt) {
+      tile_load<NT>(rk, Kp, a.k_rs, kt * KT, a.Lk, tid);
+      tile_load<NT>(rv, Vp, a.v_rs, kt * KT, a.Lk, tid);
+      tile_store<NT>(rk, smem[kt], tid);
+      tile_store<NT>(rv, smem[kt] + KT * 128, tid);
     }
-    mx = group_max(mx);
-    const float m_new = fmaxf(m_i, mx);
-    const float alpha = exp2f(m_i - m_new);
-    float rs = 0.f;
+  } else {
+    tile_load<NT>(rk, Kp, a.k_rs, 0, a.Lk, tid);
+    tile_load<NT>(rv, Vp, a.v_rs, 0, a.Lk, tid);
+    tile_store<NT>(rk, smem[0], tid);
+    tile_store<NT>(rv, smem[0] + KT * 128, tid);
+  }
+  __syncthreads();
+  for (int kt = 0; kt < nkt; ++kt) {
+    const uint32_t ktile = lds_addr(smem[RES ? kt : (kt & 1)]), vtile = ktile + KT * 128;
+    if (!RES && kt + 1 < nkt) {             // next tile's HBM loads fly under this tile's MFMAs
+      tile_load<NT>(rk, Kp, a.k_rs, (kt + 1) * KT, a.Lk, tid);
+      tile_load<NT>(rv, Vp, a.v_rs, (kt + 1) * KT, a.Lk, tid);
+    }
+    f32x4 st[QG][4];
+#pragma unroll
+    for (int gq = 0; gq < QG; ++gq)
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) st[gq][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { st[nt][r] = exp2f(st[nt][r] - m_new); rs += st[nt][r]; }
-    l_i = l_i * alpha + group_sum(rs);
-    m_i = m_new;
-    if (a.drop.thr16) {      // normalisation uses the undropped sum; only the P that multiplies V is dropped
-      const uint32_t e0 = (uint32_t)(((long)b * a.H + h) * a.Lq + q) * (uint32_t)((a.Lk + 63) & ~63) + (uint32_t)(kt * KT + g * 4);
+      for (int ks = 0; ks < 2; ++ks) {
+        const bf16x8 kfr = frag_rows(ktile, nt * 16 + fi, ks * 4 + g);
+#pragma unroll
+        for (int gq = 0; gq < QG; ++gq) st[gq][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr, qf[gq][ks], st[gq][nt], 0, 0, 0);
+      }
+    bf16x8 pf[QG][2];
+#pragma unroll
+    for (int gq = 0; gq < QG; ++gq) {
+      float mx = NEG_BIG;
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) {
-        float dm[4];
-        drop_mul4(a.drop, e0 + nt * 16, dm);
-        st[nt][0] *= dm[0]; st[nt][1] *= dm[1]; st[nt][2] *= dm[2]; st[nt][3] *= dm[3];
+        st[gq][nt] = add_bias_mask(st[gq][nt], a, h, b, q[gq], kt * KT + nt * 16 + g * 4, sc2);
+        mx = fmaxf(fmaxf(mx, fmaxf(st[gq][nt][0], st[gq][nt][1])), fmaxf(st[gq][nt][2], st[gq][nt][3]));
       }
+      mx = group_max(mx);
+      const float m_new = fmaxf(m_i[gq], mx);
+      const float alpha = exp2f(m_i[gq] - m_new);
+      float rs = 0.f;
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { st[gq][nt][r] = exp2f(st[gq][nt][r] - m_new); rs += st[gq][nt][r]; }
+      l_i[gq] = l_i[gq] * alpha + group_sum(rs);
+      m_i[gq] = m_new;
+      if (a.drop.thr16) {      // normalisation uses the undropped sum; only the P that multiplies V is dropped
+        const uint32_t e0 = (uint32_t)(((long)b * a.H + h) * a.Lq + q[gq]) * (uint32_t)lkp + (uint32_t)(kt * KT + g * 4);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+          float dm[4];
+          drop_mul4(a.drop, e0 + nt * 16, dm);
+          st[gq][nt][0] *= dm[0]; st[gq][nt][1] *= dm[1]; st[gq][nt][2] *= dm[2]; st[gq][nt][3] *= dm[3];
+        }
+      }
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) o[gq][dt] *= alpha;
+      pf[gq][0] = pack8(st[gq][0], st[gq][1]);
+      pf[gq][1] = pack8(st[gq][2], st[gq][3]);
     }
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) o[dt] *= alpha;
+    for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      const bf16x8 pf = pack8(st[2 * s], st[2 * s + 1]);
+      for (int dt = 0; dt < 4; ++dt) {
+        const bf16x8 vfr = frag_cols(vtile, s2, dt, lane);
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt)
-        o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_cols(vtile, s, dt, lane), pf, o[dt], 0, 0, 0);
+        for (int gq = 0; gq < QG; ++gq) o[gq][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfr, pf[gq][s2], o[gq][dt], 0, 0, 0);
+      }
+    if (!RES) {
+      if (kt + 1 < nkt) {
+        tile_store<NT>(rk, smem[(kt + 1) & 1], tid);
+        tile_store<NT>(rv, smem[(kt + 1) & 1] + KT * 128, tid);
+      }
+      __syncthreads();
     }
   }
-  if (q0 + fi < a.Lq) {
-    const float inv = 1.0f / l_i;
-    bf16_t* op = a.Out + b * a.o_bs + (long)q * a.o_rs + h * HD + g * 4;
+#pragma unroll
+  for (int gq = 0; gq < QG; ++gq) {
+    if (!qok[gq]) continue;
+    const float inv = 1.0f / l_i[gq];
+    bf16_t* op = a.Out + b * a.o_bs + (long)q[gq] * a.o_rs + h * HD + g * 4;
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt)
-      *reinterpret_cast<u32x2*>(op + dt * 16) = u32x2{pack_bf16(o[dt][0] * inv, o[dt][1] * inv), pack_bf16(o[dt][2] * inv, o[dt][3] * inv)};
-    if (g == 0) a.LSE[((long)b * a.H + h) * a.Lq + q] = m_i + log2f(l_i);   // log2 domain
+      *reinterpret_cast<u32x2*>(op + dt * 16) = u32x2{pack_bf16(o[gq][dt][0] * inv, o[gq][dt][1] * inv), pack_bf16(o[gq][dt][2] * inv, o[gq][dt][3] * inv)};
+    if (g == 0) a.LSE[((long)b * a.H + h) * a.Lq + q[gq]] = m_i[gq] + log2f(l_i[gq]);   // log2 domain
   }
 }
 
 // ------------------------------------------------------------------------------------------ backward: dQ (+ dS)
-template <int QW>
+template <int QW, int QG, bool RES>
 __global__ __launch_bounds__(64 * QW) void attn_bwd_dq_kernel(AttnArgs a) {
-  __shared__ __attribute__((aligned(16))) char smem[2 * KT * 128];
+  constexpr int NT = 64 * QW;
+  __shared__ __attribute__((aligned(16))) char smem[RES ? 4 : 2][2 * KT * 128];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fi = lane & 15, g = lane >> 4;
   const int h = blockIdx.y, b = blockIdx.z, bk = a.kv_idx ? a.kv_idx[b] : b;
-  const int q0 = blockIdx.x * 16 * QW + wave * 16;
-  const int q = min(q0 + fi, a.Lq - 1);
-  const bool qvalid = q0 + fi < a.Lq;
-  const uint32_t ktile = lds_addr(smem), vtile = ktile + KT * 128;
   const bf16_t* Kp = a.K + bk * a.k_bs + h * HD;
   const bf16_t* Vp = a.V + bk * a.v_bs + h * HD;
   const float sc2 = a.scale * LOG2E;
+  const int lkp = (a.Lk + 63) & ~63;
 
-  bf16x8 qf[2], dof[2];
-  float delta = 0.f;
+  int q[QG]; bool qok[QG];
+  bf16x8 qf[QG][2], dof[QG][2];
+  float delta[QG], lse[QG];
+  f32x4 dq[QG][4];
 #pragma unroll
-  for (int ks = 0; ks < 2; ++ks) {
-    qf[ks] = *reinterpret_cast<const bf16x8*>(a.Q + b * a.q_bs + (long)q * a.q_rs + h * HD + ks * 32 + g * 8);
-    dof[ks] = *reinterpret_cast<const bf16x8*>(a.dO + b * a.do_bs + (long)q * a.do_rs + h * HD + ks * 32 + g * 8);
-    const bf16x8 of = *reinterpret_cast<const bf16x8*>(a.O + b * a.o_bs + (long)q * a.o_rs + h * HD + ks * 32 + g * 8);
+  for (int gq = 0; gq < QG; ++gq) {
+    const int q0 = (blockIdx.x * QW * QG + wave * QG + gq) * 16;
+    qok[gq] = q0 + fi < a.Lq;
+    q[gq] = min(q0 + fi, a.Lq - 1);
+    float dl = 0.f;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) delta += bf2f((bf16_t)dof[ks][e]) * bf2f((bf16_t)of[e]);
+    for (int ks = 0; ks < 2; ++ks) {
+      qf[gq][ks] = *reinterpret_cast<const bf16x8*>(a.Q + b * a.q_bs + (long)q[gq] * a.q_rs + h * HD + ks * 32 + g * 8);
+      dof[gq][ks] = *reinterpret_cast<const bf16x8*>(a.dO + b * a.do_bs + (long)q[gq] * a.do_rs + h * HD + ks * 32 + g * 8);
+      const bf16x8 of = *reinterpret_cast<const bf16x8*>(a.O + b * a.o_bs + (long)q[gq] * a.o_rs + h * HD + ks * 32 + g * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) dl += bf2f((bf16_t)dof[gq][ks][e]) * bf2f((bf16_t)of[e]);
+    }
+    delta[gq] = group_sum(dl);
+    lse[gq] = a.LSE[((long)b * a.H + h) * a.Lq + q[gq]];
+    if (qok[gq] && g == 0) a.Delta[((long)b * a.H + h) * a.Lq + q[gq]] = delta[gq];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) dq[gq][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
-  delta = group_sum(delta);
-  const float lse = a.LSE[((long)b * a.H + h) * a.Lq + q];
-  if (qvalid && g == 0) a.Delta[((long)b * a.H + h) * a.Lq + q] = delta;
-
-  f32x4 dq[4];
-#pragma unroll
-  for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nkt = (a.Lk + KT - 1) / KT;
+  TileRegs<NT> rk, rv;
+  if (RES) {
+    for (int kt = 0; kt < nkt; ++kt) {
+      tile_load<NT>(rk, Kp, a.k_rs, kt * KT, a.Lk, tid);
+      tile_load<NT>(rv, Vp, a.v_rs, kt * KT, a.Lk, tid);
+      tile_store<NT>(rk, smem[kt], tid);
+      tile_store<NT>(rv, smem[kt] + KT * 128, tid);
+    }
+  } else {
+    tile_load<NT>(rk, Kp, a.k_rs, 0, a.Lk, tid);
+    tile_load<NT>(rv, Vp, a.v_rs, 0, a.Lk, tid);
+    tile_store<NT>(rk, smem[0], tid);
+    tile_store<NT>(rv, smem[0] + KT * 128, tid);
+  }
+  __syncthreads();
   for (int kt = 0; kt < nkt; ++kt) {
-    __syncthreads();
-    load_tile<64 * QW>(smem, Kp, a.k_rs, kt * KT, a.Lk, tid);
-    load_tile<64 * QW>(smem + KT * 128, Vp, a.v_rs, kt * KT, a.Lk, tid);
-    __syncthreads();
-    f32x4 ds[4];
+    const uint32_t ktile = lds_addr(smem[RES ? kt : (kt & 1)]), vtile = ktile + KT * 128;
+    if (!RES && kt + 1 < nkt) {
+      tile_load<NT>(rk, Kp, a.k_rs, (kt + 1) * KT, a.Lk, tid);
+      tile_load<NT>(rv, Vp, a.v_rs, (kt + 1) * KT, a.Lk, tid);
+    }
+    f32x4 ds[QG][4];
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
-      f32x4 s{0.f, 0.f, 0.f, 0.f}, dp{0.f, 0.f, 0.f, 0.f};
+      f32x4 s[QG], dp[QG];
+#pragma unroll
+      for (int gq = 0; gq < QG; ++gq) { s[gq] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[gq] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
-        s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(ktile, nt * 16 + fi, ks * 4 + g), qf[ks], s, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(vtile, nt * 16 + fi, ks * 4 + g), dof[ks], dp, 0, 0, 0);
+        const bf16x8 kfr = frag_rows(ktile, nt * 16 + fi, ks * 4 + g), vfr = frag_rows(vtile, nt * 16 + fi, ks * 4 + g);
+#pragma unroll
+        for (int gq = 0; gq < QG; ++gq) {
+          s[gq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr, qf[gq][ks], s[gq], 0, 0, 0);
+          dp[gq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfr, dof[gq][ks], dp[gq], 0, 0, 0);
+        }
       }
       const int key0 = kt * KT + nt * 16 + g * 4;
-      s = add_bias_mask(s, a, h, b, q, key0, sc2);
-      if (a.drop.thr16) {
-        float dm[4];
-        drop_mul4(a.drop, (uint32_t)(((long)b * a.H + h) * a.Lq + q) * (uint32_t)((a.Lk + 63) & ~63) + (uint32_t)key0, dm);
-        dp[0] *= dm[0]; dp[1] *= dm[1]; dp[2] *= dm[2]; dp[3] *= dm[3];
-      }
 #pragma unroll
-      for (int r = 0; r < 4; ++r) ds[nt][r] = exp2f(s[r] - lse) * (dp[r] - delta);
-      if (a.dS && qvalid && key0 < a.ds_ld)
-        *reinterpret_cast<u32x2*>(a.dS + (((long)b * a.H + h) * a.Lq + q) * a.ds_ld + key0) =
-            u32x2{pack_bf16(ds[nt][0], ds[nt][1]), pack_bf16(ds[nt][2], ds[nt][3])};
+      for (int gq = 0; gq < QG; ++gq) {
+        s[gq] = add_bias_mask(s[gq], a, h, b, q[gq], key0, sc2);
+        if (a.drop.thr16) {
+          float dm[4];
+          drop_mul4(a.drop, (uint32_t)(((long)b * a.H + h) * a.Lq + q[gq]) * (uint32_t)lkp + (uint32_t)key0, dm);
+          dp[gq][0] *= dm[0]; dp[gq][1] *= dm[1]; dp[gq][2] *= dm[2]; dp[gq][3] *= dm[3];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ds[gq][nt][r] = exp2f(s[gq][r] - lse[gq]) * (dp[gq][r] - delta[gq]);
+        if (a.dS && qok[gq] && key0 < a.ds_ld)
+          *reinterpret_cast<u32x2*>(a.dS + (((long)b * a.H + h) * a.Lq + q[gq]) * a.ds_ld + key0) =
+              u32x2{pack_bf16(ds[gq][nt][0], ds[gq][nt][1]), pack_bf16(ds[gq][nt][2], ds[gq][nt][3])};
+      }
     }
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) {
-      const bf16x8 dsf = pack8(ds[2 * s2], ds[2 * s2 + 1]);
+      bf16x8 dsf[QG];
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt)
-        dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_cols(ktile, s2, dt, lane), dsf, dq[dt], 0, 0, 0);
+      for (int gq = 0; gq < QG; ++gq) dsf[gq] = pack8(ds[gq][2 * s2], ds[gq][2 * s2 + 1]);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        const bf16x8 ktr = frag_cols(ktile, s2, dt, lane);
+#pragma unroll
+        for (int gq = 0; gq < QG; ++gq) dq[gq][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktr, dsf[gq], dq[gq][dt], 0, 0, 0);
+      }
+    }
+    if (!RES) {
+      if (kt + 1 < nkt) {
+        tile_store<NT>(rk, smem[(kt + 1) & 1], tid);
+        tile_store<NT>(rv, smem[(kt + 1) & 1] + KT * 128, tid);
+      }
+      __syncthreads();
     }
   }
-  if (qvalid) {
-    bf16_t* op = a.dQ + b * a.dq_bs + (long)q * a.dq_rs + h * HD + g * 4;
+#pragma unroll
+  for (int gq = 0; gq < QG; ++gq) {
+    if (!qok[gq]) continue;
+    bf16_t* op = a.dQ + b * a.dq_bs + (long)q[gq] * a.dq_rs + h * HD + g * 4;
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt)
-      *reinterpret_cast<u32x2*>(op + dt * 16) = u32x2{pack_bf16(dq[dt][0] * a.scale, dq[dt][1] * a.scale),
-                                                       pack_bf16(dq[dt][2] * a.scale, dq[dt][3] * a.scale)};
+      *reinterpret_cast<u32x2*>(op + dt * 16) = u32x2{pack_bf16(dq[gq][dt][0] * a.scale, dq[gq][dt][1] * a.scale),
+                                                       pack_bf16(dq[gq][dt][2] * a.scale, dq[gq][dt][3] * a.scale)};
   }
 }
 
 // ------------------------------------------------------------------------------------------ backward: dK, dV
-template <int KW>
+// KW waves, KG groups of 16 keys per wave; the workgroup walks every (sequence using this K/V batch, 64-query tile).
+template <int KW, int KG, bool RES>
 __global__ __launch_bounds__(64 * KW) void attn_bwd_dkv_kernel(AttnArgs a) {
-  __shared__ __attribute__((aligned(16))) char smem[2 * KT * 128 + 2 * KT * 4];
+  constexpr int NT = 64 * KW;
+  __shared__ __attribute__((aligned(16))) char smem[RES ? 4 : 2][2 * KT * 128 + 2 * KT * 4];   // {Q tile, dO tile, LSE[64], Delta[64]} per slot
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fi = lane & 15, g = lane >> 4;
   const int h = blockIdx.y, bk = blockIdx.z;
-  const int k0 = blockIdx.x * 16 * KW + wave * 16;
-  const int key = min(k0 + fi, a.Lk - 1);
-  const bool kvalid = k0 + fi < a.Lk;
-  const uint32_t qtile = lds_addr(smem), dotile = qtile + KT * 128;
-  float* lse_s = reinterpret_cast<float*>(smem + 2 * KT * 128);
-  float* del_s = lse_s + KT;
   const float sc2 = a.scale * LOG2E;
+  const int lkp = (a.Lk + 63) & ~63;
 
-  bf16x8 kf[2], vf[2];
+  int key[KG]; bool kok[KG];
+  bf16x8 kf[KG][2], vf[KG][2];
+  f32x4 dk[KG][4], dv[KG][4];
 #pragma unroll
-  for (int ks = 0; ks < 2; ++ks) {
-    kf[ks] = *reinterpret_cast<const bf16x8*>(a.K + bk * a.k_bs + (long)key * a.k_rs + h * HD + ks * 32 + g * 8);
-    vf[ks] = *reinterpret_cast<const bf16x8*>(a.V + bk * a.v_bs + (long)key * a.v_rs + h * HD + ks * 32 + g * 8);
+  for (int gk = 0; gk < KG; ++gk) {
+    const int k0 = (blockIdx.x * KW * KG + wave * KG + gk) * 16;
+    kok[gk] = k0 + fi < a.Lk;
+    key[gk] = min(k0 + fi, a.Lk - 1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      kf[gk][ks] = *reinterpret_cast<const bf16x8*>(a.K + bk * a.k_bs + (long)key[gk] * a.k_rs + h * HD + ks * 32 + g * 8);
+      vf[gk][ks] = *reinterpret_cast<const bf16x8*>(a.V + bk * a.v_bs + (long)key[gk] * a.v_rs + h * HD + ks * 32 + g * 8);
+    }
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) { dk[gk][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[gk][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
   }
-  f32x4 dk[4], dv[4];
-#pragma unroll
-  for (int dt = 0; dt < 4; ++dt) { dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
   const int sb = a.seq_off ? a.seq_off[bk] : bk, se = a.seq_off ? a.seq_off[bk + 1] : bk + 1;
   const int nqt = (a.Lq + KT - 1) / KT;
-  for (int si = sb; si < se; ++si) {
-    const int b = a.seq_ids ? a.seq_ids[si] : si;
-    const float mk = (a.mask ? a.mask[(long)b * a.mask_ld + key] : 0.f) * LOG2E;
-    for (int qt = 0; qt < nqt; ++qt) {
-      __syncthreads();
-      load_tile<64 * KW>(smem, a.Q + b * a.q_bs + h * HD, a.q_rs, qt * KT, a.Lq, tid);
-      load_tile<64 * KW>(smem + KT * 128, a.dO + b * a.do_bs + h * HD, a.do_rs, qt * KT, a.Lq, tid);
+  const int nit = (se - sb) * nqt;                   // flattened (sequence, q-tile) iterations
+  if (nit > 0) {
+    TileRegs<NT> rq, rdo;
+    float rl = 0.f, rd = 0.f;
+    auto fetch = [&](int it) {
+      const int si = sb + it / nqt, qt = it % nqt;
+      const int bb = a.seq_ids ? a.seq_ids[si] : si;
+      tile_load<NT>(rq, a.Q + bb * a.q_bs + h * HD, a.q_rs, qt * KT, a.Lq, tid);
+      tile_load<NT>(rdo, a.dO + bb * a.do_bs + h * HD, a.do_rs, qt * KT, a.Lq, tid);
       if (tid < KT) {
         const int qq = min(qt * KT + tid, a.Lq - 1);
-        lse_s[tid] = a.LSE[((long)b * a.H + h) * a.Lq + qq];
-        del_s[tid] = a.Delta[((long)b * a.H + h) * a.Lq + qq];
+        rl = a.LSE[((long)bb * a.H + h) * a.Lq + qq];
+        rd = a.Delta[((long)bb * a.H + h) * a.Lq + qq];
       }
-      __syncthreads();
-      f32x4 p[4], ds[4];
+    };
+    auto commit = [&](int buf) {
+      tile_store<NT>(rq, smem[buf], tid);
+      tile_store<NT>(rdo, smem[buf] + KT * 128, tid);
+      if (tid < KT) {
+        reinterpret_cast<float*>(smem[buf] + 2 * KT * 128)[tid] = rl;
+        reinterpret_cast<float*>(smem[buf] + 2 * KT * 128)[KT + tid] = rd;
+      }
+    };
+    if (RES) {
+      for (int it = 0; it < nit; ++it) { fetch(it); commit(it); }
+    } else {
+      fetch(0);
+      commit(0);
+    }
+    __syncthreads();
+    for (int it = 0; it < nit; ++it) {
+      const int si = sb + it / nqt, qt = it % nqt;
+      const int b = a.seq_ids ? a.seq_ids[si] : si;
+      char* buf = smem[RES ? it : (it & 1)];
+      const uint32_t qtile = lds_addr(buf), dotile = qtile + KT * 128;
+      const float* lse_s = reinterpret_cast<const float*>(buf + 2 * KT * 128);
+      const float* del_s = lse_s + KT;
+      if (!RES && it + 1 < nit) fetch(it + 1);
+      float mk[KG];
+#pragma unroll
+      for (int gk = 0; gk < KG; ++gk) mk[gk] = (a.mask ? a.mask[(long)b * a.mask_ld + key[gk]] : 0.f) * LOG2E;
+      f32x4 p[KG][4], ds[KG][4];
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        f32x4 s{0.f, 0.f, 0.f, 0.f}, dp{0.f, 0.f, 0.f, 0.f};
+        f32x4 s[KG], dp[KG];
+#pragma unroll
+        for (int gk = 0; gk < KG; ++gk) { s[gk] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[gk] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-          s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(qtile, t * 16 + fi, ks * 4 + g), kf[ks], s, 0, 0, 0);
-          dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(dotile, t * 16 + fi, ks * 4 + g), vf[ks], dp, 0, 0, 0);
+          const bf16x8 qfr = frag_rows(qtile, t * 16 + fi, ks * 4 + g), dofr = frag_rows(dotile, t * 16 + fi, ks * 4 + g);
+#pragma unroll
+          for (int gk = 0; gk < KG; ++gk) {
+            s[gk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qfr, kf[gk][ks], s[gk], 0, 0, 0);
+            dp[gk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dofr, vf[gk][ks], dp[gk], 0, 0, 0);
+          }
         }
-        // this lane: key = its own, queries qq0 .. qq0+3
+        // this lane: keys = its own (one per group), queries qq0 .. qq0+3
         const int qq0 = qt * KT + t * 16 + g * 4;
-        float4 bb{0.f, 0.f, 0.f, 0.f};
-        if (a.biasT) bb = *reinterpret_cast<const float4*>(a.biasT + ((long)h * a.Lk + key) * a.biasT_ld + qq0);
         const float4 ls = *reinterpret_cast<const float4*>(lse_s + t * 16 + g * 4);
         const float4 dl = *reinterpret_cast<const float4*>(del_s + t * 16 + g * 4);
-        const float bbv[4] = {bb.x, bb.y, bb.z, bb.w}, lsv[4] = {ls.x, ls.y, ls.z, ls.w}, dlv[4] = {dl.x, dl.y, dl.z, dl.w};
+        const float lsv[4] = {ls.x, ls.y, ls.z, ls.w}, dlv[4] = {dl.x, dl.y, dl.z, dl.w};
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const bool ok = kvalid && (qq0 + r < a.Lq);
-          const float pv = ok ? exp2f(s[r] * sc2 + bbv[r] * LOG2E + mk - lsv[r]) : 0.f;
-          float dm = 1.f;
-          if (a.drop.thr16)
-            dm = drop_mul(a.drop, (uint32_t)(((long)b * a.H + h) * a.Lq + min(qq0 + r, a.Lq - 1)) * (uint32_t)((a.Lk + 63) & ~63) + (uint32_t)key);
-          p[t][r] = pv * dm;
-          ds[t][r] = pv * (dp[r] * dm - dlv[r]);
+        for (int gk = 0; gk < KG; ++gk) {
+          float4 bb{0.f, 0.f, 0.f, 0.f};
+          if (a.biasT) bb = *reinterpret_cast<const float4*>(a.biasT + ((long)h * a.Lk + key[gk]) * a.biasT_ld + qq0);
+          const float bbv[4] = {bb.x, bb.y, bb.z, bb.w};
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const bool ok = kok[gk] && (qq0 + r < a.Lq);
+            const float pv = ok ? exp2f(s[gk][r] * sc2 + bbv[r] * LOG2E + mk[gk] - lsv[r]) : 0.f;
+            float dm = 1.f;
+            if (a.drop.thr16)
+              dm = drop_mul(a.drop, (uint32_t)(((long)b * a.H + h) * a.Lq + min(qq0 + r, a.Lq - 1)) * (uint32_t)lkp + (uint32_t)key[gk]);
+            p[gk][t][r] = pv * dm;
+            ds[gk][t][r] = pv * (dp[gk][r] * dm - dlv[r]);
+          }
         }
       }
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
-        const bf16x8 pf = pack8(p[2 * s2], p[2 * s2 + 1]);
-        const bf16x8 dsf = pack8(ds[2 * s2], ds[2 * s2 + 1]);
+        bf16x8 pf[KG], dsf[KG];
+#pragma unroll
+        for (int gk = 0; gk < KG; ++gk) { pf[gk] = pack8(p[gk][2 * s2], p[gk][2 * s2 + 1]); dsf[gk] = pack8(ds[gk][2 * s2], ds[gk][2 * s2 + 1]); }
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
-          dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_cols(dotile, s2, dt, lane), pf, dv[dt], 0, 0, 0);
-          dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_cols(qtile, s2, dt, lane), dsf, dk[dt], 0, 0, 0);
+          const bf16x8 dotr = frag_cols(dotile, s2, dt, lane), qtr = frag_cols(qtile, s2, dt, lane);
+#pragma unroll
+          for (int gk = 0; gk < KG; ++gk) {
+            dv[gk][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dotr, pf[gk], dv[gk][dt], 0, 0, 0);
+            dk[gk][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qtr, dsf[gk], dk[gk][dt], 0, 0, 0);
+          }
         }
+      }
+      if (!RES) {
+        if (it + 1 < nit) commit((it + 1) & 1);
+        __syncthreads();
       }
     }
   }
-  if (kvalid) {
-    bf16_t* kp = a.dK + bk * a.dk_bs + (long)key * a.dk_rs + h * HD + g * 4;
-    bf16_t* vp = a.dV + bk * a.dv_bs + (long)key * a.dv_rs + h * HD + g * 4;
+#pragma unroll
+  for (int gk = 0; gk < KG; ++gk) {
+    if (!kok[gk]) continue;
+    bf16_t* kp = a.dK + bk * a.dk_bs + (long)key[gk] * a.dk_rs + h * HD + g * 4;
+    bf16_t* vp = a.dV + bk * a.dv_bs + (long)key[gk] * a.dv_rs + h * HD + g * 4;
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) {
-      *reinterpret_cast<u32x2*>(kp + dt * 16) = u32x2{pack_bf16(dk[dt][0] * a.scale, dk[dt][1] * a.scale),
-                                                       pack_bf16(dk[dt][2] * a.scale, dk[dt][3] * a.scale)};
-      *reinterpret_cast<u32x2*>(vp + dt * 16) = u32x2{pack_bf16(dv[dt][0], dv[dt][1]), pack_bf16(dv[dt][2], dv[dt][3])};
+      *reinterpret_cast<u32x2*>(kp + dt * 16) = u32x2{pack_bf16(dk[gk][dt][0] * a.scale, dk[gk][dt][1] * a.scale),
+                                                       pack_bf16(dk[gk][dt][2] * a.scale, dk[gk][dt][3] * a.scale)};
+      *reinterpret_cast<u32x2*>(vp + dt * 16) = u32x2{pack_bf16(dv[gk][dt][0], dv[gk][dt][1]), pack_bf16(dv[gk][dt][2], dv[gk][dt][3])};
     }
   }
 }
@@ -345,8 +504,12 @@ extern "C" int x2_attn_fwd(const AttnArgs* pa, void* stream) {
   if (int e = check_common(a, "x2_attn_fwd")) return e;
   X2_REQUIRE(a.Q && a.K && a.V && a.Out && a.LSE, "x2_attn_fwd: null tensor");
   X2_REQUIRE((a.o_rs % 4 | a.o_bs % 4) == 0, "x2_attn_fwd: output strides");
-  if (a.Lq <= 32) hipLaunchKernelGGL(attn_fwd_kernel<2>, dim3((a.Lq + 31) / 32, a.H, a.B), dim3(128), 0, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL(attn_fwd_kernel<4>, dim3((a.Lq + 63) / 64, a.H, a.B), dim3(256), 0, (hipStream_t)stream, a);
+  const hipStream_t st = (hipStream_t)stream;
+  // long query side and <= 4 key tiles: 8-wave workgroups with K/V resident in LDS (64 KB); otherwise key tiles are
+  // streamed through a double buffer (short query side: the 64 KB would leave 2 waves / workgroup alone on a CU)
+  if (a.Lq <= 32) hipLaunchKernelGGL((attn_fwd_kernel<2, 1, false>), dim3(1, a.H, a.B), dim3(128), 0, st, a);
+  else if (a.Lq <= 64 || a.Lk > 256) hipLaunchKernelGGL((attn_fwd_kernel<4, 1, false>), dim3((a.Lq + 63) / 64, a.H, a.B), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((attn_fwd_kernel<8, 1, true>), dim3((a.Lq + 127) / 128, a.H, a.B), dim3(512), 0, st, a);
   return x2_check_launch("x2_attn_fwd");
 }
 
@@ -358,10 +521,18 @@ extern "C" int x2_attn_bwd(const AttnArgs* pa, void* stream) {
   X2_REQUIRE(!a.dS || (a.ds_ld % 64 == 0 && a.ds_ld >= a.Lk), "x2_attn_bwd: ds_ld must be a multiple of 64 covering Lk");
   X2_REQUIRE((a.kv_idx == nullptr) == (a.seq_off == nullptr), "x2_attn_bwd: kv_idx and seq_off/seq_ids come together");
   X2_REQUIRE(a.Bkv > 0, "x2_attn_bwd: Bkv");
-  if (a.Lq <= 32) hipLaunchKernelGGL(attn_bwd_dq_kernel<2>, dim3((a.Lq + 31) / 32, a.H, a.B), dim3(128), 0, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL(attn_bwd_dq_kernel<4>, dim3((a.Lq + 63) / 64, a.H, a.B), dim3(256), 0, (hipStream_t)stream, a);
+  const hipStream_t st = (hipStream_t)stream;
+  if (a.Lq <= 32) hipLaunchKernelGGL((attn_bwd_dq_kernel<2, 1, false>), dim3(1, a.H, a.B), dim3(128), 0, st, a);
+  else if (a.Lq <= 64 || a.Lk > 256) hipLaunchKernelGGL((attn_bwd_dq_kernel<4, 1, false>), dim3((a.Lq + 63) / 64, a.H, a.B), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((attn_bwd_dq_kernel<8, 1, true>), dim3((a.Lq + 127) / 128, a.H, a.B), dim3(512), 0, st, a);
   if (int e = x2_check_launch("x2_attn_bwd(dq)")) return e;
-  if (a.Lk <= 32) hipLaunchKernelGGL(attn_bwd_dkv_kernel<2>, dim3((a.Lk + 31) / 32, a.H, a.Bkv), dim3(128), 0, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL(attn_bwd_dkv_kernel<4>, dim3((a.Lk + 63) / 64, a.H, a.Bkv), dim3(256), 0, (hipStream_t)stream, a);
+  const bool res = !a.seq_off && a.Lq > 64 && a.Lq <= 256;   // one sequence per K/V batch, 2..4 query tiles: resident Q/dO
+  if (a.Lk <= 32) {
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<2, 1, false>), dim3(1, a.H, a.Bkv), dim3(128), 0, st, a);
+  } else if (res) {
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<4, 1, true>), dim3((a.Lk + 63) / 64, a.H, a.Bkv), dim3(256), 0, st, a);
+  } else {
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<4, 1, false>), dim3((a.Lk + 63) / 64, a.H, a.Bkv), dim3(256), 0, st, a);
+  }
   return x2_check_launch("x2_attn_bwd(dkv)");
 }
