@@ -80,6 +80,10 @@ def main():
     ap.add_argument("--seq-len", type=int, default=30)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eval-mode", action="store_true", help="model.eval(): dropout / DropPath off (not the headline number)")
+    ap.add_argument("--tiny", action="store_true", help="debug: 2-layer towers (NOT the benchmark configuration)")
+    ap.add_argument("--serialize", action="store_true",
+                    help="profiling aid: one HIP stream only (no concurrent text tower / weight-gradient stream), so that "
+                         "per-kernel durations are not inflated by co-running kernels")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -101,15 +105,32 @@ def main():
     acc = importlib.import_module("x2-vlm_amd.accelerator")
 
     torch.manual_seed(0)
+    if os.environ.get("X2_FAULT_DUMP"):
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["X2_FAULT_DUMP"]), exit=True)
     cfg = cfgs.pretrain_config(tempfile.mkdtemp(), "base", 224)
+    if args.tiny:
+        cfg.update(vision_num_hidden_layers=2, text_num_hidden_layers=3, text_fusion_start_at=2)
     model = mp.XVLM(config=cfg, load_vision_params=False, load_text_params=False, pretraining=True).to(dev)
     model.train(not args.eval_mode)
+    if args.serialize:
+        model.overlap_towers = False
+        importlib.import_module("x2-vlm_amd.engine").SIDE.enabled = False
     ddp = acc.GradientBuckets(model, world) if world > 1 else None
     batch = {k: v.to(dev) for k, v in synthetic_batch(rank, args.batch, args.seq_len, 224).items()}
 
     eng = importlib.import_module("x2-vlm_amd.engine")
 
+    # the critical path (vision tower, fusion stack, input-gradient chain) runs on a high-priority HIP stream; the text
+    # tower and the weight-gradient GEMMs are on default-priority streams and fill the CUs it leaves idle
+    # (measured: no gain on MI355X/ROCm 7.2, so off by default)
+    hi = torch.cuda.Stream(priority=-1) if os.environ.get("X2_BENCH_HIPRIO", "0") == "1" else torch.cuda.current_stream()
+
     def step():
+        with torch.cuda.stream(hi):
+            return _step()
+
+    def _step():
         eng.BANK.invalidate()        # as after an optimizer step: fp32 master weights are re-cast to bf16 inside the step
         model.zero_grad(set_to_none=True)
         loss = model(batch["image"], batch["text_ids"], batch["text_atts"], text_ids_masked=batch["text_ids_masked"],
@@ -128,6 +149,10 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
+    # dominant kernel = the bf16 MFMA NT GEMM (7.56 of the 11.74 PFLOP of a step): HIP events around every one of its
+    # launches during the timed steps, recorded on the stream each launch goes to (rank 0 only; ~1 us of host time each)
+    if rank == 0:
+        K.GEMM_TIMER = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
@@ -139,24 +164,45 @@ def main():
         dt = float(t)
     pairs_s = world * args.batch * args.steps / dt
 
-    # dominant kernel: every bf16 MFMA GEMM launch of one more step, HIP events on the launch stream
     roof = None
     if rank == 0:
-        K.GEMM_TIMER = []
-        step()
-        torch.cuda.synchronize()
-        ms = sum(a.elapsed_time(b) for a, b, _ in K.GEMM_TIMER)
-        fl = sum(f for _, _, f in K.GEMM_TIMER)
-        n_launch = len(K.GEMM_TIMER)
-        K.GEMM_TIMER = None
+        recs, K.GEMM_TIMER = K.GEMM_TIMER, None
+        stat = {}
+        for a, b, f, name in recs:
+            ms, fl, n = stat.get(name, (0.0, 0.0, 0))
+            stat[name] = (ms + a.elapsed_time(b), fl + f, n + 1)
+        ms, fl, n = stat["gemm_nt"]
         ach = fl / (ms * 1e-3) / 1e12
+        tn_ms, tn_fl, tn_n = stat.get("gemm_tn", (0.0, 0.0, 0))
         roof = {"bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(ach / PEAK_TFLOPS, 4), "traffic": None,
-                "kernel": "gemm_nt_kernel+gemm_tn_kernel", "launches_per_step": n_launch,
-                "avg_launch_us": round(1e3 * ms / n_launch, 1), "gemm_ms_per_step": round(ms, 2),
-                "gemm_gflop_per_step": round(fl / 1e9, 1),
-                "whole_step_tflops": round(pairs_s / world * F_MIN_GFLOP / 1e3, 1),
-                "whole_step_frac": round(pairs_s / world * F_MIN_GFLOP / 1e3 / PEAK_TFLOPS, 4)}
+                "kernel": "gemm_nt_kernel (forward linears + input gradients)", "launches_per_step": n // args.steps,
+                "avg_launch_us": round(1e3 * ms / n, 1), "gflop_per_launch": round(fl / n / 1e9, 2),
+                "nt_gemm_ms_per_step": round(ms / args.steps, 2),
+                "also": {"gemm_tn_kernel (weight gradients, side stream)": {
+                             "launches_per_step": tn_n // args.steps, "avg_launch_us": round(1e3 * tn_ms / max(tn_n, 1), 1),
+                             "achieved": round(tn_fl / max(tn_ms, 1e-9) / 1e9, 1)},
+                         "whole_step_tflops": round(pairs_s / world * F_MIN_GFLOP / 1e3, 1),
+                         "whole_step_frac": round(pairs_s / world * F_MIN_GFLOP / 1e3 / PEAK_TFLOPS, 4),
+                         "note": "launch durations are taken while the text tower and the weight-gradient GEMMs run "
+                                 "concurrently on other HIP streams (a launch also waits for CUs they hold); "
+                                 "'isolated' below = same kernel timed in one extra single-stream step, the figure a "
+                                 "rocprofv3 kernel trace of `bench.py --serialize` reproduces"}}
+        # one extra step on a single stream: per-kernel durations without co-running kernels
+        if not args.serialize:
+            model.overlap_towers = False
+            eng.SIDE.enabled = False
+            step(); torch.cuda.synchronize()
+            K.GEMM_TIMER = []
+            step(); torch.cuda.synchronize()
+            recs, K.GEMM_TIMER = K.GEMM_TIMER, None
+            ims = sum(a.elapsed_time(b) for a, b, f, nm in recs if nm == "gemm_nt")
+            ifl = sum(f for a, b, f, nm in recs if nm == "gemm_nt")
+            inn = sum(1 for r in recs if r[3] == "gemm_nt")
+            roof["also"]["isolated"] = {"avg_launch_us": round(1e3 * ims / inn, 1), "achieved": round(ifl / ims / 1e9, 1),
+                                        "frac": round(ifl / ims / 1e9 / PEAK_TFLOPS, 4)}
+            model.overlap_towers = True
+            eng.SIDE.enabled = True
     if world > 1:
         dist.barrier()
     if rank == 0:
@@ -167,7 +213,7 @@ def main():
                "config": {"workload": "X2VLM-base (BEiT2-base + BERT-base 12+6) pre-training step fwd+bwd, ITC+ITM+MLM, "
                                       "224px, %d-token captions, 12 masks" % args.seq_len,
                           "per_gpu_batch": args.batch, "global_batch": args.batch * world,
-                          "parallelism": "dp%d" % world, "mode": "eval (dropout/DropPath off)" if args.eval_mode else
+                          "parallelism": "dp%d" % world, "streams": "single (--serialize)" if args.serialize else "concurrent", "mode": "eval (dropout/DropPath off)" if args.eval_mode else
                           "train (BERT dropout 0.1, attention dropout 0.1, DropPath 0..0.1)",
                           "losses": {k: round(float(v), 4) for k, v in loss.items()}},
                "roofline": roof}

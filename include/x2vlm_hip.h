@@ -76,6 +76,7 @@ typedef struct X2AttnArgs {
   int ds_ld;
   unsigned drop_thr16, drop_seed; float drop_scale;   /* dropout on the probabilities (xbert.py:399);
                                                           element = ((b*H + h)*Lq + q) * round_up(Lk,64) + key */
+  int dbg;                                           /* 0; ablation switches for probes/bench_attn.py */
 } X2AttnArgs;
 int x2_attn_fwd(const X2AttnArgs* args, void* stream);
 int x2_attn_bwd(const X2AttnArgs* args, void* stream);   /* dQ (+dS, Delta) then dK/dV; no atomics */

@@ -1,0 +1,48 @@
+"""Attention micro-benchmark / ablation on the shapes of the X2VLM-base step (B=64)."""
+import importlib, sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+K = importlib.import_module("x2-vlm_amd.kernels")
+dev = "cuda"
+
+def timeit(fn, iters=20):
+    for _ in range(3): fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters): fn()
+    b.record(); torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters * 1e3
+
+def case(B, H, Lq, Lk, bias, mask):
+    d = 64
+    qkv = torch.randn(B * Lq, 3 * H * d, device=dev).bfloat16()
+    kv = qkv if Lq == Lk else torch.randn(B * Lk, 3 * H * d, device=dev).bfloat16()
+    out = torch.empty(B * Lq, H * d, device=dev, dtype=torch.bfloat16)
+    lse = torch.empty(B * H * Lq, device=dev); delta = torch.empty_like(lse)
+    dout = torch.randn_like(out); dqkv = torch.empty_like(qkv); dkv = dqkv if Lq == Lk else torch.empty_like(kv)
+    kw = {}
+    if bias:
+        kw["bias"] = torch.randn(H, Lq, K.round_up(Lk, 64), device=dev); kw["biasT"] = torch.randn(H, Lk, K.round_up(Lq, 64), device=dev)
+    if mask:
+        kw["mask"] = torch.zeros(B, K.round_up(Lk, 64), device=dev)
+    HD = H * d
+    q3, k3, v3 = K.view3(qkv, B, Lq, 0), K.view3(kv, B, Lk, HD), K.view3(kv, B, Lk, 2 * HD)
+    dS = torch.empty(B, H, Lq, K.round_up(Lk, 64), device=dev, dtype=torch.bfloat16) if bias else None
+    def fwd(dbg=0):
+        a = K._attn_args(q3, k3, v3, B, B, H, Lq, Lk, d ** -0.5, **{k_: v_ for k_, v_ in kw.items() if k_ != "biasT"})
+        a.Out, a.o_bs, a.o_rs = K.view3(out, B, Lq); a.LSE = lse.data_ptr(); a.dbg = dbg
+        K.call("x2_attn_fwd", K.C.byref(a))
+    def bwd():
+        K.attn_bwd(q3, k3, v3, K.view3(out, B, Lq), K.view3(dout, B, Lq), B, B, H, Lq, Lk, d ** -0.5, lse, delta,
+                   K.view3(dqkv, B, Lq, 0), K.view3(dkv, B, Lk, HD), K.view3(dkv, B, Lk, 2 * HD), dS=dS, **kw)
+    return fwd, bwd
+
+for name, B, H, Lq, Lk, bias, mask in [("vision", 64, 12, 197, 197, True, False), ("text self", 128, 12, 30, 30, False, True),
+                                       ("fusion self", 256, 12, 30, 30, False, True)]:
+    fwd, bwd = case(B, H, Lq, Lk, bias, mask)
+    fl = 4.0 * B * H * Lq * Lk * 64
+    t = timeit(fwd); tb = timeit(bwd)
+    print("%-12s fwd %6.1fus %5.0fTF   bwd(dq+dkv) %6.1fus %5.0fTF" % (name, t, fl / t / 1e6, tb, 2.5 * fl / tb / 1e6))
+    if name == "vision":
+        print("   fwd ablation: " + "  ".join("d%d %.1fus" % (g, timeit(lambda g=g: fwd(g))) for g in (0, 1, 2, 3, 4, 8, 12, 15)))

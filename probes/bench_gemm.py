@@ -54,6 +54,17 @@ def main():
             res.append(timeit(fn))
         fl = 2.0 * M * N * Kd
         print("  %-11s M=%5d N=%5d K=%4d %-5s " % (name, M, N, Kd, epi) + "  ".join("g%-2d %6.1fus %5.0fTF" % (g, t, fl / t / 1e6) for g, t in zip(knobs, res)))
+    lib.x2_tune(3, 0)
+    print("write-through (sc1) output stores: knob2 = 0 plain, 16 sc1 (interleaved rounds)")
+    for name, M, N, Kd, epi in NT:
+        fn = nt_case(M, N, Kd, epi)
+        res = {0: [], 16: []}
+        for rep in range(3):
+            for g in (0, 16):
+                lib.x2_tune(2, g)
+                res[g].append(timeit(fn, 10))
+        lib.x2_tune(2, 0)
+        print("  %-11s plain %6.1fus  sc1 %6.1fus" % (name, min(res[0]), min(res[16])))
     lib.x2_tune(3, 1)
     print("ablation on the 128x128 kernel (knob2: 0 full, 1 no loads in loop, 2 no MFMA, 4 no epilogue, 5 = 1+4, 6 = 2+4, 3 = 1+2)")
     for name, M, N, Kd, epi in NT[:5]:

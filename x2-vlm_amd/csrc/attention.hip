@@ -34,6 +34,7 @@ struct AttnArgs {
   int ds_ld;                           // dS: [B][H][Lq][ds_ld]
   DropSpec drop;                       // dropout on the attention probabilities (xbert.py:399), element index
                                        // ((b*H + h)*Lq + q) * round_up(Lk,64) + key
+  int dbg;                             // ablation (probes/bench_attn.py): 1 no bias/mask loads, 2 no exp2, 4 no PV MFMAs, 8 no QK MFMAs
 };
 
 // Staging of a [64 rows][64 d] bf16 tile (rows clamped to `nrows-1`) HBM -> registers -> LDS in two halves, so the
@@ -83,8 +84,8 @@ __device__ __forceinline__ float group_sum(float v) { v += __shfl_xor(v, 16, 64)
 // scores (log2 domain) of one S^T tile row-group for this lane: keys key0..key0+3, query q
 __device__ __forceinline__ f32x4 add_bias_mask(f32x4 s, const AttnArgs& a, int h, int b, int q, int key0, float sc2) {
   float4 bb{0.f, 0.f, 0.f, 0.f}, mm{0.f, 0.f, 0.f, 0.f};
-  if (a.bias) bb = *reinterpret_cast<const float4*>(a.bias + ((long)h * a.Lq + q) * a.bias_ld + key0);
-  if (a.mask) mm = *reinterpret_cast<const float4*>(a.mask + (long)b * a.mask_ld + key0);
+  if (a.bias && !(a.dbg & 1)) bb = *reinterpret_cast<const float4*>(a.bias + ((long)h * a.Lq + q) * a.bias_ld + key0);
+  if (a.mask && !(a.dbg & 1)) mm = *reinterpret_cast<const float4*>(a.mask + (long)b * a.mask_ld + key0);
   f32x4 o;
   o[0] = key0 + 0 < a.Lk ? s[0] * sc2 + (bb.x + mm.x) * LOG2E : NEG_BIG;
   o[1] = key0 + 1 < a.Lk ? s[1] * sc2 + (bb.y + mm.y) * LOG2E : NEG_BIG;
@@ -157,6 +158,7 @@ __global__ __launch_bounds__(64 * QW) void attn_fwd_kernel(AttnArgs a) {
     for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
+        if (a.dbg & 8) continue;
         const bf16x8 kfr = frag_rows(ktile, nt * 16 + fi, ks * 4 + g);
 #pragma unroll
         for (int gq = 0; gq < QG; ++gq) st[gq][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr, qf[gq][ks], st[gq][nt], 0, 0, 0);
@@ -177,7 +179,7 @@ __global__ __launch_bounds__(64 * QW) void attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { st[gq][nt][r] = exp2f(st[gq][nt][r] - m_new); rs += st[gq][nt][r]; }
+        for (int r = 0; r < 4; ++r) { st[gq][nt][r] = (a.dbg & 2) ? (st[gq][nt][r] - m_new) * 0.001f : exp2f(st[gq][nt][r] - m_new); rs += st[gq][nt][r]; }
       l_i[gq] = l_i[gq] * alpha + group_sum(rs);
       m_i[gq] = m_new;
       if (a.drop.thr16) {      // normalisation uses the undropped sum; only the P that multiplies V is dropped
@@ -198,6 +200,7 @@ __global__ __launch_bounds__(64 * QW) void attn_fwd_kernel(AttnArgs a) {
     for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
+        if (a.dbg & 4) continue;
         const bf16x8 vfr = frag_cols(vtile, s2, dt, lane);
 #pragma unroll
         for (int gq = 0; gq < QG; ++gq) o[gq][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfr, pf[gq][s2], o[gq][dt], 0, 0, 0);

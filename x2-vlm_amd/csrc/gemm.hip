@@ -33,6 +33,7 @@ struct GemmNT {
   const float* rowscale;    // [M] per-row factor before the residual add: DropPath keep/(1-p) per sample (beit2.py:206-207)
   float* colsum;            // [N] += column sums of the stored C (bias gradient of the layer below, fused)
   int dbg;                  // ablation switches for probes/bench_gemm.py: 1 = no operand loads in the K loop, 2 = no MFMA, 4 = no epilogue
+  int stagger;              // experiment: odd workgroups start `stagger` x 4 us late (de-phases the two workgroups of a CU)
 };
 
 // logical tile id -> (row tile, col tile): XCD-contiguous chunks, inside a chunk groups of `gm` row panels
@@ -51,6 +52,13 @@ __device__ __forceinline__ void tile_coords(int t, int tiles_m, int tiles_n, int
 // full-line stores of C and aux.  bias / GELU / GELU' / dropout / layer-scale / DropPath / residual are applied
 // on the way out; optional column sums (bias gradient of the layer below) leave as one atomic per column.
 // Caller guarantees (barrier) that no wave still reads operand tiles from `smem`.
+// 16-byte global store; wt = write-through + do not keep the line in this XCD's L2 (sc1): outputs are consumed by
+// a later kernel, keeping them resident only evicts the operand panels the other workgroups of the XCD re-read.
+__device__ __forceinline__ void st16(void* p, u32x4 v, bool wt) {
+  if (wt) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+  else *reinterpret_cast<u32x4*>(p) = v;
+}
+
 template <int TM>
 __device__ __forceinline__ void nt_epilogue(const GemmNT& p, f32x4 (&acc)[TM][4], char* smem, int wave, int lane, int mw0, int nw0) {
   const int frow = lane & 15, fg = lane >> 4;
@@ -68,6 +76,7 @@ __device__ __forceinline__ void nt_epilogue(const GemmNT& p, f32x4 (&acc)[TM][4]
   if (nok && p.gamma) { const float4 g0 = *reinterpret_cast<const float4*>(p.gamma + n), g1 = *reinterpret_cast<const float4*>(p.gamma + n + 4);
     gg[0] = g0.x; gg[1] = g0.y; gg[2] = g0.z; gg[3] = g0.w; gg[4] = g1.x; gg[5] = g1.y; gg[6] = g1.z; gg[7] = g1.w; }
   float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const bool wt = (p.dbg & 16) != 0;
 #pragma unroll
   for (int half = 0; half < TM / 2; ++half) {
 #pragma unroll
@@ -84,8 +93,7 @@ __device__ __forceinline__ void nt_epilogue(const GemmNT& p, f32x4 (&acc)[TM][4]
       if (m >= p.M || !nok) continue;
       float v[8] = {a0.x + bb[0], a0.y + bb[1], a0.z + bb[2], a0.w + bb[3], a1.x + bb[4], a1.y + bb[5], a1.z + bb[6], a1.w + bb[7]};
       if (p.act == 1) {
-        *reinterpret_cast<u32x4*>(p.aux + (size_t)m * p.ldaux + n) =
-            u32x4{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7])};
+        st16(p.aux + (size_t)m * p.ldaux + n, u32x4{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7])}, wt);
 #pragma unroll
         for (int r = 0; r < 8; ++r) v[r] = gelu_f(v[r]);
       } else if (p.act == 2) {
@@ -93,8 +101,7 @@ __device__ __forceinline__ void nt_epilogue(const GemmNT& p, f32x4 (&acc)[TM][4]
 #pragma unroll
         for (int r = 0; r < 4; ++r) { v[2 * r] *= dgelu_f(bf_lo(pre[r])); v[2 * r + 1] *= dgelu_f(bf_hi(pre[r])); }
       } else if (p.aux) {
-        *reinterpret_cast<u32x4*>(p.aux + (size_t)m * p.ldaux + n) =
-            u32x4{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7])};
+        st16(p.aux + (size_t)m * p.ldaux + n, u32x4{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7])}, wt);
       }
       if (p.drop.thr16) {
         float dm[4];
@@ -114,11 +121,11 @@ __device__ __forceinline__ void nt_epilogue(const GemmNT& p, f32x4 (&acc)[TM][4]
       for (int r = 0; r < 8; ++r) cs[r] += v[r];
       if (p.out_f32) {
         float* c = reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n;
-        *reinterpret_cast<float4*>(c) = float4{v[0], v[1], v[2], v[3]};
-        *reinterpret_cast<float4*>(c + 4) = float4{v[4], v[5], v[6], v[7]};
+        st16(c, u32x4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])}, wt);
+        st16(c + 4, u32x4{__float_as_uint(v[4]), __float_as_uint(v[5]), __float_as_uint(v[6]), __float_as_uint(v[7])}, wt);
       } else {
-        *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.C) + (size_t)m * p.ldc + n) =
-            u32x4{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7])};
+        st16(reinterpret_cast<bf16_t*>(p.C) + (size_t)m * p.ldc + n,
+             u32x4{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7])}, wt);
       }
     }
   }
@@ -183,6 +190,11 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNT p) {
   const uint32_t offB = (uint32_t)(A_BYTES + (wn * 64 + frow) * 128);
 
   const int nk = p.K / BK;
+  // The two workgroups of a CU are dispatched together and take equally long, so they stay in phase for the whole
+  // kernel: both in the L2-bound main loop, then both in the HBM-write-bound epilogue.  Delaying the second-slot
+  // workgroups of the FIRST round once (workgroups 256..511) de-phases every later round.
+  if (p.stagger && blockIdx.x >= 256 && blockIdx.x < 512)
+    for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(127);
   stage(0, 0);
   for (int kt = 0; kt < nk; ++kt) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -313,7 +325,7 @@ extern "C" int x2_gemm_nt(const void* A, const void* B, void* C, int M, int N, i
   X2_REQUIRE(act == 0 || aux, "x2_gemm_nt: act=%d needs aux", act);
   X2_REQUIRE((!resid || ldr % 4 == 0) && (!aux || ldaux % 8 == 0), "x2_gemm_nt: ldr/ldaux alignment");
   GemmNT p{(const bf16_t*)A, (const bf16_t*)B, C, bias, gamma, resid, (bf16_t*)aux, M, N, K, lda, ldb, ldc, ldr, ldaux, act, out_f32,
-           g_tune[0] > 0 ? g_tune[0] : 8, DropSpec{drop_thr16, drop_seed, drop_scale}, rowscale, colsum, g_tune[2]};
+           g_tune[0] > 0 ? g_tune[0] : 8, DropSpec{drop_thr16, drop_seed, drop_scale}, rowscale, colsum, g_tune[2], g_tune[4]};
   // tile choice: [1] = 0 auto, 1 force 128x128 (4 waves), 2 force 256x128 (8 waves, 3-deep ring)
   const int tiles8 = ((M + 255) / 256) * ((N + 127) / 128);
   // measured (probes/bench_gemm.py): two independent 4-wave workgroups per CU beat one 8-wave workgroup with a

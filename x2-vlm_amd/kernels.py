@@ -17,8 +17,9 @@ GEMM_TIMER = None   # bench.py: list collecting (start_event, end_event, flops) 
 class _timed:
     """HIP events around one launch on the current stream (only while bench.py's GEMM_TIMER is set)."""
 
-    def __init__(self, flops):
+    def __init__(self, flops, name="gemm_nt"):
         self.flops = flops
+        self.name = name
 
     def __enter__(self):
         if GEMM_TIMER is not None:
@@ -29,7 +30,7 @@ class _timed:
     def __exit__(self, *exc):
         if GEMM_TIMER is not None:
             self.b.record()
-            GEMM_TIMER.append((self.a, self.b, self.flops))
+            GEMM_TIMER.append((self.a, self.b, self.flops, self.name))
 
 
 NO_DROP = (0, 0, 1.0)
@@ -127,7 +128,7 @@ def gemm_tn_grouped(problems, accumulate=False, split=1):
     for i in range(0, len(rows), 8):
         chunk = rows[i:i + 8]
         arr = (C.c_int64 * (11 * len(chunk)))(*[v for r in chunk for v in r])
-        with _timed(sum(2.0 * r[3] * r[4] * r[5] for r in chunk)):
+        with _timed(sum(2.0 * r[3] * r[4] * r[5] for r in chunk), "gemm_tn"):
             call("x2_gemm_tn_grouped", arr, len(chunk), 1 if accumulate else 0, split)
 
 
