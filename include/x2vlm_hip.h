@@ -93,13 +93,16 @@ int x2_layernorm_fwd(const float* x, const float* w, const float* b, void* y_bf1
 int x2_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* w,
                      const float* dres, float* dx, void* dx_bf16, float* dw, float* db, float* dcol, int rows, int D,
                      int period, unsigned in_thr16, unsigned in_seed, float in_scale, unsigned out_thr16,
-                     unsigned out_seed, float out_scale, float* ws /* [ceil(rows/16)][3][D] */, void* stream);
+                     unsigned out_seed, float out_scale, float* ws /* [ceil(rows/16)][3][D] */, int defer, void* stream);
 /* Column reductions are two-stage (per-workgroup partial rows in the caller's workspace `ws`, then a deterministic
  * add): fp32 atomics measured ~43 G adds/s on MI355X, slower than the HBM traffic of these kernels. */
-int x2_colsum_bf16(const void* y, float* out, int M, int N, int ld, float* ws /* [ceil(M/64)][N] */, void* stream);
+int x2_colsum_bf16(const void* y, float* out, int M, int N, int ld, float* ws /* [ceil(M/64)][N] */, int defer, void* stream);
+/* defer != 0: only stage 1 (partials into ws); the caller finishes with x2_reduce_partials, possibly on another stream:
+ * out_k[c] += sum_blk ws[blk][k][c], k < nk <= 3 */
+int x2_reduce_partials(const float* part, int nblk, int nk, int width, float* o0, float* o1, float* o2, void* stream);
 /* backward of x + gamma * u (beit2.py:206-207): du = gamma*dx (bf16), dgamma += sum dx*u, dbias += sum du */
 int x2_layerscale_bwd(const float* dx, const void* u, const float* gamma, void* du, float* dgamma, float* dbias,
-                      const float* rowscale, int M, int D, float* ws /* [ceil(M/32)][2][D] */, void* stream);
+                      const float* rowscale, int M, int D, float* ws /* [ceil(M/32)][2][D] */, int defer, void* stream);
 int x2_cast_bf16(const float* src, void* dst, long n, void* stream);
 int x2_cast_transpose_bf16(const float* src, void* dst, void* dstT, int R, int C, int ldt, void* stream);
 /* PatchEmbed input rows (beit2.py:225-232): image (B,3,R,R) -> bf16 [B*(R/ps)^2][3*ps*ps] */

@@ -95,6 +95,13 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
 static void launch_reduce(const float* part, int nblk, int nk, int width, float* o0, float* o1, float* o2, hipStream_t st) {
   hipLaunchKernelGGL(reduce_partials_kernel, dim3((width + 63) / 64, nk), dim3(256), 0, st, part, nblk, nk, width, o0, o1, o2);
 }
+// Stage 2 on its own: the parameter-gradient sums are not on the critical path of the backward, so the host may
+// run this on another stream (stage 1 launched with defer = 1 and a private workspace).
+extern "C" int x2_reduce_partials(const float* part, int nblk, int nk, int width, float* o0, float* o1, float* o2, void* stream) {
+  X2_REQUIRE(part && nblk > 0 && nk >= 1 && nk <= 3 && width > 0, "x2_reduce_partials: nblk=%d nk=%d width=%d", nblk, nk, width);
+  launch_reduce(part, nblk, nk, width, o0, o1, o2, (hipStream_t)stream);
+  return x2_check_launch("x2_reduce_partials");
+}
 
 // ---------------------------------------------------------------------------------- LayerNorm bwd
 // dx = dres + rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * w ; dw += sum dy*xhat ; db += sum dy ;
@@ -203,7 +210,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
 extern "C" int x2_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* w,
                                 const float* dres, float* dx, void* dx_bf16, float* dw, float* db, float* dcol, int rows, int D,
                                 int period, unsigned in_thr16, unsigned in_seed, float in_scale, unsigned out_thr16,
-                                unsigned out_seed, float out_scale, float* ws, void* stream) {
+                                unsigned out_seed, float out_scale, float* ws, int defer, void* stream) {
   X2_REQUIRE(rows > 0 && D > 0 && D % 4 == 0 && D <= 256 * LN_MAXV, "x2_layernorm_bwd: rows=%d D=%d", rows, D);
   X2_REQUIRE(dw && db && ws, "x2_layernorm_bwd: dw/db and the workspace ws[ceil(rows/%d)*3*D] are required", LNB_ROWS);
   X2_REQUIRE(!(dcol && dres), "x2_layernorm_bwd: dcol sums the LN-input gradient, which excludes dres");
@@ -212,7 +219,7 @@ extern "C" int x2_layernorm_bwd(const float* dy, const float* x, const float* me
                      (hipStream_t)stream, dy, x, mean, rstd, w, dres, dx, (bf16_t*)dx_bf16, ws, rows, D, period,                \
                      DropSpec{in_thr16, in_seed, in_scale}, DropSpec{out_thr16, out_seed, out_scale})
   LN_DISPATCH(D, X2_LNB);
-  launch_reduce(ws, (rows + LNB_ROWS - 1) / LNB_ROWS, 3, D, dw, db, dcol, (hipStream_t)stream);
+  if (!defer) launch_reduce(ws, (rows + LNB_ROWS - 1) / LNB_ROWS, 3, D, dw, db, dcol, (hipStream_t)stream);
   return x2_check_launch("x2_layernorm_bwd");
 }
 
@@ -247,12 +254,12 @@ __global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16_t* __restri
     }
   }
 }
-extern "C" int x2_colsum_bf16(const void* y, float* out, int M, int N, int ld, float* ws, void* stream) {
+extern "C" int x2_colsum_bf16(const void* y, float* out, int M, int N, int ld, float* ws, int defer, void* stream) {
   X2_REQUIRE(M > 0 && N > 0 && N % 8 == 0 && ld % 8 == 0, "x2_colsum_bf16: M=%d N=%d ld=%d (N, ld multiples of 8)", M, N, ld);
   X2_REQUIRE(ws, "x2_colsum_bf16: workspace ws[ceil(M/%d)*N] required", CS_ROWS);
   hipLaunchKernelGGL(colsum_bf16_kernel, dim3((M + CS_ROWS - 1) / CS_ROWS, (N + 511) / 512), dim3(256), 0, (hipStream_t)stream,
                      (const bf16_t*)y, ws, M, N, ld);
-  launch_reduce(ws, (M + CS_ROWS - 1) / CS_ROWS, 1, N, out, nullptr, nullptr, (hipStream_t)stream);
+  if (!defer) launch_reduce(ws, (M + CS_ROWS - 1) / CS_ROWS, 1, N, out, nullptr, nullptr, (hipStream_t)stream);
   return x2_check_launch("x2_colsum_bf16");
 }
 
@@ -295,11 +302,11 @@ __global__ __launch_bounds__(256) void layerscale_bwd_kernel(const float* __rest
   }
 }
 extern "C" int x2_layerscale_bwd(const float* dx, const void* u, const float* gamma, void* du, float* dgamma, float* dbias,
-                                 const float* rowscale, int M, int D, float* ws, void* stream) {
+                                 const float* rowscale, int M, int D, float* ws, int defer, void* stream) {
   X2_REQUIRE(M > 0 && D > 0 && D % 4 == 0 && ws, "x2_layerscale_bwd: M=%d D=%d (workspace ws[ceil(M/%d)*2*D] required)", M, D, LS_ROWS);
   hipLaunchKernelGGL(layerscale_bwd_kernel, dim3((M + LS_ROWS - 1) / LS_ROWS, (D + 255) / 256), dim3(256), 0, (hipStream_t)stream, dx,
                      (const bf16_t*)u, gamma, (bf16_t*)du, ws, rowscale, M, D);
-  launch_reduce(ws, (M + LS_ROWS - 1) / LS_ROWS, 2, D, dgamma, dbias, nullptr, (hipStream_t)stream);
+  if (!defer) launch_reduce(ws, (M + LS_ROWS - 1) / LS_ROWS, 2, D, dgamma, dbias, nullptr, (hipStream_t)stream);
   return x2_check_launch("x2_layerscale_bwd");
 }
 

@@ -148,6 +148,23 @@ class SideStream:
 
 SIDE = SideStream()
 
+
+def _begin_layer_backward():
+    """Collect the layer's stage-2 parameter-gradient reductions instead of launching them in line."""
+    K.DEFERRED = [] if (SIDE.enabled and torch.cuda.is_available()) else None
+
+
+def _finish_layer_backward(G, tn):
+    """Side stream: the deferred reductions, then the layer's weight-gradient GEMMs; publish the arena."""
+    deferred, K.DEFERRED = K.DEFERRED, None
+
+    def work():
+        for ws, nblk, nk, width, outs in deferred or ():
+            K.reduce_partials(ws, nblk, nk, width, outs)
+        K.gemm_tn_grouped(tn)
+    keep = [t for pr in tn for t in pr[:2]] + [G.flat] + [d[0] for d in (deferred or ())]
+    G.publish(SIDE.launch(work, keep))
+
 GRAD_READY_HOOK = None      # set by accelerator.GradientBuckets: f(flat_fp32_arena, key)
 STAGE_CALLS = {}            # key -> number of forward calls since the last reset (see GradientBuckets)
 
@@ -270,6 +287,7 @@ class VisionEncoderFn(torch.autograd.Function):
                             ("mlp.fc1.bias", (F4,), True), ("mlp.fc2.bias", (D,), True),
                             ("attn.qkv.weight", (3 * D, D), False), ("attn.proj.weight", (D, D), False),
                             ("mlp.fc1.weight", (F4, D), False), ("mlp.fc2.weight", (D, F4), False)], key=("vit", id(p[b + "gamma_1"])))
+            _begin_layer_backward()
             _, w2T = BANK.linear(p[b + "mlp.fc2.weight"])
             _, w1T = BANK.linear(p[b + "mlp.fc1.weight"])
             _, wprojT = BANK.linear(p[b + "attn.proj.weight"])
@@ -293,7 +311,7 @@ class VisionEncoderFn(torch.autograd.Function):
             dxn, _ = K.layernorm_bwd(dh1, x, mean1, rstd1, p[b + "norm1.weight"], G["norm1.weight"], G["norm1.bias"], dres=dx1)
             tn = [(dy2, act, G["mlp.fc2.weight"]), (dpre, h2, G["mlp.fc1.weight"]),
                   (dy1, att, G["attn.proj.weight"]), (dqkv, h1, G["attn.qkv.weight"])]
-            G.publish(SIDE.launch(lambda tn=tn: K.gemm_tn_grouped(tn), [t for pr in tn for t in pr[:2]] + [G.flat]))
+            _finish_layer_backward(G, tn)
             for n in names:
                 if n.startswith(b):
                     out[n] = G.g[n[len(b):]]
@@ -440,6 +458,7 @@ class BertLayersFn(torch.autograd.Function):
                          ("c.kv_weight", (2 * Hd, Dv), False), ("crossattention.output.dense.weight", (Hd, Hd), False)]
             G = Grads(dev, spec, key=("bert", id(p[a + "self.query.weight"])))
             tn = []
+            _begin_layer_backward()
             ds3, ds3b = K.layernorm_bwd(dh, s3, m3, r3, p[b + "output.LayerNorm.weight"], G["output.LayerNorm.weight"],
                                         G["output.LayerNorm.bias"], dcol=G["output.dense.bias"], want_bf16=True,
                                         drop_out=BertLayersFn._drop(meta, i, 4))
@@ -495,7 +514,7 @@ class BertLayersFn(torch.autograd.Function):
             _, wqkvT = BANK.linear(p[a + "self.query.weight"], p[a + "self.key.weight"], p[a + "self.value.weight"])
             dh = K.gemm_nt(dqkv, wqkvT, resid=ds1, out_dtype=F32)
             tn += [(ds1b, att, G["attention.output.dense.weight"]), (dqkv, hb, G["a.qkv_weight"])]
-            G.publish(SIDE.launch(lambda tn=tn: K.gemm_tn_grouped(tn), [t for pr in tn for t in pr[:2]] + [G.flat]))
+            _finish_layer_backward(G, tn)
             for n in names:
                 if n.startswith(b):
                     out[n] = G.g[n[len(b):]]

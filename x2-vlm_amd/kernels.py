@@ -79,6 +79,23 @@ def workspace(device, nfloats):
     return buf
 
 
+DEFERRED = None     # engine sets this to a list while a layer's backward runs: stage-2 reductions of the parameter
+                    # gradients are collected here and launched later on the weight-gradient side stream
+
+
+def _ws_and_defer(device, nfloats):
+    """(workspace, defer flag): a private buffer when the reduction is deferred (the shared per-stream workspace
+    would be overwritten by the next kernel before the side stream reads it)."""
+    if DEFERRED is not None:
+        return torch.empty(nfloats, device=device, dtype=F32), 1
+    return workspace(device, nfloats), 0
+
+
+def reduce_partials(ws, nblk, nk, width, outs):
+    o = list(outs) + [None] * (3 - len(outs))
+    call("x2_reduce_partials", ptr(ws), nblk, nk, width, ptr(o[0]), ptr(o[1]), ptr(o[2]))
+
+
 def _rows(t):
     assert t.dim() == 2 and t.stride(1) == 1, "expected a row-major 2-D tensor (got strides %s)" % (t.stride(),)
     return t.stride(0)
@@ -218,21 +235,31 @@ def layernorm_bwd(dy, x, mean, rstd, w, dw, db, *, dres=None, dcol=None, period=
     if want_f32 and dx is None:
         dx = torch.empty_like(x) if period == 0 else torch.zeros_like(x)
     dxb = torch.empty(x.shape, device=x.device, dtype=BF16) if want_bf16 else None
+    nblk = (R + 15) // 16
+    ws, defer = _ws_and_defer(x.device, nblk * 3 * D)
     call("x2_layernorm_bwd", ptr(dy), ptr(x), ptr(mean), ptr(rstd), ptr(w), ptr(dres), ptr(dx), ptr(dxb), ptr(dw), ptr(db),
-         ptr(dcol), R, D, period, drop_in[0], drop_in[1], drop_in[2], drop_out[0], drop_out[1], drop_out[2],
-         ptr(workspace(x.device, ((R + 15) // 16) * 3 * D)))
+         ptr(dcol), R, D, period, drop_in[0], drop_in[1], drop_in[2], drop_out[0], drop_out[1], drop_out[2], ptr(ws), defer)
+    if defer:
+        DEFERRED.append((ws, nblk, 3, D, (dw, db, dcol)))
     return dx, dxb
 
 
 def colsum_bf16(y, out):
-    call("x2_colsum_bf16", ptr(y), ptr(out), y.shape[0], y.shape[1], _rows(y),
-         ptr(workspace(y.device, ((y.shape[0] + 63) // 64) * y.shape[1])))
+    nblk = (y.shape[0] + 63) // 64
+    ws, defer = _ws_and_defer(y.device, nblk * y.shape[1])
+    call("x2_colsum_bf16", ptr(y), ptr(out), y.shape[0], y.shape[1], _rows(y), ptr(ws), defer)
+    if defer:
+        DEFERRED.append((ws, nblk, 1, y.shape[1], (out,)))
 
 
 def layerscale_bwd(dx, u, gamma, dgamma, dbias, rowscale=None):
     du = torch.empty_like(u)
+    nblk = (u.shape[0] + 31) // 32
+    ws, defer = _ws_and_defer(u.device, nblk * 2 * u.shape[1])
     call("x2_layerscale_bwd", ptr(dx), ptr(u), ptr(gamma), ptr(du), ptr(dgamma), ptr(dbias), ptr(rowscale), u.shape[0], u.shape[1],
-         ptr(workspace(u.device, ((u.shape[0] + 31) // 32) * 2 * u.shape[1])))
+         ptr(ws), defer)
+    if defer:
+        DEFERRED.append((ws, nblk, 2, u.shape[1], (dgamma, dbias)))
     return du
 
 
