@@ -81,6 +81,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eval-mode", action="store_true", help="model.eval(): dropout / DropPath off (not the headline number)")
     ap.add_argument("--tiny", action="store_true", help="debug: 2-layer towers (NOT the benchmark configuration)")
+    ap.add_argument("--with-optimizer", action="store_true",
+                    help="also run clip + fused AdamW inside every step (the headline metric is fwd+bwd only)")
     ap.add_argument("--serialize", action="store_true",
                     help="profiling aid: one HIP stream only (no concurrent text tower / weight-gradient stream), so that "
                          "per-kernel durations are not inflated by co-running kernels")
@@ -130,8 +132,14 @@ def main():
         with torch.cuda.stream(hi):
             return _step()
 
+    opt = None
+    if args.with_optimizer:
+        opt = importlib.import_module("x2-vlm_amd.optim").create_optimizer(dict(lr=1e-4, weight_decay=0.01, lr_mult=2), model)
+
     def _step():
         eng.BANK.invalidate()        # as after an optimizer step: fp32 master weights are re-cast to bf16 inside the step
+        with torch.no_grad():
+            model.temp.clamp_(0.001, 0.5)                # Pretrain.py:327-328
         model.zero_grad(set_to_none=True)
         loss = model(batch["image"], batch["text_ids"], batch["text_atts"], text_ids_masked=batch["text_ids_masked"],
                      masked_pos=batch["masked_pos"], masked_ids=batch["masked_ids"])
@@ -139,6 +147,9 @@ def main():
         total.backward()
         if ddp is not None:
             ddp.finish()
+        if opt is not None:
+            opt.grad_norm(max_norm=1.0)                   # CLIP_GRAD_NORM 1.0, no host sync
+            opt.step()
         return loss
 
     def fence():
@@ -213,7 +224,8 @@ def main():
                "config": {"workload": "X2VLM-base (BEiT2-base + BERT-base 12+6) pre-training step fwd+bwd, ITC+ITM+MLM, "
                                       "224px, %d-token captions, 12 masks" % args.seq_len,
                           "per_gpu_batch": args.batch, "global_batch": args.batch * world,
-                          "parallelism": "dp%d" % world, "streams": "single (--serialize)" if args.serialize else "concurrent", "mode": "eval (dropout/DropPath off)" if args.eval_mode else
+                          "parallelism": "dp%d" % world, "streams": "single (--serialize)" if args.serialize else "concurrent",
+                          "optimizer_in_step": bool(args.with_optimizer), "mode": "eval (dropout/DropPath off)" if args.eval_mode else
                           "train (BERT dropout 0.1, attention dropout 0.1, DropPath 0..0.1)",
                           "losses": {k: round(float(v), 4) for k, v in loss.items()}},
                "roofline": roof}

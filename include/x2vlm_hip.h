@@ -143,6 +143,15 @@ int x2_sample_negatives(const float* sim, int n, const long* group, const float*
 int x2_gelu_f32(const float* x, const float* dy, float* out, long n, void* stream);               /* nn.GELU, xvlm.py:167 */
 int x2_colsum_f32(const float* x, float* out, int M, int N, void* stream);
 
+/* ---- optimizer (csrc/optim.hip) -- "next" row of the scope table ------------------------------------------
+ * optim.py:26-104 (transformers==4.12.5 AdamW, eps 1e-8, betas (0.9,0.98), correct_bias) and the global-norm clip of
+ * accelerators/apex_ddp_accelerator.py:99-102, as two multi-tensor launches.  table: ntensors records
+ * {float* p; const float* g (NULL = no gradient); float* m; float* v; long n; int group; int blk0} in device memory,
+ * blk0 = prefix sum of ceil(n / 16384); nblocks = total.  out2 = {total norm, min(1, max_norm / (norm + 1e-6))}. */
+int x2_grad_norm(const void* table, int ntensors, int nblocks, float max_norm, float* partial, float* out2, void* stream);
+int x2_adamw_multi(const void* table, int ntensors, int nblocks, const float* lr, const float* wd, int ngroups, float b1,
+                   float b2, float eps, int step, const float* clip2 /* out2 of x2_grad_norm or NULL */, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

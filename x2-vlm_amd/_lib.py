@@ -55,6 +55,8 @@ _SIGS = {
     "x2_ce_bwd": [P, L, P, P, P, P, F, I, I, P, P, L, P],
     "x2_sample_negatives": [P, I, P, P, P, P],
     "x2_gelu_f32": [P, P, P, L, P],
+    "x2_grad_norm": [P, I, I, F, P, P, P],
+    "x2_adamw_multi": [P, I, I, P, P, I, F, F, F, I, P, P],
     "x2_colsum_f32": [P, P, I, I, P],
 }
 EXPORTS = sorted(list(_SIGS) + ["x2_last_error", "x2_abi_version", "x2_device_cus", "x2_tune"])

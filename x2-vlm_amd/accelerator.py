@@ -157,6 +157,11 @@ class RocmDDPAccelerator(Accelerator):
             self.buckets.finish()
 
     def optimizer_step(self, optimizer, model, grad_norm):
+        """Clip to `grad_norm`, return the total norm as a float (one host sync, like the reference's float(...)).
+        With optim.FusedAdamW the norm is one multi-tensor launch and the clip coefficient is applied inside
+        optimizer.step() instead of rewriting 1 GB of gradients."""
+        if hasattr(optimizer, "grad_norm"):
+            return float(optimizer.grad_norm(max_norm=grad_norm)[0])
         params = [p for g in optimizer.param_groups for p in g["params"]] if optimizer is not None else list(model.parameters())
         return float(torch.nn.utils.clip_grad_norm_(params, grad_norm))
 
