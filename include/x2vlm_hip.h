@@ -100,11 +100,18 @@ int x2_colsum_bf16(const void* y, float* out, int M, int N, int ld, float* ws /*
 /* defer != 0: only stage 1 (partials into ws); the caller finishes with x2_reduce_partials, possibly on another stream:
  * out_k[c] += sum_blk ws[blk][k][c], k < nk <= 3 */
 int x2_reduce_partials(const float* part, int nblk, int nk, int width, float* o0, float* o1, float* o2, void* stream);
+/* `count` such reductions in one launch (all parameter-gradient sums of one layer's backward);
+ * desc: count rows of 7 int64 {part, nblk, nk, width, o0, o1, o2} */
+int x2_reduce_partials_multi(const int64_t* desc, int count, void* stream);
 /* backward of x + gamma * u (beit2.py:206-207): du = gamma*dx (bf16), dgamma += sum dx*u, dbias += sum du */
 int x2_layerscale_bwd(const float* dx, const void* u, const float* gamma, void* du, float* dgamma, float* dbias,
                       const float* rowscale, int M, int D, float* ws /* [ceil(M/32)][2][D] */, int defer, void* stream);
 int x2_cast_bf16(const float* src, void* dst, long n, void* stream);
 int x2_cast_transpose_bf16(const float* src, void* dst, void* dstT, int R, int C, int ldt, void* stream);
+/* bf16 (W, W^T) copies of many fp32 weights in one launch (what apex O1's per-call weight casts amount to, done once per
+ * optimizer step): desc = count rows of 7 int64 {src, dst, dstT, R, C, ldt, roff}: src [R][C] fp32 -> rows roff.. of
+ * dst [*][C] and columns roff.. of dstT [C][ldt]; R, C, ldt, roff multiples of 4 */
+int x2_cast_transpose_multi(const int64_t* desc, int count, void* stream);
 /* PatchEmbed input rows (beit2.py:225-232): image (B,3,R,R) -> bf16 [B*(R/ps)^2][3*ps*ps] */
 int x2_patchify(const float* image, void* cols, int B, int R, int ps, void* stream);
 /* torch.cat((cls_tokens, x), 1) (beit2.py:385-387) and its backward */
@@ -115,7 +122,10 @@ int x2_pool_tokens(float* x, const float* w, int B, int P, int D, int bwd, void*
 /* relative_position_bias_table[relative_position_index] -> [H][N][ld] (+ transposed), beit2.py:138-144 */
 int x2_relpos_bias(const float* table, const long* index, float* bias, float* biasT, int N, int H, int ld, int ldT,
                    void* stream);
-int x2_relpos_bias_bwd(const void* dS, const long* index, float* dtable, int B, int N, int H, int ld, void* stream);
+/* dtable[index[i][j]][h] += sum_b dS[b][h][i][j] (dS bf16 [B][H][N][ld]); the index arrives as its CSR inverse
+ * (inv_off [T+1], inv_pos = i*ld + j); ws: slices*H*N*ld floats (batch-slice sums, then a gather: no atomics) */
+int x2_relpos_bias_bwd(const void* dS, const int* inv_off, const int* inv_pos, float* dtable, int B, int N, int H, int ld,
+                       int T, float* ws, int slices, void* stream);
 
 /* ---- embeddings, heads, losses (csrc/heads.hip) -----------------------------------------------------
  * BertEmbeddings xbert.py:205-213 (word + position + token-type 0); backward scatter-adds. */
@@ -129,7 +139,8 @@ int x2_scatter_add_rows(const float* src, const int* idx, float* dst, int R, lon
 /* small fp32 linear with arbitrary strides: vision_proj / text_proj (xvlm.py:785-792), similarity matrices
  * (xvlm.py:807, 831-832), last layers of itm_head / bbox_head (xvlm.py:163-169) and their backward */
 int x2_linear_f32(const float* A, const float* B, float* C, const float* bias, const float* alpha_ptr, float alpha,
-                  int M, int N, int K, long sam, long sak, long sbn, long sbk, long ldc, int accumulate, void* stream);
+                  int M, int N, int K, long sam, long sak, long sbn, long sbk, long ldc, int accumulate,
+                  int ksplit /* K slices adding atomically onto a defined C (needs accumulate) */, void* stream);
 int x2_l2norm(const float* x, const float* dy, float* out, int R, int D, int bwd, void* stream);   /* F.normalize */
 /* F.cross_entropy / CrossEntropyLoss(ignore_index=-100): xvlm.py:812-813, 899; xbert.py:1660-1661.
  * out2 = {mean loss, number of counted rows}; backward writes (softmax - onehot) * gscale * g / count. */

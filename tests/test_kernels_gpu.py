@@ -245,6 +245,42 @@ def test_colsum_layerscale_casts(K):
     assert torch.equal(plain.cpu(), bf(w)) and torch.equal(tr[:, :300].cpu(), bf(w).t()) and float(tr[:, 300:].abs().max()) == 0
 
 
+def test_multi_tensor_cast_and_reduce(K):
+    """One-launch variants: stacked (W, W^T) copies of many weights == per-weight casts; batched stage-2 reductions."""
+    eng = importlib.import_module("x2-vlm_amd.engine")
+    bank = eng.WeightBank()
+    ws = [torch.nn.Parameter(rnd(r, c, seed=10 + i).to(dev)) for i, (r, c) in enumerate(
+        [(768, 768), (768, 768), (768, 768), (3072, 768), (768, 3072), (256, 768), (64, 132)] + [(128, 64)] * 60)]
+    groups = [(ws[0], ws[1], ws[2])] + [(w,) for w in ws[3:]]
+    bank.prepare(groups)
+    for g in groups:
+        plain, tr = bank.linear(*g)                      # cache hit: built by prepare()
+        ref = bf(torch.cat([w.detach().cpu() for w in g], 0))
+        assert torch.equal(plain.cpu(), ref) and torch.equal(tr.cpu(), ref.t())
+    assert len(bank._c) == len(groups)
+    items, refs = [], []
+    for i, (nblk, nk, width) in enumerate([(37, 3, 768), (5, 1, 100), (200, 2, 3072)] * 7):
+        part = rnd(nblk, nk, width, seed=100 + i).to(dev)
+        outs = tuple(torch.full((width,), float(k), device=dev) for k in range(nk))
+        items.append((part, nblk, nk, width, outs))
+        refs.append([part[:, k].double().sum(0).cpu() + k for k in range(nk)])
+    K.reduce_partials_multi(items)
+    for (part, nblk, nk, width, outs), ref in zip(items, refs):
+        for o, r in zip(outs, ref):
+            assert relerr(o, r) < 1e-5
+
+
+def test_linear_f32_split_k(K):
+    """Head-sized outputs take the K-sliced (atomic) path; large ones the single-pass path: same numbers."""
+    for (M, N, Kd) in [(64, 256, 768), (192, 2, 768), (64, 768, 256), (1000, 700, 96)]:
+        a, b, bias = rnd(M, Kd, seed=1), rnd(N, Kd, seed=2), rnd(N, seed=3)
+        out = K.linear_f32(a.to(dev), b.to(dev), bias=bias.to(dev))
+        assert relerr(out, a.double() @ b.double().t() + bias.double()) < 1e-5
+        acc = torch.ones(M, N, device=dev)
+        K.linear_f32(a.to(dev), b.to(dev), out=acc, accumulate=True, alpha=0.5)
+        assert relerr(acc, 1 + 0.5 * (a.double() @ b.double().t())) < 1e-5
+
+
 def test_patch_tokens_pool_relpos(K):
     cfg = O.OracleConfig(image_res=64, vision_layers=1)
     img = rnd(3, 3, 64, 64, seed=1)
@@ -282,6 +318,14 @@ def test_patch_tokens_pool_relpos(K):
     tl = table.clone().requires_grad_(True)
     (tl[idx.reshape(-1)].view(17, 17, 12).permute(2, 0, 1) * dS[..., :17].float().sum(0)).sum().backward()
     assert relerr(dtab, tl.grad) < 1e-5
+    idx14 = O.relative_position_index(14).to(dev)                  # the 224px window, batch cut into slices
+    T14 = int(idx14.max()) + 1
+    dS = bf(rnd(40, 3, 197, 256, seed=7)); dS[..., 197:] = 0
+    dtab = torch.ones(T14, 3, device=dev)
+    K.relpos_bias_bwd(dS.to(dev), idx14, dtab)
+    ref = torch.ones(T14, 3, dtype=torch.float64).index_add_(0, idx14.reshape(-1).cpu(),
+                                                             dS[..., :197].double().sum(0).permute(1, 2, 0).reshape(-1, 3))
+    assert relerr(dtab, ref) < 1e-5
 
 
 def test_embed_gather_linear_l2norm(K):

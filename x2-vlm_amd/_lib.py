@@ -10,7 +10,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libx2vlm_hip.so")
+# X2VLM_HIP_LIB: A/B a differently built library from the probes (never a fallback: the file must exist)
+LIB_PATH = os.environ.get("X2VLM_HIP_LIB") or os.path.join(_HERE, "libx2vlm_hip.so")
 
 P, I, L, F, U = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_uint
 
@@ -36,6 +37,8 @@ _SIGS = {
     "x2_layernorm_bwd": [P, P, P, P, P, P, P, P, P, P, P, I, I, I, U, U, F, U, U, F, P, I, P],
     "x2_colsum_bf16": [P, P, I, I, I, P, I, P],
     "x2_reduce_partials": [P, I, I, I, P, P, P, P],
+    "x2_reduce_partials_multi": [P, I, P],
+    "x2_cast_transpose_multi": [P, I, P],
     "x2_layerscale_bwd": [P, P, P, P, P, P, P, I, I, P, I, P],
     "x2_cast_bf16": [P, P, L, P],
     "x2_cast_transpose_bf16": [P, P, P, I, I, I, P],
@@ -44,12 +47,12 @@ _SIGS = {
     "x2_assemble_tokens_bwd": [P, P, P, I, I, I, P],
     "x2_pool_tokens": [P, P, I, I, I, I, P],
     "x2_relpos_bias": [P, P, P, P, I, I, I, I, P],
-    "x2_relpos_bias_bwd": [P, P, P, I, I, I, I, P],
+    "x2_relpos_bias_bwd": [P, P, P, P, I, I, I, I, I, P, I, P],
     "x2_embed_fwd": [P, P, P, P, P, I, I, I, P],
     "x2_embed_bwd": [P, P, P, P, P, I, I, I, P],
     "x2_gather_rows": [P, P, P, P, I, L, P],
     "x2_scatter_add_rows": [P, P, P, I, L, P],
-    "x2_linear_f32": [P, P, P, P, P, F, I, I, I, L, L, L, L, L, I, P],
+    "x2_linear_f32": [P, P, P, P, P, F, I, I, I, L, L, L, L, L, I, I, P],
     "x2_l2norm": [P, P, P, I, I, I, P],
     "x2_ce_fwd": [P, L, P, I, I, P, P, P, P],
     "x2_ce_bwd": [P, L, P, P, P, P, F, I, I, P, P, L, P],
@@ -90,10 +93,20 @@ def lib():
     return _lib
 
 
+_get_device = torch._C._cuda_getDevice if hasattr(torch._C, "_cuda_getDevice") else None
+_get_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
+def raw_stream():
+    """hipStream_t (as int) of torch's current stream on the current device.  torch.cuda.current_stream() costs
+    several microseconds of python per call (device-index normalisation, env lookups); a step makes ~4500 launches."""
+    return _get_raw_stream(_get_device())
+
+
 def call(name, *args):
     """Invoke an entry point on torch's current HIP stream; raise on a non-zero return."""
-    h = lib()
-    rc = getattr(h, name)(*args, torch.cuda.current_stream().cuda_stream)
+    h = _lib or lib()
+    rc = getattr(h, name)(*args, _get_raw_stream(_get_device()))
     if rc != 0:
         raise X2HipError("%s failed (%d): %s" % (name, rc, h.x2_last_error().decode()))
 

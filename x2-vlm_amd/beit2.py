@@ -112,8 +112,13 @@ class VisionTransformer(nn.Module):
         return len(self.blocks)
 
     def _params(self):
-        sd = dict(self.named_parameters())
-        return [sd[n] for n in vision_param_names(self.depth)]
+        # resolved once: walking named_parameters() costs ~1 ms of host time per call (Parameter objects are stable:
+        # .to() / load_state_dict() update them in place)
+        cached = self.__dict__.get("_param_list")
+        if cached is None:
+            sd = dict(self.named_parameters())
+            cached = self.__dict__["_param_list"] = [sd[n] for n in vision_param_names(self.depth)]
+        return cached
 
     def drop_path_scales(self, B, T, device, keep=None):
         """Per-row keep/(1-p) factors of every block's two residual branches (timm drop_path: one Bernoulli per

@@ -13,6 +13,7 @@
 // Replaces (reference, all implicit ATen/cuBLAS calls): F.linear in beit2.py:131,160,62,66 and
 // xbert.py:338-350,428,497,512,798,822 and their autograd backward.
 #include "x2_common.h"
+#include <type_traits>
 
 #define BM 128
 #define BN 128
@@ -195,29 +196,60 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNT p) {
   // workgroups of the FIRST round once (workgroups 256..511) de-phases every later round.
   if (p.stagger && blockIdx.x >= 256 && blockIdx.x < 512)
     for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(127);
-  stage(0, 0);
-  for (int kt = 0; kt < nk; ++kt) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (kt + 1 < nk && !(p.dbg & 1)) stage(kt + 1, (kt + 1) & 1);
-    const uint32_t sb = lds0 + (kt & 1) * STG;
-    if (p.dbg & 2) continue;
+  // Software pipeline (one barrier per K-step, placed in the MIDDLE of the step):
+  //   fragments of k-half 1 are requested before the MFMAs of k-half 0 are issued, and the fragments of the NEXT
+  //   tile's k-half 0 before the MFMAs of k-half 1, so every LDS read has 4*TM MFMAs (>= 256 cycles) to land behind;
+  //   at the barrier each wave has all of tile kt in registers, so slot kt&1 is refilled (tile kt+2) right after it:
+  //   a global->LDS request still has a full K-step to complete with only two slots.
+  bf16x8 a0[TM], b0[4], a1[TM], b1[4];
+  auto frags = [&](uint32_t sb, int ks, bf16x8 (&a)[TM], bf16x8 (&b)[4]) {
+    const uint32_t cs = (uint32_t)(((ks * 4 + fg) ^ fsw) << 4);
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const uint32_t cs = (uint32_t)(((ks * 4 + fg) ^ fsw) << 4);
-      bf16x8 a[TM], b[4];
+    for (int j = 0; j < 4; ++j) b[j] = lds_read_b128(sb + offB + j * 2048 + cs);
 #pragma unroll
-      for (int i = 0; i < TM; ++i) a[i] = lds_read_b128(sb + offA + i * 2048 + cs);
+    for (int i = 0; i < TM; ++i) a[i] = lds_read_b128(sb + offA + i * 2048 + cs);
+  };
+  // MFMAs [first, last) of the 4*TM that consume one fragment set (operands swapped: the accumulator tile is C^T,
+  // i.e. a lane holds m = frow and 4 consecutive n)
+  auto mma = [&](bf16x8 (&a)[TM], bf16x8 (&b)[4], auto first, auto last) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) b[j] = lds_read_b128(sb + offB + j * 2048 + cs);
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          // operands swapped: accumulator tile = C^T, i.e. lane holds (m = frow, 4 consecutive n)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+    for (int t = decltype(first)::value; t < decltype(last)::value; ++t)
+      acc[t >> 2][t & 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[t & 3], a[t >> 2], acc[t >> 2][t & 3], 0, 0, 0);
+  };
+  using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using IN = std::integral_constant<int, 4 * TM>;
+  // One K-step.  Each fragment set is requested right after the FIRST MFMA of the previous set, so the only LDS wait
+  // (the compiler's lgkmcnt(0) in front of that first MFMA) finds nothing outstanding that was not issued 4*TM-1
+  // MFMAs earlier.  The loop is peeled (refill / has-next are compile-time) to keep the body branch-free.
+  auto step = [&](int kt, auto refill, auto has_next) {
+    mma(a0, b0, I0{}, I1{});
+    __builtin_amdgcn_sched_barrier(0);
+    frags(lds0 + (kt & 1) * STG, 1, a1, b1);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(a0, b0, I1{}, IN{});
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (decltype(has_next)::value) {
+      // tile kt is in registers (lgkmcnt) and tile kt+1 has landed (vmcnt) for this wave; after the barrier, for all
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if constexpr (decltype(refill)::value) stage(kt + 2, kt & 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(a1, b1, I0{}, I1{});
+      __builtin_amdgcn_sched_barrier(0);
+      frags(lds0 + ((kt + 1) & 1) * STG, 0, a0, b0);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(a1, b1, I1{}, IN{});
+    } else {
+      mma(a1, b1, I0{}, IN{});
     }
-  }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  stage(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+  if (nk > 1) stage(1, 1);
+  frags(lds0, 0, a0, b0);
+  int kt = 0;
+  for (; kt + 2 < nk; ++kt) step(kt, std::true_type{}, std::true_type{});
+  if (kt + 1 < nk) { step(kt, std::false_type{}, std::true_type{}); ++kt; }
+  step(kt, std::false_type{}, std::false_type{});
 
   __syncthreads();                                   // every wave is done reading the last operand tiles
   if (p.dbg & 4) { if (acc[0][0][0] == 12345.678f) reinterpret_cast<float*>(p.C)[0] = acc[1][1][1] + acc[2][2][2] + acc[3][3][3]; return; }

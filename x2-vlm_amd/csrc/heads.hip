@@ -84,20 +84,24 @@ extern "C" int x2_scatter_add_rows(const float* src, const int* idx, float* dst,
 
 // ------------------------------------------------------------------------------------ small fp32 linear
 // C[m][n] (+)= alpha * sum_k A[m*sam + k*sak] * B[n*sbn + k*sbk] (+ bias[n]); alpha read from device if alpha_ptr.
-// 64x64 tile, 256 threads x (4x4) outputs, K step 16 through LDS.  For the heads (M <= a few hundred).
+// 64x64 tile, 256 threads x (4x4) outputs, K step 16 through LDS.  For the heads (M <= a few hundred): their
+// output grids are 1-12 workgroups, so the contraction is cut into gridDim.z slices that add their partial tile
+// with fp32 atomics (distinct addresses, a few thousand per launch) onto a zeroed / accumulating C.
 __global__ __launch_bounds__(256) void linear_f32_kernel(const float* __restrict__ A, const float* __restrict__ B, float* C,
                                                          const float* __restrict__ bias, const float* alpha_ptr, float alpha, int M, int N,
                                                          int K, long sam, long sak, long sbn, long sbk, long ldc, int accumulate) {
   __shared__ float As[16][65], Bs[16][65];
   const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
   const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+  const int kper = ((K + gridDim.z - 1) / gridDim.z + 15) & ~15;
+  const int kbeg = blockIdx.z * kper, kend = min(K, kbeg + kper);
   float acc[4][4] = {};
-  for (int k0 = 0; k0 < K; k0 += 16) {
+  for (int k0 = kbeg; k0 < kend; k0 += 16) {
     for (int e = threadIdx.x; e < 1024; e += 256) {
       const int kk = e & 15, rr = e >> 4;
       const int m = m0 + rr, n = n0 + rr, k = k0 + kk;
-      As[kk][rr] = (m < M && k < K) ? A[m * sam + k * sak] : 0.f;
-      Bs[kk][rr] = (n < N && k < K) ? B[n * sbn + k * sbk] : 0.f;
+      As[kk][rr] = (m < M && k < kend) ? A[m * sam + k * sak] : 0.f;
+      Bs[kk][rr] = (n < N && k < kend) ? B[n * sbn + k * sbk] : 0.f;
     }
     __syncthreads();
 #pragma unroll
@@ -113,23 +117,26 @@ __global__ __launch_bounds__(256) void linear_f32_kernel(const float* __restrict
     __syncthreads();
   }
   const float al = alpha_ptr ? alpha * alpha_ptr[0] : alpha;
+  const bool split = gridDim.z > 1;
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int m = m0 + ty * 4 + i, n = n0 + tx * 4 + j;
       if (m < M && n < N) {
-        float v = al * acc[i][j] + (bias ? bias[n] : 0.f);
-        if (accumulate) v += C[m * ldc + n];
-        C[m * ldc + n] = v;
+        float v = al * acc[i][j] + ((bias && blockIdx.z == 0) ? bias[n] : 0.f);
+        if (split) atomicAdd(C + m * ldc + n, v);
+        else { if (accumulate) v += C[m * ldc + n]; C[m * ldc + n] = v; }
       }
     }
 }
+// ksplit > 1: C must hold zeros (or the values to accumulate onto) when the kernel starts
 extern "C" int x2_linear_f32(const float* A, const float* B, float* C, const float* bias, const float* alpha_ptr, float alpha, int M,
-                             int N, int K, long sam, long sak, long sbn, long sbk, long ldc, int accumulate, void* stream) {
-  X2_REQUIRE(M > 0 && N > 0 && K > 0, "x2_linear_f32: M=%d N=%d K=%d", M, N, K);
-  hipLaunchKernelGGL(linear_f32_kernel, dim3((N + 63) / 64, (M + 63) / 64), dim3(256), 0, (hipStream_t)stream, A, B, C, bias, alpha_ptr,
-                     alpha, M, N, K, sam, sak, sbn, sbk, ldc, accumulate);
+                             int N, int K, long sam, long sak, long sbn, long sbk, long ldc, int accumulate, int ksplit, void* stream) {
+  X2_REQUIRE(M > 0 && N > 0 && K > 0 && ksplit >= 1 && ksplit <= 64, "x2_linear_f32: M=%d N=%d K=%d ksplit=%d", M, N, K, ksplit);
+  X2_REQUIRE(ksplit == 1 || accumulate, "x2_linear_f32: ksplit>1 adds atomically: pass accumulate=1 and a defined C");
+  hipLaunchKernelGGL(linear_f32_kernel, dim3((N + 63) / 64, (M + 63) / 64, ksplit), dim3(256), 0, (hipStream_t)stream, A, B, C, bias,
+                     alpha_ptr, alpha, M, N, K, sam, sak, sbn, sbk, ldc, accumulate);
   return x2_check_launch("x2_linear_f32");
 }
 

@@ -103,6 +103,52 @@ extern "C" int x2_reduce_partials(const float* part, int nblk, int nk, int width
   return x2_check_launch("x2_reduce_partials");
 }
 
+// Several stage-2 reductions in one launch (all parameter-gradient sums of one layer's backward): the reductions
+// are tiny (a few dozen workgroups each), so one launch per reduction is pure launch latency on both sides.
+// desc rows of 7 int64: {part, nblk, nk, width, o0, o1, o2}.
+#define RPM_MAX 16
+struct ReduceDesc { const float* part; float* o[3]; int nblk, nk, width, blk0; };
+struct ReduceGroup { ReduceDesc d[RPM_MAX]; int count; };
+__global__ __launch_bounds__(256) void reduce_partials_multi_kernel(ReduceGroup g) {
+  int e = 0;
+#pragma unroll
+  for (int i = 1; i < RPM_MAX; ++i) if (i < g.count && (int)blockIdx.x >= g.d[i].blk0) e = i;
+  const ReduceDesc d = g.d[e];
+  const int local = blockIdx.x - d.blk0, ctiles = (d.width + 63) / 64;
+  const int k = local / ctiles, c = (local % ctiles) * 64 + (threadIdx.x & 63), sl = threadIdx.x >> 6;
+  __shared__ float red[3][64];
+  float s = 0.f;
+  if (c < d.width) {
+#pragma unroll 4
+    for (int b = sl; b < d.nblk; b += 4) s += d.part[((long)b * d.nk + k) * d.width + c];
+  }
+  if (sl > 0) red[sl - 1][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (sl == 0 && c < d.width) {
+    float* o = d.o[k];
+    if (o) o[c] += s + red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x];
+  }
+}
+extern "C" int x2_reduce_partials_multi(const int64_t* desc, int count, void* stream) {
+  X2_REQUIRE(desc && count >= 1, "x2_reduce_partials_multi: count=%d", count);
+  for (int i0 = 0; i0 < count; i0 += RPM_MAX) {
+    ReduceGroup g; g.count = count - i0 < RPM_MAX ? count - i0 : RPM_MAX;
+    int blocks = 0;
+    for (int i = 0; i < g.count; ++i) {
+      const int64_t* q = desc + (size_t)(i0 + i) * 7;
+      ReduceDesc& d = g.d[i];
+      d.part = (const float*)q[0]; d.nblk = (int)q[1]; d.nk = (int)q[2]; d.width = (int)q[3];
+      d.o[0] = (float*)q[4]; d.o[1] = (float*)q[5]; d.o[2] = (float*)q[6];
+      X2_REQUIRE(d.part && d.nblk > 0 && d.nk >= 1 && d.nk <= 3 && d.width > 0, "x2_reduce_partials_multi[%d]: nblk=%d nk=%d width=%d",
+                 i0 + i, d.nblk, d.nk, d.width);
+      d.blk0 = blocks;
+      blocks += ((d.width + 63) / 64) * d.nk;
+    }
+    hipLaunchKernelGGL(reduce_partials_multi_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g);
+  }
+  return x2_check_launch("x2_reduce_partials_multi");
+}
+
 // ---------------------------------------------------------------------------------- LayerNorm bwd
 // dx = dres + rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * w ; dw += sum dy*xhat ; db += sum dy ;
 // optionally dcol += sum_rows dx (the bias gradient of the linear layer that produced the LN input).
@@ -373,6 +419,65 @@ extern "C" int x2_cast_transpose_bf16(const float* src, void* dst, void* dstT, i
   return x2_check_launch("x2_cast_transpose_bf16");
 }
 
+// The bf16 copies of MANY fp32 weights in one launch (all linears of a tower: once per optimizer step).  Entry i
+// casts src_i [R_i][C_i] into rows roff_i.. of a bf16 matrix dst [*][C_i] and into columns roff_i.. of the transposed
+// bf16 matrix dstT [C_i][ldt_i], so weights that are used stacked (q/k/v) need no concatenation pass.
+// desc rows of 7 int64: {src, dst, dstT, R, C, ldt, roff}; R, C, ldt, roff multiples of 4.
+#define CTM_MAX 48
+struct CastDesc { const float* s; bf16_t* d; bf16_t* dT; int R, C, ldt, blk0; };
+struct CastGroup { CastDesc e[CTM_MAX]; int count; };
+__global__ __launch_bounds__(256) void cast_transpose_multi_kernel(CastGroup g) {
+  __shared__ float tile[64][65];
+  int lo = 0, hi = g.count - 1;                    // last entry whose first block is <= blockIdx.x
+  while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if ((int)blockIdx.x >= g.e[mid].blk0) lo = mid; else hi = mid - 1; }
+  const CastDesc d = g.e[lo];
+  const int local = blockIdx.x - d.blk0, ct = (d.C + 63) / 64;
+  const int r0 = (local / ct) * 64, c0 = (local % ct) * 64;
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = r0 + ty + 16 * i, c = c0 + tx * 4;
+    float4 v{0.f, 0.f, 0.f, 0.f};
+    if (r < d.R && c < d.C) {
+      v = *reinterpret_cast<const float4*>(d.s + (long)r * d.C + c);
+      *reinterpret_cast<u32x2*>(d.d + (long)r * d.C + c) = u32x2{pack_bf16(v.x, v.y), pack_bf16(v.z, v.w)};
+    }
+    tile[ty + 16 * i][tx * 4 + 0] = v.x; tile[ty + 16 * i][tx * 4 + 1] = v.y;
+    tile[ty + 16 * i][tx * 4 + 2] = v.z; tile[ty + 16 * i][tx * 4 + 3] = v.w;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = c0 + ty + 16 * i, r = r0 + tx * 4;
+    if (c >= d.C || r >= d.R) continue;
+    *reinterpret_cast<u32x2*>(d.dT + (long)c * d.ldt + r) =
+        u32x2{pack_bf16(tile[tx * 4 + 0][ty + 16 * i], tile[tx * 4 + 1][ty + 16 * i]),
+              pack_bf16(tile[tx * 4 + 2][ty + 16 * i], tile[tx * 4 + 3][ty + 16 * i])};
+  }
+}
+extern "C" int x2_cast_transpose_multi(const int64_t* desc, int count, void* stream) {
+  X2_REQUIRE(desc && count >= 1, "x2_cast_transpose_multi: count=%d", count);
+  for (int i0 = 0; i0 < count; i0 += CTM_MAX) {
+    CastGroup g; g.count = count - i0 < CTM_MAX ? count - i0 : CTM_MAX;
+    int blocks = 0;
+    for (int i = 0; i < g.count; ++i) {
+      const int64_t* q = desc + (size_t)(i0 + i) * 7;
+      CastDesc& d = g.e[i];
+      d.R = (int)q[3]; d.C = (int)q[4]; d.ldt = (int)q[5];
+      const int roff = (int)q[6];
+      X2_REQUIRE(q[0] && q[1] && q[2] && d.R > 0 && d.C > 0 && roff >= 0 && d.ldt >= roff + d.R && ((d.R | d.C | d.ldt | roff) & 3) == 0,
+                 "x2_cast_transpose_multi[%d]: R=%d C=%d ldt=%d roff=%d (multiples of 4 required)", i0 + i, d.R, d.C, d.ldt, roff);
+      d.s = (const float*)q[0];
+      d.d = (bf16_t*)q[1] + (size_t)roff * d.C;
+      d.dT = (bf16_t*)q[2] + roff;
+      d.blk0 = blocks;
+      blocks += ((d.R + 63) / 64) * ((d.C + 63) / 64);
+    }
+    hipLaunchKernelGGL(cast_transpose_multi_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g);
+  }
+  return x2_check_launch("x2_cast_transpose_multi");
+}
+
 // ---------------------------------------------------------------------------------- patches / tokens
 // image fp32 (B,3,R,R) -> patch rows bf16 [B*g*g][3*ps*ps], column = c*ps*ps + py*ps + px (Conv2d weight order)
 __global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ img, bf16_t* __restrict__ cols, int B, int R, int ps) {
@@ -503,32 +608,59 @@ extern "C" int x2_relpos_bias(const float* table, const long* index, float* bias
                      biasT, N, H, ld, ldT);
   return x2_check_launch("x2_relpos_bias");
 }
-// dtable[index[i][j]][h] += sum_b dS[b][h][i][j]   (dS bf16 [B][H][N][ld], ld % 8 == 0).
-// One thread = 8 consecutive j of one (h, i): 16-byte loads down the batch, then 8 scatter-adds.
-__global__ __launch_bounds__(256) void relpos_bias_bwd_kernel(const bf16_t* __restrict__ dS, const long* __restrict__ index,
-                                                              float* dtable, int B, int N, int H, int ld) {
+// dtable[index[i][j]][h] += sum_b dS[b][h][i][j]   (dS bf16 [B][H][N][ld], ld % 8 == 0), without atomics:
+//   stage 1: the batch is cut into S slices; one thread sums 8 consecutive j of one (h, i) down its slice with 16-byte
+//            loads and writes ws[s][h][i][j] (fp32);
+//   stage 2: one wave per (table entry t, head h) gathers the positions that index t (CSR inverse of the static
+//            relative_position_index: inv_off [T+1], inv_pos = i * ld + j) from all S slices and adds the total.
+// (An atomic scatter - 465 k adds onto 8.8 k addresses per layer - took 3x the time of reading dS.)
+__global__ __launch_bounds__(256) void relpos_bias_bsum_kernel(const bf16_t* __restrict__ dS, float* __restrict__ ws, int B, int N, int H,
+                                                               int ld, int per) {
   const int per_row = ld >> 3;
   const long t = blockIdx.x * 256L + threadIdx.x;
   if (t >= (long)H * N * per_row) return;
-  const int j0 = (int)(t % per_row) * 8, i = (int)((t / per_row) % N), h = (int)(t / ((long)per_row * N));
+  const int j0 = (int)(t % per_row) * 8;
   if (j0 >= N) return;
+  const long hi = t / per_row;                       // h * N + i
   float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  const bf16_t* p = dS + ((long)h * N + i) * ld + j0;
   const long bstride = (long)H * N * ld;
-#pragma unroll 4
-  for (int b = 0; b < B; ++b) {
+  const int b0 = blockIdx.y * per, b1 = min(B, b0 + per);
+  const bf16_t* p = dS + hi * ld + j0;
+#pragma unroll 8
+  for (int b = b0; b < b1; ++b) {
     const u32x4 v = *reinterpret_cast<const u32x4*>(p + b * bstride);
 #pragma unroll
     for (int e = 0; e < 4; ++e) { acc[2 * e] += bf_lo(v[e]); acc[2 * e + 1] += bf_hi(v[e]); }
   }
-#pragma unroll
-  for (int e = 0; e < 8; ++e)
-    if (j0 + e < N) atomicAdd(dtable + index[(long)i * N + j0 + e] * H + h, acc[e]);
+  float* o = ws + ((long)blockIdx.y * H * N + hi) * ld + j0;
+  *reinterpret_cast<float4*>(o) = float4{acc[0], acc[1], acc[2], acc[3]};
+  *reinterpret_cast<float4*>(o + 4) = float4{acc[4], acc[5], acc[6], acc[7]};
 }
-extern "C" int x2_relpos_bias_bwd(const void* dS, const long* index, float* dtable, int B, int N, int H, int ld, void* stream) {
-  X2_REQUIRE(B > 0 && N > 0 && H > 0 && ld >= N && ld % 8 == 0, "x2_relpos_bias_bwd: B=%d N=%d H=%d ld=%d", B, N, H, ld);
+__global__ __launch_bounds__(256) void relpos_bias_gather_kernel(const float* __restrict__ ws, const int* __restrict__ inv_off,
+                                                                 const int* __restrict__ inv_pos, float* dtable, int T, int H, long plane,
+                                                                 int S) {
+  const int w = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (w >= T * H) return;
+  const int t = w / H, h = w % H;
+  const int q0 = inv_off[t], q1 = inv_off[t + 1];
+  float acc = 0.f;
+  for (int q = q0 + lane; q < q1; q += 64) {
+    const float* src = ws + (long)h * plane + inv_pos[q];
+    for (int s_ = 0; s_ < S; ++s_) acc += src[(long)s_ * H * plane];
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) dtable[(long)t * H + h] += acc;
+}
+extern "C" int x2_relpos_bias_bwd(const void* dS, const int* inv_off, const int* inv_pos, float* dtable, int B, int N, int H, int ld,
+                                  int T, float* ws, int slices, void* stream) {
+  X2_REQUIRE(B > 0 && N > 0 && H > 0 && T > 0 && ld >= N && ld % 8 == 0 && slices >= 1 && slices <= B && ws && inv_off && inv_pos,
+             "x2_relpos_bias_bwd: B=%d N=%d H=%d ld=%d T=%d slices=%d", B, N, H, ld, T, slices);
   const long threads = (long)H * N * (ld >> 3);
-  hipLaunchKernelGGL(relpos_bias_bwd_kernel, dim3((int)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dS, index,
-                     dtable, B, N, H, ld);
+  const int per = (B + slices - 1) / slices;
+  hipLaunchKernelGGL(relpos_bias_bsum_kernel, dim3((int)((threads + 255) / 256), slices), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)dS, ws, B, N, H, ld, per);
+  hipLaunchKernelGGL(relpos_bias_gather_kernel, dim3((T * H + 3) / 4), dim3(256), 0, (hipStream_t)stream, ws, inv_off, inv_pos, dtable, T,
+                     H, (long)N * ld, slices);
   return x2_check_launch("x2_relpos_bias_bwd");
 }
+

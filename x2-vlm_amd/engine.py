@@ -15,6 +15,7 @@ import math
 import torch
 
 from . import kernels as K
+from ._lib import raw_stream
 
 BF16, F32 = torch.bfloat16, torch.float32
 
@@ -45,6 +46,38 @@ class WeightBank:
             src = w2[0] if len(w2) == 1 else torch.cat(w2, 0)
             return K.cast_transpose_bf16(src.contiguous())
         return self._get(key, vers, build)
+
+    def prepare(self, groups):
+        """Build every stale (W, W^T) pair of `groups` (tuples of weights, as `linear` takes them) with ONE
+        multi-tensor launch and one allocation, instead of one cast launch (+ a concatenation) per weight when the
+        layer first asks for it: a tower's ~50-100 weights are all re-cast once per optimizer step."""
+        todo = []
+        for ws in groups:
+            key = tuple(id(w) for w in ws)
+            vers = tuple((w._version, w.data_ptr()) for w in ws)
+            ent = self._c.get(key)
+            if ent is not None and ent[0] == vers:
+                continue
+            shapes = [(w.shape[0], w.numel() // w.shape[0]) for w in ws]
+            C_ = shapes[0][1]
+            if any(c != C_ or (r | c) & 3 or w.dtype != F32 or not w.is_contiguous() for (r, c), w in zip(shapes, ws)):
+                continue                                   # left to the one-at-a-time path of `linear`
+            todo.append((key, vers, ws, sum(r for r, _ in shapes), C_))
+        if not todo:
+            return
+        total = sum(2 * R * C_ for _, _, _, R, C_ in todo)
+        flat = torch.empty(total, device=todo[0][2][0].device, dtype=BF16)
+        desc, o = [], 0
+        for key, vers, ws, R, C_ in todo:
+            plain = flat[o:o + R * C_].view(R, C_)
+            tr = flat[o + R * C_:o + 2 * R * C_].view(C_, R)
+            o += 2 * R * C_
+            roff = 0
+            for w in ws:
+                desc.append((w.data_ptr(), plain.data_ptr(), tr.data_ptr(), w.shape[0], C_, R, roff))
+                roff += w.shape[0]
+            self._c[key] = (vers, (plain, tr))
+        K.cast_transpose_multi(desc)
 
     def vocab(self, w):
         """word embeddings [V,Hd] -> (bf16 [Vp,Hd] zero-padded rows, bf16 [Hd,Vp]), Vp = V rounded to 64."""
@@ -115,7 +148,7 @@ class SideStream:
 
     @property
     def stream(self):
-        key = torch.cuda.current_stream().cuda_stream
+        key = raw_stream()
         if key not in self.streams:
             self.streams[key] = torch.cuda.Stream()
         return self.streams[key]
@@ -141,7 +174,7 @@ class SideStream:
     def join(self):
         """Make the current stream wait for the side stream (call before gradients leave the stage)."""
         if self.enabled and torch.cuda.is_available():
-            key = torch.cuda.current_stream().cuda_stream
+            key = raw_stream()
             if key in self.streams:
                 torch.cuda.current_stream().wait_stream(self.streams[key])
 
@@ -159,8 +192,8 @@ def _finish_layer_backward(G, tn):
     deferred, K.DEFERRED = K.DEFERRED, None
 
     def work():
-        for ws, nblk, nk, width, outs in deferred or ():
-            K.reduce_partials(ws, nblk, nk, width, outs)
+        if deferred:
+            K.reduce_partials_multi(deferred)
         K.gemm_tn_grouped(tn)
     keep = [t for pr in tn for t in pr[:2]] + [G.flat] + [d[0] for d in (deferred or ())]
     G.publish(SIDE.launch(work, keep))
@@ -213,6 +246,8 @@ class VisionEncoderFn(torch.autograd.Function):
         D = p["cls_token"].numel()
         M = B * T
         scale = (D // H) ** -0.5
+        BANK.prepare([(p["patch_embed.proj.weight"],)] + [(p["blocks.%d.%s.weight" % (i, n)],) for i in range(meta["depth"])
+                                                            for n in ("attn.qkv", "attn.proj", "mlp.fc1", "mlp.fc2")])
         cols = K.patchify(image.contiguous(), ps)
         wpe, _ = BANK.linear(p["patch_embed.proj.weight"])
         patch = K.gemm_nt(cols, wpe, bias=p["patch_embed.proj.bias"], out_dtype=F32)
@@ -381,6 +416,16 @@ class BertLayersFn(torch.autograd.Function):
         if cross:
             Bi, T, Dv = enc.shape
             encb = K.cast_bf16(enc.contiguous().view(Bi * T, Dv))
+        groups = []
+        for i in range(meta["lo"], meta["hi"]):
+            b = "layer.%d." % i
+            a, c = b + "attention.", b + "crossattention."
+            groups += [(p[a + "self.query.weight"], p[a + "self.key.weight"], p[a + "self.value.weight"]),
+                       (p[a + "output.dense.weight"],), (p[b + "intermediate.dense.weight"],), (p[b + "output.dense.weight"],)]
+            if cross and i >= meta["fusion_at"]:
+                groups += [(p[c + "self.query.weight"],), (p[c + "self.key.weight"], p[c + "self.value.weight"]),
+                           (p[c + "output.dense.weight"],)]
+        BANK.prepare(groups)
         saved = []
         for i in range(meta["lo"], meta["hi"]):
             b = "layer.%d." % i

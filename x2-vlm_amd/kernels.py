@@ -6,7 +6,7 @@ import ctypes as C
 
 import torch
 
-from ._lib import AttnArgs, call, ptr
+from ._lib import AttnArgs, call, ptr, raw_stream
 
 BF16, F32 = torch.bfloat16, torch.float32
 
@@ -71,7 +71,7 @@ _WS = {}
 def workspace(device, nfloats):
     """Scratch for the two-stage column reductions: one growing fp32 buffer per (device, stream); kernels on one
     stream use it strictly in order (stage 1 writes, stage 2 reads, next kernel overwrites)."""
-    key = (device, torch.cuda.current_stream().cuda_stream)
+    key = (device, raw_stream())
     buf = _WS.get(key)
     if buf is None or buf.numel() < nfloats:
         buf = torch.empty(max(nfloats, 1 << 22), device=device, dtype=F32)
@@ -94,6 +94,21 @@ def _ws_and_defer(device, nfloats):
 def reduce_partials(ws, nblk, nk, width, outs):
     o = list(outs) + [None] * (3 - len(outs))
     call("x2_reduce_partials", ptr(ws), nblk, nk, width, ptr(o[0]), ptr(o[1]), ptr(o[2]))
+
+
+def reduce_partials_multi(items):
+    """Several stage-2 reductions (tuples as collected in DEFERRED) in one launch."""
+    flat = []
+    for ws, nblk, nk, width, outs in items:
+        o = list(outs) + [None] * (3 - len(outs))
+        flat += [ws.data_ptr(), nblk, nk, width] + [0 if t is None else t.data_ptr() for t in o]
+    call("x2_reduce_partials_multi", (C.c_int64 * len(flat))(*flat), len(items))
+
+
+def cast_transpose_multi(desc):
+    """desc: tuples (src_ptr, dst_ptr, dstT_ptr, R, C, ldt, row_offset), see csrc/rowwise.hip."""
+    flat = [v for d in desc for v in d]
+    call("x2_cast_transpose_multi", (C.c_int64 * len(flat))(*flat), len(desc))
 
 
 def _rows(t):
@@ -324,9 +339,34 @@ def relpos_bias(table, index, want_T=True):
     return bias, biasT
 
 
+_RELPOS_CSR = {}
+
+
+def _relpos_csr(index, ld, T):
+    """CSR inverse of the (static) relative_position_index: for table entry t the flat positions i * ld + j that
+    read it.  Built once per (index tensor, ld) with torch ops on the device."""
+    key = (index.data_ptr(), index._version, ld, T)
+    ent = _RELPOS_CSR.get(key)
+    if ent is None:
+        N = index.shape[0]
+        flat = index.reshape(-1)
+        order = torch.argsort(flat, stable=True)
+        off = torch.zeros(T + 1, device=index.device, dtype=torch.int32)
+        off[1:] = torch.cumsum(torch.bincount(flat, minlength=T), 0)
+        pos = ((order // N) * ld + order % N).to(torch.int32).contiguous()
+        ent = _RELPOS_CSR[key] = (off, pos, index)       # keeps `index` alive: the key holds its address
+    return ent[0], ent[1]
+
+
 def relpos_bias_bwd(dS, index, dtable):
+    """dtable[index[i][j]][h] += sum_b dS[b][h][i][j]: batch-slice sums into the stream workspace, then a gather."""
     B, H, N, ld = dS.shape
-    call("x2_relpos_bias_bwd", ptr(dS), ptr(index), ptr(dtable), B, N, H, ld)
+    T = dtable.shape[0]
+    assert dS.dtype == BF16 and dS.is_contiguous() and dtable.dtype == F32 and dtable.is_contiguous() and dtable.shape[1] == H
+    off, pos = _relpos_csr(index, ld, T)
+    slices = max(1, min(8, B // 8))
+    ws = workspace(dS.device, slices * H * N * ld)
+    call("x2_relpos_bias_bwd", ptr(dS), ptr(off), ptr(pos), ptr(dtable), B, N, H, ld, T, ptr(ws), slices)
 
 
 # ----------------------------------------------------------------------------- embeddings, heads, losses
@@ -366,11 +406,16 @@ def linear_f32(A, B, *, bias=None, transA=False, transB=False, alpha=1.0, alpha_
     N = B.shape[1] if transB else B.shape[0]
     sam, sak = (A.stride(1), A.stride(0)) if transA else (A.stride(0), A.stride(1))
     sbn, sbk = (B.stride(1), B.stride(0)) if transB else (B.stride(0), B.stride(1))
+    # head-sized outputs (a handful of 64x64 tiles) with a long contraction: slice K over gridDim.z (atomic partial tiles)
+    tiles = ((M + 63) // 64) * ((N + 63) // 64)
+    ksplit = 1 if tiles >= 64 or K < 128 else max(1, min(16, K // 64, 256 // tiles))
     if out is None:
         assert not accumulate
-        out = torch.empty(M, N, device=A.device, dtype=F32)
+        out = (torch.zeros if ksplit > 1 else torch.empty)(M, N, device=A.device, dtype=F32)
+    elif ksplit > 1 and not accumulate:
+        out.zero_()
     call("x2_linear_f32", ptr(A), ptr(B), ptr(out), ptr(bias), ptr(alpha_ptr), alpha, M, N, K, sam, sak, sbn, sbk,
-         out.stride(0), 1 if accumulate else 0)
+         out.stride(0), 1 if (accumulate or ksplit > 1) else 0, ksplit)
     return out
 
 

@@ -143,8 +143,11 @@ class BertEncoder(nn.Module):
                 off = torch.zeros(Bi + 1, device=kv.device, dtype=torch.int32)
                 off[1:] = torch.cumsum(counts, 0)
                 meta.update(kv_idx=kv.contiguous(), seq_off=off, seq_ids=order.contiguous())
-        sd = dict(self.named_parameters())
-        params = [sd[n] for n in bert_layer_param_names(lo, hi, cfg.fusion_layer, cross)]
+        cache = self.__dict__.setdefault("_param_lists", {})      # see beit2.VisionTransformer._params
+        params = cache.get((lo, hi, cross))
+        if params is None:
+            sd = dict(self.named_parameters())
+            params = cache[(lo, hi, cross)] = [sd[n] for n in bert_layer_param_names(lo, hi, cfg.fusion_layer, cross)]
         return BertLayersFn.apply(hidden, enc if cross else None, meta, *params)
 
 
