@@ -52,8 +52,12 @@ int x2_gemm_nt(const void* A, const void* B, void* C, int M, int N, int K, int l
 /* Weight gradients of one layer in one launch: for each problem  dW[N,K] (+)= dY[Mc,N]^T . X[Mc,K]  (fp32 out).
  * problems: count (<= 8) rows of 11 int64 {dY, X, dW, Mc, N, K, ld_dY, ld_X, ld_dW, n_ld, k_ld}; n_ld / k_ld are
  * the readable widths of dY / X rows (>= N / K, multiples of 8).  accumulate: dW += instead of dW =.
- * split > 1 splits the contraction over `split` workgroups per tile (fp32 atomics; requires accumulate). */
-int x2_gemm_tn_grouped(const int64_t* problems, int count, int accumulate, int split, void* stream);
+ * Contraction lengths that are all multiples of 64 run on 256x256 tiles (one workgroup per CU); split = slices of the
+ * contraction per tile (0 = chosen to fill the CUs), whose partial tiles pass through ws (split * tiles256 * 65536
+ * floats; ws = NULL: never split) and are added in a fixed order.  Otherwise 128x128 tiles, where split > 1 adds with
+ * fp32 atomics and requires accumulate. */
+int x2_gemm_tn_grouped(const int64_t* problems, int count, int accumulate, int split, float* ws, long ws_floats,
+                       void* stream);
 
 /* ---- fused attention, head dim 64 (csrc/attention.hip) ----------------------------------------------
  * beit2.py:135-159 (q*scale, QK^T, + relative_position_bias, softmax, PV); xbert.py:364-409 (QK^T/sqrt(d),

@@ -91,8 +91,17 @@ def test_gemm_nt_strided_views(K):
     assert float(outw[:, :256].abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("Mc,N,K_", [(128, 128, 128), (788, 768, 768), (1920, 256, 3072), (12608, 768, 2304), (100, 136, 72)])
-def test_gemm_tn_grouped(K, Mc, N, K_):
+@pytest.fixture(params=[1, 2], ids=["tn128x128", "tn256x256"])
+def tn_tile(request):
+    lib = importlib.import_module("x2-vlm_amd._lib").lib()
+    lib.x2_tune(5, request.param)        # 1: always the 128x128 kernel, 2: 256x256 whenever the contraction allows
+    yield request.param
+    lib.x2_tune(5, 0)
+
+
+@pytest.mark.parametrize("Mc,N,K_", [(128, 128, 128), (788, 768, 768), (1920, 256, 3072), (12608, 768, 2304), (100, 136, 72),
+                                     (64, 256, 256), (3840, 520, 264)])
+def test_gemm_tn_grouped(K, Mc, N, K_, tn_tile):
     dY, X = bf(rnd(Mc, N, seed=1)), bf(rnd(Mc, K_, seed=2))
     ref = dY.float().t() @ X.float()
     dW = torch.full((N, K_), 7.0, device=dev)
@@ -103,9 +112,14 @@ def test_gemm_tn_grouped(K, Mc, N, K_):
     dW.zero_()
     K.gemm_tn_grouped([(dY.to(dev), X.to(dev), dW)], accumulate=True, split=3)
     assert relerr(dW, ref) < 1e-5
+    if Mc % 64 == 0 and tn_tile == 2:    # deterministic split (256x256 kernel): plain store, several slice counts
+        for split in (1, 2, 4):
+            dW.fill_(3.0)
+            K.gemm_tn_grouped([(dY.to(dev), X.to(dev), dW)], split=split)
+            assert relerr(dW, ref) < 1e-5
 
 
-def test_gemm_tn_group_of_problems_and_padded_rows(K):
+def test_gemm_tn_group_of_problems_and_padded_rows(K, tn_tile):
     probs, refs = [], []
     for i, (Mc, N, K_) in enumerate([(500, 256, 128), (500, 128, 384), (700, 64, 64), (64, 8, 8)]):
         dY, X = bf(rnd(Mc, N, seed=10 + i)), bf(rnd(Mc, K_, seed=20 + i))
@@ -118,6 +132,23 @@ def test_gemm_tn_group_of_problems_and_padded_rows(K):
     K.gemm_tn_grouped(probs)
     for p, r in zip(probs, refs):
         assert relerr(p[2], r) < 1e-5
+    # one layer's worth of mixed problems with 64-aligned contractions (the 256x256 path, automatic split)
+    probs, refs = [], []
+    for i, (Mc, N, K_) in enumerate([(1920, 768, 3072), (1920, 3072, 768), (1920, 768, 768), (1920, 2304, 768), (3136, 1536, 768),
+                                     (1920, 250, 64)]):
+        dY, X = bf(rnd(Mc, round_up8(N), seed=40 + i)), bf(rnd(Mc, K_, seed=50 + i))
+        probs.append((dY.to(dev), X.to(dev), torch.empty(N, K_, device=dev), round_up8(N), K_))
+        refs.append(dY.float().t()[:N] @ X.float())
+    for split in ((0, 1, 3) if tn_tile == 2 else (0, 1)):
+        for p in probs:
+            p[2].fill_(9.0)
+        K.gemm_tn_grouped(probs, split=split)
+        for p, r in zip(probs, refs):
+            assert relerr(p[2], r) < 1e-5
+
+
+def round_up8(n):
+    return (n + 7) // 8 * 8
 
 
 def attn_ref(q, k, v, scale, add):

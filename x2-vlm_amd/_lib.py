@@ -30,7 +30,7 @@ class AttnArgs(C.Structure):
 # name -> argtypes (all return int: 0 ok, < 0 error; message via x2_last_error)
 _SIGS = {
     "x2_gemm_nt": [P, P, P, I, I, I, I, I, I, P, P, P, I, P, I, I, I, U, U, F, P, P, P],
-    "x2_gemm_tn_grouped": [P, I, I, I, P],
+    "x2_gemm_tn_grouped": [P, I, I, I, P, L, P],
     "x2_attn_fwd": [C.POINTER(AttnArgs), P],
     "x2_attn_bwd": [C.POINTER(AttnArgs), P],
     "x2_layernorm_fwd": [P, P, P, P, P, P, P, I, I, F, I, U, U, F, P],

@@ -523,13 +523,208 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmTNGroup g) {
   }
 }
 
-// problems: `count` rows of 11 int64: {A, B, C, Mc, N, K, lda, ldb, ldc, n_ld, k_ld}
-extern "C" int x2_gemm_tn_grouped(const int64_t* problems, int count, int accumulate, int split, void* stream) {
+// ---------------------------------------------------------------------------------------------
+// TN, large tile: 256(n) x 256(k) outputs per 512-thread workgroup (8 waves as 2 x 4, 128 x 64 each = 8 x 4 MFMA
+// tiles, 128 accumulator VGPRs), one workgroup per CU.  Weight gradients are the one GEMM family of this step with a
+// long contraction (Mc = 3840..12608 rows) and a negligible epilogue, so what bounds them is LDS traffic per MFMA:
+// a 128x64 wave tile reads 0.375 fragments per MFMA (0.5 at 64x64) and the block stages 1/128 instead of 1/64 bytes
+// per flop through the global->LDS path.
+//   LDS: 2 contraction steps x 4 half-tiles (A0, A1 = dY columns n0.., n0+128.. ; B0, B1 = X columns) x 16 KB, each a
+//   [64 m][128 cols] image in the swizzle of the kernel above (wave wr reads only A[wr], wave wc only B[wc >> 1]).
+//   One contraction step = 4 phases of 16 MFMAs per wave (quadrants A-lo x B-lo, A-lo x B-hi, A-hi x B-hi, A-hi x B-lo
+//   of the wave tile); every phase also requests ONE half-tile:
+//     phase 1, 2: A0, A1 of step t+1 into the other buffer (its last reads were step t-1, behind the end barrier)
+//     phase 3, 4: B0, B1 of step t+2 into THIS buffer (all B reads of step t are over after phase 2: mid barrier)
+//   so 2-4 half-tiles are always in flight and each has at least two phases (32 MFMAs per wave) to land before the
+//   counted s_waitcnt vmcnt(4) + barrier at the end of the step that precedes its first read.
+// Split contraction (gridDim.y > 1): partial tiles go to `ws` in fragment order (1 KB per store instruction) and
+// gemm_tn256_reduce_kernel adds them in a fixed order: deterministic, no atomics (14 M strided fp32 atomics of a
+// split-2 layer cost more than the GEMM itself: probes/bench_tn_split.py).
+// ---------------------------------------------------------------------------------------------
+#define T2_HALF 16384
+#define T2_LDS_BYTES (8 * T2_HALF)
+__global__ __launch_bounds__(512) void gemm_tn256_kernel(GemmTNGroup g, float* ws, int total_tiles) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  int pi = 0;
+#pragma unroll
+  for (int i = 1; i < 8; ++i) if (i < g.count && tile >= g.p[i].tile_begin) pi = i;
+  const TNProblem p = g.p[pi];
+  int tnn, tkk;
+  tile_coords(tile - p.tile_begin, (p.N + 255) / 256, p.tiles_k, 4, tnn, tkk);
+  const int n0 = tnn * 256, k0 = tkk * 256;
+  const int steps = p.Mc / BK;                                     // host guarantees Mc % 64 == 0, steps >= gridDim.y
+  const int s_begin = (int)((long)steps * blockIdx.y / gridDim.y), s_end = (int)((long)steps * (blockIdx.y + 1) / gridDim.y);
+  const int nk = s_end - s_begin;
+
+  // per-thread global sources: half-tile h of A / B, chunk i (2 x 512 chunks of 16 B per half-tile)
+  const bf16_t* srcA[2][2]; const bf16_t* srcB[2][2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int q = i * 512 + tid, row = q >> 4, c = (q & 15) ^ (tn_f(row) << 1);
+      int ca = n0 + h * 128 + c * 8; ca = ca <= p.n_ld - 8 ? ca : p.n_ld - 8;
+      int cb = k0 + h * 128 + c * 8; cb = cb <= p.k_ld - 8 ? cb : p.k_ld - 8;
+      srcA[h][i] = p.A + ((size_t)s_begin * BK + row) * p.lda + ca;
+      srcB[h][i] = p.B + ((size_t)s_begin * BK + row) * p.ldb + cb;
+    }
+  const size_t stepA = (size_t)BK * p.lda, stepB = (size_t)BK * p.ldb;
+  auto issue = [&](int kt, auto slot) {                            // slot 0, 1: A halves; 2, 3: B halves
+    constexpr int S = decltype(slot)::value;
+    char* base = smem + ((kt & 1) * 4 + S) * T2_HALF + wave * 1024;
+    if constexpr (S < 2) {
+      glds16(srcA[S][0] + kt * stepA, base);
+      glds16(srcA[S][1] + kt * stepA, base + 8192);
+    } else {
+      glds16(srcB[S - 2][0] + kt * stepB, base);
+      glds16(srcB[S - 2][1] + kt * stepB, base + 8192);
+    }
+  };
+  using S0 = std::integral_constant<int, 0>; using S1 = std::integral_constant<int, 1>;
+  using S2 = std::integral_constant<int, 2>; using S3 = std::integral_constant<int, 3>;
+
+  f32x4 acc[4][8];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const uint32_t lds0 = lds_addr(smem);
+  const int fi = lane & 15, fg = lane >> 4, fr = fi >> 2, fc4 = fi & 3;
+  const int fsw = (fr | ((fg & 1) << 2)) << 1;
+  const uint32_t rowoff = (uint32_t)((fg * 8 + fr) * 256 + (fc4 & 1) * 8);
+  const uint32_t offA = (uint32_t)(wr * T2_HALF) + rowoff, offB = (uint32_t)((2 + (wc >> 1)) * T2_HALF) + rowoff;
+  bf16x8 fa[2][4], fb[2][4];                                       // [k-half of the step][tile]: one A half, all of B
+  // fragment reads are inline asm (x2_common.h: lds_read_tr_frag_async): explicit lgkmcnt waits below
+  auto readA = [&](uint32_t buf, int jh) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const uint32_t a0 = buf + offA + ks * 8192 + (uint32_t)(((2 * (jh * 4 + j) + (fc4 >> 1)) ^ fsw) << 4);
+        fa[ks][j] = lds_read_tr_frag_async(a0, a0 + 1024);
+      }
+  };
+  auto readB = [&](uint32_t buf, int ih) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const uint32_t a0 = buf + offB + ks * 8192 + (uint32_t)(((2 * ((wc & 1) * 4 + ih * 2 + i) + (fc4 >> 1)) ^ fsw) << 4);
+        fb[ks][ih * 2 + i] = lds_read_tr_frag_async(a0, a0 + 1024);
+      }
+  };
+  auto quad = [&](auto jh_, auto ih_) {                            // 16 MFMAs: A half jh (in fa) x B half ih
+    constexpr int jh = decltype(jh_)::value, ih = decltype(ih_)::value;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+          // D[row = k][col = n]: lane holds n = fi and 4 consecutive k
+          acc[ih * 2 + i][jh * 4 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[ks][ih * 2 + i], fa[ks][j], acc[ih * 2 + i][jh * 4 + j], 0, 0, 0);
+  };
+#define T2_FENCE() __builtin_amdgcn_sched_barrier(0)
+  auto ktile = [&](int kt, auto n1_, auto n2_) {                   // n1: step kt+1 exists, n2: step kt+2 exists
+    constexpr bool n1 = decltype(n1_)::value, n2 = decltype(n2_)::value;
+    const uint32_t buf = lds0 + (uint32_t)((kt & 1) * 4 * T2_HALF);
+    // phase 1: A-lo (16 reads), B-lo (8), B-hi (8) requested; the first quadrant starts when the first 24 are back
+    readA(buf, 0); readB(buf, 0); readB(buf, 1);
+    if constexpr (n1) issue(kt + 1, S0{});
+    asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory"); T2_FENCE();
+    quad(S0{}, S0{}); T2_FENCE();
+    // phase 2
+    if constexpr (n1) issue(kt + 1, S1{});
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); T2_FENCE();
+    quad(S0{}, S1{}); T2_FENCE();
+    // phase 3: every wave holds its B fragments of this step (lgkmcnt(0) above) before B0 / B1 of this buffer are refilled
+    if constexpr (n2) { asm volatile("s_barrier" ::: "memory"); issue(kt + 2, S2{}); }
+    readA(buf, 1);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); T2_FENCE();
+    quad(S1{}, S1{}); T2_FENCE();
+    // phase 4
+    if constexpr (n2) issue(kt + 2, S3{});
+    quad(S1{}, S0{}); T2_FENCE();
+    if constexpr (n1) {
+      // step kt+1 complete in LDS for this wave (only B0 / B1 of step kt+2 may still be in flight); then for all waves
+      if constexpr (n2) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+      T2_FENCE();
+    }
+  };
+  issue(0, S0{}); issue(0, S1{}); issue(0, S2{}); issue(0, S3{});
+  if (nk > 1) { issue(1, S2{}); issue(1, S3{}); asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory"); }
+  else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+  int kt = 0;
+  for (; kt + 2 < nk; ++kt) ktile(kt, std::true_type{}, std::true_type{});
+  if (kt + 1 < nk) { ktile(kt, std::true_type{}, std::false_type{}); ++kt; }
+  ktile(kt, std::false_type{}, std::false_type{});
+
+  if (gridDim.y > 1) {        // partial tile in fragment order: ws[split][tile][wave][i][j][lane] x float4
+    float* dst = ws + ((size_t)blockIdx.y * total_tiles + tile) * 65536 + (size_t)wave * 8192 + lane * 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        *reinterpret_cast<float4*>(dst + (i * 8 + j) * 256) = float4{acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+    return;
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int n = n0 + wr * 128 + j * 16 + fi;
+    if (n >= p.N) continue;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int k = k0 + wc * 64 + i * 16 + fg * 4;
+      if (k >= p.K) continue;
+      float* dst = p.C + (size_t)n * p.ldc + k;
+      float4 o = float4{acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+      if (g.accumulate) { const float4 c = *reinterpret_cast<float4*>(dst); o.x += c.x; o.y += c.y; o.z += c.z; o.w += c.w; }
+      *reinterpret_cast<float4*>(dst) = o;
+    }
+  }
+}
+// C (+)= sum over splits of the partial tiles above.  One thread = one float4 of one tile (64 workgroups per tile).
+__global__ __launch_bounds__(256) void gemm_tn256_reduce_kernel(GemmTNGroup g, const float* __restrict__ ws, int total_tiles, int split) {
+  const int tile = blockIdx.x >> 6;
+  int pi = 0;
+#pragma unroll
+  for (int i = 1; i < 8; ++i) if (i < g.count && tile >= g.p[i].tile_begin) pi = i;
+  const TNProblem p = g.p[pi];
+  int tnn, tkk;
+  tile_coords(tile - p.tile_begin, (p.N + 255) / 256, p.tiles_k, 4, tnn, tkk);
+  const int e = (blockIdx.x & 63) * 256 + threadIdx.x;             // float4 index inside the tile
+  const int lane = e & 63, ij = (e >> 6) & 31, wave = e >> 11;
+  const int i = ij >> 3, j = ij & 7, fi = lane & 15, fg = lane >> 4, wr = wave >> 2, wc = wave & 3;
+  const int n = tnn * 256 + wr * 128 + j * 16 + fi, k = tkk * 256 + wc * 64 + i * 16 + fg * 4;
+  const float* src = ws + (size_t)tile * 65536 + (size_t)e * 4;
+  float4 o = *reinterpret_cast<const float4*>(src);
+  for (int s_ = 1; s_ < split; ++s_) {
+    const float4 v = *reinterpret_cast<const float4*>(src + (size_t)s_ * total_tiles * 65536);
+    o.x += v.x; o.y += v.y; o.z += v.z; o.w += v.w;
+  }
+  if (n >= p.N || k >= p.K) return;
+  float* dst = p.C + (size_t)n * p.ldc + k;
+  if (g.accumulate) { const float4 c = *reinterpret_cast<float4*>(dst); o.x += c.x; o.y += c.y; o.z += c.z; o.w += c.w; }
+  *reinterpret_cast<float4*>(dst) = o;
+}
+
+// problems: `count` rows of 11 int64: {A, B, C, Mc, N, K, lda, ldb, ldc, n_ld, k_ld}.
+// split = 0: automatic.  ws / ws_floats: scratch for the split partial tiles of the 256x256 kernel (may be null: then
+// it never splits).  The 256x256 kernel is used when every contraction length is a multiple of 64; otherwise (ragged
+// Mc) the 128x128 kernel, where split > 1 adds atomically and needs accumulate = 1.
+extern "C" int x2_gemm_tn_grouped(const int64_t* problems, int count, int accumulate, int split, float* ws, long ws_floats,
+                                  void* stream) {
   X2_REQUIRE(count >= 1 && count <= 8, "x2_gemm_tn_grouped: count=%d not in [1,8]", count);
-  X2_REQUIRE(split >= 1, "x2_gemm_tn_grouped: split=%d", split);
-  X2_REQUIRE(split == 1 || accumulate, "x2_gemm_tn_grouped: split>1 adds atomically: pass accumulate=1 and a defined C");
+  X2_REQUIRE(split >= 0, "x2_gemm_tn_grouped: split=%d", split);
   GemmTNGroup g; g.count = count; g.accumulate = accumulate;
-  int tiles = 0;
+  int tiles = 0, tiles256 = 0, min_steps = 1 << 30;
+  bool big = g_tune[5] != 1;
   for (int i = 0; i < count; ++i) {
     const int64_t* q = problems + i * 11;
     TNProblem& p = g.p[i];
@@ -541,9 +736,37 @@ extern "C" int x2_gemm_tn_grouped(const int64_t* problems, int count, int accumu
     X2_REQUIRE(p.lda % 8 == 0 && p.ldb % 8 == 0 && p.n_ld % 8 == 0 && p.k_ld % 8 == 0 && p.n_ld >= 8 && p.k_ld >= 8,
                "x2_gemm_tn_grouped[%d]: rows must be 16-byte granular", i);
     X2_REQUIRE(p.n_ld <= p.lda && p.k_ld <= p.ldb, "x2_gemm_tn_grouped[%d]: n_ld/k_ld exceed leading dims", i);
-    p.tile_begin = tiles; p.tiles_k = (p.K + 127) / 128;
-    tiles += ((p.N + 127) / 128) * p.tiles_k;
+    tiles += ((p.N + 127) / 128) * ((p.K + 127) / 128);
+    tiles256 += ((p.N + 255) / 256) * ((p.K + 255) / 256);
+    if (p.Mc % BK != 0) big = false;
+    min_steps = p.Mc / BK < min_steps ? p.Mc / BK : min_steps;
   }
-  hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles, split), dim3(256), GEMM_LDS_BYTES, (hipStream_t)stream, g);
+  // small launches (a head's single weight) stay on the 128x128 kernel: more, smaller workgroups
+  if (g_tune[5] != 2 && tiles256 < 24) big = false;
+  if (big) {
+    int t = 0;
+    for (int i = 0; i < count; ++i) { g.p[i].tile_begin = t; g.p[i].tiles_k = (g.p[i].K + 255) / 256; t += ((g.p[i].N + 255) / 256) * g.p[i].tiles_k; }
+    int cus = 256;
+    int sp = split;
+    if (sp == 0) {              // fullest last round of one-workgroup-per-CU slots, fewest partial tiles on a tie
+      double best = -1.0; sp = 1;
+      for (int c = 1; c <= 4 && min_steps / c >= 16; ++c) {     // a slice shorter than 16 steps costs more in partial tiles than it fills
+        const long blocks = (long)t * c;
+        const double fill = (double)blocks / (double)(((blocks + cus - 1) / cus) * cus);
+        if (fill > best + 0.03) { best = fill; sp = c; }
+      }
+    }
+    while (sp > 1 && (sp > min_steps || !ws || (long)sp * t * 65536 > ws_floats)) --sp;
+    static bool attr = false;
+    if (!attr) { hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn256_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, T2_LDS_BYTES); attr = true; }
+    hipLaunchKernelGGL(gemm_tn256_kernel, dim3(t, sp), dim3(512), T2_LDS_BYTES, (hipStream_t)stream, g, ws, t);
+    if (sp > 1) hipLaunchKernelGGL(gemm_tn256_reduce_kernel, dim3(t * 64), dim3(256), 0, (hipStream_t)stream, g, ws, t, sp);
+    return x2_check_launch("x2_gemm_tn_grouped");
+  }
+  if (split == 0) split = 1;
+  X2_REQUIRE(split == 1 || accumulate, "x2_gemm_tn_grouped: split>1 on the 128x128 kernel adds atomically: pass accumulate=1 and a defined C");
+  int t = 0;
+  for (int i = 0; i < count; ++i) { g.p[i].tile_begin = t; g.p[i].tiles_k = (g.p[i].K + 127) / 128; t += ((g.p[i].N + 127) / 128) * g.p[i].tiles_k; }
+  hipLaunchKernelGGL(gemm_tn_kernel, dim3(t, split), dim3(256), GEMM_LDS_BYTES, (hipStream_t)stream, g);
   return x2_check_launch("x2_gemm_tn_grouped");
 }

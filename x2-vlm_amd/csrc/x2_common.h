@@ -106,6 +106,17 @@ __device__ __forceinline__ bf16x8 lds_read_tr_frag(uint32_t a0, uint32_t a1) {
   const bf16x4 lo = lds_read_tr64(a0), hi = lds_read_tr64(a1);
   return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
+// The same fragment read as inline asm.  hipcc treats the ds_read_tr builtin as touching unknown memory and puts an
+// s_waitcnt vmcnt(0) in front of it whenever a global->LDS copy is in flight, i.e. it drains the prefetch of the next
+// tile before every fragment read.  The asm form is invisible to that analysis: the CALLER orders it against the
+// LDS-DMA (counted vmcnt + barrier) and must issue `s_waitcnt lgkmcnt(N)` + __builtin_amdgcn_sched_barrier(0)
+// before the first use of the result (the compiler does not know the value is still in flight).
+__device__ __forceinline__ bf16x8 lds_read_tr_frag_async(uint32_t a0, uint32_t a1) {
+  bf16x4 lo, hi;
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(a0));
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(hi) : "v"(a1));
+  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
 __device__ __forceinline__ void lds_wait_all() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
 // async 16-byte global -> LDS copy; LDS destination = wave-uniform `lds_base` + lane*16

@@ -145,9 +145,12 @@ def gemm_nt(A, B, *, bias=None, gamma=None, resid=None, aux=None, act=0, out=Non
     return out
 
 
-def gemm_tn_grouped(problems, accumulate=False, split=1):
+def gemm_tn_grouped(problems, accumulate=False, split=0):
     """Weight gradients of one layer in one launch.  problems: list of (dY[Mc,N] bf16, X[Mc,K] bf16,
-    dW[N,K] fp32) or 5-tuples with (n_ld, k_ld) = readable row widths when they exceed N / K."""
+    dW[N,K] fp32) or 5-tuples with (n_ld, k_ld) = readable row widths when they exceed N / K.
+    split: slices of the contraction (0 = the library picks what fills the CUs; partial tiles go through the stream
+    workspace and are added deterministically; ragged contraction lengths use the 128x128 kernel, where split > 1 adds
+    atomically and needs accumulate=True)."""
     rows = []
     for pr in problems:
         dY, X, dW = pr[:3]
@@ -157,11 +160,15 @@ def gemm_tn_grouped(problems, accumulate=False, split=1):
         assert dY.shape[1] >= N or n_ld >= N
         rows.append([dY.data_ptr(), X.data_ptr(), dW.data_ptr(), dY.shape[0], N, K, _rows(dY), _rows(X), _rows(dW),
                      n_ld, k_ld])
+    dev = problems[0][0].device
     for i in range(0, len(rows), 8):
         chunk = rows[i:i + 8]
         arr = (C.c_int64 * (11 * len(chunk)))(*[v for r in chunk for v in r])
+        tiles256 = sum(((r[4] + 255) // 256) * ((r[5] + 255) // 256) for r in chunk)
+        want = (split if split else 4) * tiles256 * 65536
+        ws = workspace(dev, want) if (split != 1 and all(r[3] % 64 == 0 for r in chunk)) else None
         with _timed(sum(2.0 * r[3] * r[4] * r[5] for r in chunk), "gemm_tn"):
-            call("x2_gemm_tn_grouped", arr, len(chunk), 1 if accumulate else 0, split)
+            call("x2_gemm_tn_grouped", arr, len(chunk), 1 if accumulate else 0, split, ptr(ws), 0 if ws is None else ws.numel())
 
 
 # ----------------------------------------------------------------------------- attention
