@@ -26,7 +26,8 @@ def timeit(fn, iters=20):
 NT = [("fc1 fwd", 12608, 3072, 768, "gelu"), ("fc2 fwd", 12608, 768, 3072, "resid"), ("qkv fwd", 12608, 2304, 768, "bias"),
       ("proj fwd", 12608, 768, 768, "resid"), ("dqkv dgrad", 12608, 768, 2304, "f32"), ("text qkv", 3840, 2304, 768, "bias"),
       ("text ffn2", 3840, 768, 3072, "resid"), ("fus ffn1", 7680, 3072, 768, "gelu"), ("fus out", 7680, 768, 768, "resid"),
-      ("cross kv", 12608, 1536, 768, "bias"), ("mlm dec", 768, 30528, 768, "f32")]
+      ("cross kv", 12608, 1536, 768, "bias"), ("mlm dec", 768, 30528, 768, "f32"),
+      ("text out", 3840, 768, 768, "resid"), ("fus ffn2", 7680, 768, 3072, "resid"), ("text dqkv", 3840, 768, 2304, "f32")]
 
 
 def nt_case(M, N, Kd, epi):
@@ -43,8 +44,8 @@ def nt_case(M, N, Kd, epi):
 
 
 def main():
-    knobs = [int(x) for x in (sys.argv[1].split(",") if len(sys.argv) > 1 else ["1", "2"])]
-    print("NT GEMM, knob3 (1 = 128x128 tile, 2 = 192x128 tile; both 4 waves, 2 workgroups / CU) in", knobs)
+    knobs = [int(x) for x in (sys.argv[1].split(",") if len(sys.argv) > 1 else ["1", "2", "3"])]
+    print("NT GEMM, knob3 (1 = 128x128 tile, 2 = 192x128, 3 = 64x128; all 4 waves, 2-3 workgroups / CU) in", knobs)
     lib.x2_tune(1, 1)
     for name, M, N, Kd, epi in NT:
         fn = nt_case(M, N, Kd, epi)

@@ -37,7 +37,7 @@ def relerr(got, ref):
     return float((got - ref).abs().max() / ref.abs().max().clamp_min(1e-12))
 
 
-@pytest.fixture(params=[(1, 1), (1, 2), (2, 0)], ids=["tile128x128", "tile192x128", "tile256x128w8"])
+@pytest.fixture(params=[(1, 1), (1, 2), (2, 0), (1, 3)], ids=["tile128x128", "tile192x128", "tile256x128w8", "tile64x128"])
 def nt_tile(request):
     lib = importlib.import_module("x2-vlm_amd._lib").lib()
     lib.x2_tune(1, request.param[0])

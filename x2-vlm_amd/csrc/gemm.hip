@@ -372,10 +372,19 @@ extern "C" int x2_gemm_nt(const void* A, const void* B, void* C, int M, int N, i
     hipLaunchKernelGGL(gemm_nt_w8_kernel, dim3(tiles8), dim3(512), W8_LDS_BYTES, (hipStream_t)stream, p);
   } else {
     // 192x128 tiles when that gives a single resident round (<= 2 workgroups per CU) where 128x128 needs a second,
-    // nearly empty one: the N = 768 outputs of this model (66 x 6 = 396 tiles vs 99 x 6 = 594 on 512 slots)
+    // nearly empty one: the N = 768 outputs of this model (66 x 6 = 396 tiles vs 99 x 6 = 594 on 512 slots).
+    // 64x128 tiles when 128x128 would leave CUs with a single (or no) workgroup: the text / fusion rows (M = 3840, 7680)
+    // times N = 768 give 180 / 360 tiles, each a serial chain of K/64 load->wait->multiply steps with nothing else on the
+    // CU to hide the load latency; half-height tiles double the chains in flight (3 fit a CU: 48 KB LDS each).
     const int t128 = ((M + 127) / 128) * ((N + BN - 1) / BN), t192 = ((M + 191) / 192) * ((N + BN - 1) / BN);
-    const bool use192 = g_tune[3] == 2 || (g_tune[3] == 0 && t128 > 512 && t192 <= 512);
-    if (use192) {
+    const int t64 = ((M + 63) / 64) * ((N + BN - 1) / BN);
+    // measured (probes/bench_gemm.py): 64x128 wins up to ~1.2 workgroups of 128x128 per CU slot pair, except on long
+    // contractions with exactly one 192x128 round (fc2, dqkv: 757 / 817 TFLOP/s on 192x128)
+    const bool use64 = g_tune[3] == 3 || (g_tune[3] == 0 && (t128 <= 512 || (t128 <= 600 && K <= 1024)));
+    const bool use192 = !use64 && (g_tune[3] == 2 || (g_tune[3] == 0 && t128 > 512 && t192 <= 512));
+    if (use64) {
+      hipLaunchKernelGGL(gemm_nt_kernel<2>, dim3(t64), dim3(256), 2 * (64 * 128 + TILE_BYTES), (hipStream_t)stream, p);
+    } else if (use192) {
       static bool attr192 = false;
       if (!attr192) { hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<6>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (192 * 128 + TILE_BYTES)); attr192 = true; }
       hipLaunchKernelGGL(gemm_nt_kernel<6>, dim3(t192), dim3(256), 2 * (192 * 128 + TILE_BYTES), (hipStream_t)stream, p);
