@@ -27,6 +27,20 @@ F_MIN_GFLOP = 183.5      # fwd+bwd FLOPs per pair actually executed (K/V de-dupl
 PEAK_TFLOPS = 2500.0     # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
 
 
+def _pmc_traffic():
+    """HBM traffic of the dominant kernel, measured offline with PMC counters (cannot be collected from inside the
+    process): profiles/pmc_traffic.json is written from the rocprofv3 --pmc summaries committed next to it."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return {}
+
+
+PMC_TRAFFIC = _pmc_traffic()
+
+
 def synthetic_batch(rank, B, L, res, vocab=30522, masks=12):
     """per-rank generator seed 1234+rank."""
     g = torch.Generator().manual_seed(1234 + rank)
@@ -190,7 +204,10 @@ def main():
         ach = fl / (ms * 1e-3) / 1e12
         tn_ms, tn_fl, tn_n = stat.get("gemm_tn", (0.0, 0.0, 0))
         roof = {"bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(ach / PEAK_TFLOPS, 4), "traffic": None,
+                "frac": round(ach / PEAK_TFLOPS, 4), "traffic": PMC_TRAFFIC.get("hbm_bytes_per_launch"),
+                "traffic_note": ("HBM bytes per launch (fetch + write) of this kernel from separate rocprofv3 --pmc passes, "
+                                 "corrected per MI355X_MICROARCH.md; summaries: " + ", ".join(PMC_TRAFFIC.get("files", [])))
+                                if PMC_TRAFFIC else "no PMC pass committed",
                 "kernel": "gemm_nt_kernel (forward linears + input gradients)", "launches_per_step": n // args.steps,
                 "avg_launch_us": round(1e3 * ms / n, 1), "gflop_per_launch": round(fl / n / 1e9, 2),
                 "nt_gemm_ms_per_step": round(ms / args.steps, 2),
