@@ -304,6 +304,30 @@ def cross_embeds(sd, cfg, image_embeds, image_atts, text_atts, text_embeds=None,
     return bert_encoder(sd, cfg, text_embeddings(sd, cfg, text_ids), text_atts, image_embeds, image_atts)
 
 
+# --------------------------------------------------------------------------- retrieval re-ranking
+
+def rerank_scores(sd, cfg, image_feats, image_embeds, text_feats, text_atts, text_embeds, k_test):
+    """Retrieval.py:113-160 on one rank, one query at a time as the reference does: for every image the k_test texts
+    with the highest ITC similarity are re-scored by a fusion pass + itm_head (logit of class 1), and symmetrically for
+    every text; all other entries stay at -100."""
+    sims = image_embeds @ text_embeds.t()
+    score_i2t = torch.full((image_feats.shape[0], text_feats.shape[0]), -100.0)
+    for i in range(sims.shape[0]):
+        idx = sims[i].topk(k=k_test, dim=0).indices
+        enc = image_feats[i].repeat(k_test, 1, 1)
+        out = cross_embeds(sd, cfg, enc, torch.ones(enc.shape[:2], dtype=torch.long), text_atts[idx], text_embeds=text_feats[idx])
+        score_i2t[i, idx] = head_mlp(sd, "itm_head", out[:, 0])[:, 1]
+    score_t2i = torch.full((text_feats.shape[0], image_feats.shape[0]), -100.0)
+    sims_t = sims.t()
+    for i in range(sims_t.shape[0]):
+        idx = sims_t[i].topk(k=k_test, dim=0).indices
+        enc = image_feats[idx]
+        out = cross_embeds(sd, cfg, enc, torch.ones(enc.shape[:2], dtype=torch.long), text_atts[i].repeat(k_test, 1),
+                           text_embeds=text_feats[i].repeat(k_test, 1, 1))
+        score_t2i[i, idx] = head_mlp(sd, "itm_head", out[:, 0])[:, 1]
+    return score_i2t, score_t2i
+
+
 # --------------------------------------------------------------------------- heads and losses
 
 def head_mlp(sd, name, x):

@@ -85,6 +85,7 @@ class VisionTransformer(nn.Module):
             depth = vision_num_hidden_layers
         self.depth, self.embed_dim, self.num_heads, self.eps = depth, embed_dim, num_heads, eps
         self.num_features = embed_dim
+        self.use_rel_pos_bias, self.pos_embed = True, None        # per-block tables, no absolute embedding (checkpoint.py reads these)
         self.patch_embed = PatchEmbed(img_size, patch_size, 3, embed_dim)
         self.cls_token = nn.Parameter(torch.zeros(1, 1, embed_dim))
         dpr = [x.item() for x in torch.linspace(0, drop_path_rate, depth)]

@@ -9,7 +9,7 @@ import torch
 import torch.distributed as dist
 import torch.nn as nn
 
-from . import box_ops, ops
+from . import box_ops, checkpoint, ops
 from . import kernels as K
 from .beit2 import beit_base_patch16, beit_large_patch16, read_json, trunc_normal_
 from .xbert import BertForMaskedLM, BertModel, get_bert_config
@@ -57,7 +57,7 @@ def build_vision_encoder(config, load_params=False):
     enc = fn(img_size=config["image_res"], drop_path_rate=config.get("drop_path_rate", 0.1), init_values=0.1,
              vision_num_hidden_layers=config.get("vision_num_hidden_layers", -1))
     if load_params:
-        raise NotImplementedError("checkpoint loading / rel-pos interpolation (beit2.py:473-601) is a 'next' row")
+        checkpoint.load_pretrained_beit2(enc, vc["ckpt"])          # xvlm.py:264-266
     enc.vision_width = vc["vision_width"]
     return enc
 
@@ -69,10 +69,9 @@ def build_text_encoder(config, vision_width, load_text_params=False, use_mlm_los
                                       cross_start_at=config["text_fusion_start_at"])
     config_text.hidden_dropout_prob = config.get("dropout", config_text.hidden_dropout_prob)
     config_text.encoder_width = vision_width
-    if load_text_params:
-        raise NotImplementedError("initialising from pytorch_model.bin (xvlm.py:318-385) is a 'next' row")
     enc = BertForMaskedLM(config_text) if use_mlm_loss else BertModel(config_text)
-    return enc, []
+    missing = checkpoint.load_text_params(enc, config, config_text, use_mlm_loss) if load_text_params else []
+    return enc, missing
 
 
 class XVLMBase(nn.Module):
@@ -84,6 +83,7 @@ class XVLMBase(nn.Module):
         self.vision_encoder = build_vision_encoder(config, load_params=load_vision_params)
         self.vision_width = self.vision_encoder.vision_width
         self.text_encoder, missing = build_text_encoder(config, self.vision_width, load_text_params, use_mlm_loss, config_text)
+        self.update_init_params(["text_encoder.%s" % k for k in missing])          # xvlm.py:477
         tc = self.text_encoder.config
         self.vocab_size, self.num_text_layers, self.text_width = tc.vocab_size, tc.fusion_layer, tc.hidden_size
         self.num_cross_layers, self.cross_width = tc.num_hidden_layers - tc.fusion_layer, tc.hidden_size
@@ -129,12 +129,27 @@ class XVLMBase(nn.Module):
         self.init_params = [n for n in self.init_params if n in named]
 
     def load_pretrained(self, ckpt_rpath, config, is_eval=False, is_domain_pretrain=False):
-        """xvlm.py:579-613 for checkpoints at the model's own resolution (same key names); the
-        resolution-changing rel-pos interpolation is a 'next' row."""
-        ck = torch.load(ckpt_rpath, map_location="cpu")
-        sd = ck["model"] if "model" in ck else ck
-        msg = self.load_state_dict(sd, strict=False)
-        self.update_init_params(list(msg.missing_keys))
+        """xvlm.py:579-613: load an X2-VLM checkpoint (vision tables resampled to this model's resolution unless
+        is_eval / is_domain_pretrain); parameters the checkpoint lacks join init_params (lr * lr_mult group)."""
+        print("load checkpoint from %s" % ckpt_rpath)
+        if is_domain_pretrain:
+            ck = torch.load(ckpt_rpath, map_location="cpu")
+            state_dict = ck["model"] if "model" in ck.keys() else ck
+            if config.get("init_timesformer", False):
+                checkpoint.init_timesformer_keys(state_dict)
+        else:
+            state_dict = checkpoint.load_pretrained(self, ckpt_rpath, config, is_eval=is_eval, load_text=True)
+        if hasattr(self, "absolute_frame_pos_embed") and ("absolute_frame_pos_embed" in state_dict.keys()):
+            pretrained = state_dict["absolute_frame_pos_embed"]
+            if pretrained.shape != self.absolute_frame_pos_embed.shape:
+                frame_len = min(pretrained.shape[1], self.absolute_frame_pos_embed.shape[1])
+                self.absolute_frame_pos_embed.data[:, :frame_len, :, :] = pretrained.data[:, :frame_len, :, :]
+                print(f"load absolute_frame_pos_embed[:{frame_len}] ({pretrained.shape[1]}/{self.absolute_frame_pos_embed.shape[1]})", flush=True)
+                del state_dict["absolute_frame_pos_embed"]
+        msg = self.load_state_dict(state_dict, strict=False)
+        print("unexpected_keys: ", msg.unexpected_keys)
+        self.update_init_params([p for p in msg.missing_keys])
+        print("train from scratch: ", sorted(self.init_params))
         return msg
 
     # ------------------------------------------------------------------ encoders
