@@ -11,6 +11,7 @@
 // Backward = two kernels (no atomics, deterministic): dQ (+ the dS stream the bias gradient is
 // reduced from) and dK/dV.
 #include "x2_common.h"
+#include <cstdlib>
 
 #define HD 64                 // head dim
 #define KT 64                 // keys (or queries) per LDS tile
@@ -494,6 +495,14 @@ __global__ __launch_bounds__(64 * KW) void attn_bwd_dkv_kernel(AttnArgs a) {
 // ------------------------------------------------------------------------------------------ C ABI
 // `args` is the AttnArgs struct laid out as 8-byte slots (pointers, longs) followed by ints/floats;
 // the Python side fills it through ctypes.Structure with the same field order.
+// experiment switch (probes/bench_attn.py): X2_ATTN_VARIANT bit 0: dkv back to 4 waves per workgroup,
+// bit 1: dq with 2 query groups per wave, bit 2: fwd with 2 query groups per wave
+static int attn_variant() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("X2_ATTN_VARIANT"); v = e ? atoi(e) : 0; }
+  return v;
+}
+
 static int check_common(const AttnArgs& a, const char* who) {
   X2_REQUIRE(a.B > 0 && a.H > 0 && a.Lq > 0 && a.Lk > 0, "%s: empty problem", who);
   X2_REQUIRE(!a.bias || (a.bias_ld % 64 == 0 && a.bias_ld >= a.Lk), "%s: bias_ld must be a multiple of 64 covering Lk", who);
@@ -512,6 +521,7 @@ extern "C" int x2_attn_fwd(const AttnArgs* pa, void* stream) {
   // streamed through a double buffer (short query side: the 64 KB would leave 2 waves / workgroup alone on a CU)
   if (a.Lq <= 32) hipLaunchKernelGGL((attn_fwd_kernel<2, 1, false>), dim3(1, a.H, a.B), dim3(128), 0, st, a);
   else if (a.Lq <= 64 || a.Lk > 256) hipLaunchKernelGGL((attn_fwd_kernel<4, 1, false>), dim3((a.Lq + 63) / 64, a.H, a.B), dim3(256), 0, st, a);
+  else if (attn_variant() & 4) hipLaunchKernelGGL((attn_fwd_kernel<4, 2, true>), dim3((a.Lq + 127) / 128, a.H, a.B), dim3(256), 0, st, a);
   else hipLaunchKernelGGL((attn_fwd_kernel<8, 1, true>), dim3((a.Lq + 127) / 128, a.H, a.B), dim3(512), 0, st, a);
   return x2_check_launch("x2_attn_fwd");
 }
@@ -527,11 +537,16 @@ extern "C" int x2_attn_bwd(const AttnArgs* pa, void* stream) {
   const hipStream_t st = (hipStream_t)stream;
   if (a.Lq <= 32) hipLaunchKernelGGL((attn_bwd_dq_kernel<2, 1, false>), dim3(1, a.H, a.B), dim3(128), 0, st, a);
   else if (a.Lq <= 64 || a.Lk > 256) hipLaunchKernelGGL((attn_bwd_dq_kernel<4, 1, false>), dim3((a.Lq + 63) / 64, a.H, a.B), dim3(256), 0, st, a);
+  else if (attn_variant() & 2) hipLaunchKernelGGL((attn_bwd_dq_kernel<4, 2, true>), dim3((a.Lq + 127) / 128, a.H, a.B), dim3(256), 0, st, a);
   else hipLaunchKernelGGL((attn_bwd_dq_kernel<8, 1, true>), dim3((a.Lq + 127) / 128, a.H, a.B), dim3(512), 0, st, a);
   if (int e = x2_check_launch("x2_attn_bwd(dq)")) return e;
   const bool res = !a.seq_off && a.Lq > 64 && a.Lq <= 256;   // one sequence per K/V batch, 2..4 query tiles: resident Q/dO
   if (a.Lk <= 32) {
     hipLaunchKernelGGL((attn_bwd_dkv_kernel<2, 1, false>), dim3(1, a.H, a.Bkv), dim3(128), 0, st, a);
+  } else if (res && !(attn_variant() & 1)) {
+    // 8 waves (128 keys) share the resident Q / dO image (133 KB: one workgroup per CU either way): 206 -> 189 us per
+    // vision layer against 4-wave workgroups, which left 4 waves on a CU (probes/bench_attn.py)
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<8, 1, true>), dim3((a.Lk + 127) / 128, a.H, a.Bkv), dim3(512), 0, st, a);
   } else if (res) {
     hipLaunchKernelGGL((attn_bwd_dkv_kernel<4, 1, true>), dim3((a.Lk + 63) / 64, a.H, a.Bkv), dim3(256), 0, st, a);
   } else {
