@@ -95,6 +95,39 @@ __device__ __forceinline__ f32x4 add_bias_mask(f32x4 s, const AttnArgs& a, int h
   return o;
 }
 
+// the same with the bias / mask values already in registers (loaded at the top of the key tile, so that their L2
+// latency is covered by the QK^T MFMAs instead of sitting between them and the softmax)
+__device__ __forceinline__ f32x4 apply_bias_mask(f32x4 s, float4 bb, float4 mm, int key0, int Lk, float sc2) {
+  f32x4 o;
+  o[0] = key0 + 0 < Lk ? s[0] * sc2 + (bb.x + mm.x) * LOG2E : NEG_BIG;
+  o[1] = key0 + 1 < Lk ? s[1] * sc2 + (bb.y + mm.y) * LOG2E : NEG_BIG;
+  o[2] = key0 + 2 < Lk ? s[2] * sc2 + (bb.z + mm.z) * LOG2E : NEG_BIG;
+  o[3] = key0 + 3 < Lk ? s[3] * sc2 + (bb.w + mm.w) * LOG2E : NEG_BIG;
+  return o;
+}
+template <int QG>
+__device__ __forceinline__ void load_bias_mask(const AttnArgs& a, int h, int b, const int (&q)[QG], int key_base, int g, int nsub,
+                                               float4 (&bb)[QG][4], float4 (&mm)[4]) {
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) {
+    mm[nt] = float4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int gq = 0; gq < QG; ++gq) bb[gq][nt] = float4{0.f, 0.f, 0.f, 0.f};
+  }
+  if (a.bias && !(a.dbg & 1)) {
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int gq = 0; gq < QG; ++gq)
+        if (nt < nsub) bb[gq][nt] = *reinterpret_cast<const float4*>(a.bias + ((long)h * a.Lq + q[gq]) * a.bias_ld + key_base + nt * 16 + g * 4);
+  }
+  if (a.mask && !(a.dbg & 1)) {
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+      if (nt < nsub) mm[nt] = *reinterpret_cast<const float4*>(a.mask + (long)b * a.mask_ld + key_base + nt * 16 + g * 4);
+  }
+}
+
 // ------------------------------------------------------------------------------------------ forward
 // QW waves per workgroup, QG groups of 16 queries per wave (K / V^T fragments read from LDS once serve QG MFMAs).
 // RES: all K / V tiles of the (batch, head) are resident in LDS (Lk <= 256): one load phase and one barrier per
@@ -131,12 +164,15 @@ __global__ __launch_bounds__(64 * QW) void attn_fwd_kernel(AttnArgs a) {
   const int nkt = (a.Lk + KT - 1) / KT;
   TileRegs<NT> rk, rv;
   if (RES) {
-    for (int kt = 0; kt < nkt; ++kt) {
-      tile_load<NT>(rk, Kp, a.k_rs, kt * KT, a.Lk, tid);
-      tile_load<NT>(rv, Vp, a.v_rs, kt * KT, a.Lk, tid);
-      tile_store<NT>(rk, smem[kt], tid);
-      tile_store<NT>(rv, smem[kt] + KT * 128, tid);
-    }
+    // all (<= 4) key tiles are requested before the first one is written to LDS: one exposed HBM/L2 latency per
+    // workgroup instead of one per tile
+    TileRegs<NT> rka[4], rva[4];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+      if (kt < nkt) { tile_load<NT>(rka[kt], Kp, a.k_rs, kt * KT, a.Lk, tid); tile_load<NT>(rva[kt], Vp, a.v_rs, kt * KT, a.Lk, tid); }
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+      if (kt < nkt) { tile_store<NT>(rka[kt], smem[kt], tid); tile_store<NT>(rva[kt], smem[kt] + KT * 128, tid); }
   } else {
     tile_load<NT>(rk, Kp, a.k_rs, 0, a.Lk, tid);
     tile_load<NT>(rv, Vp, a.v_rs, 0, a.Lk, tid);
@@ -144,12 +180,19 @@ __global__ __launch_bounds__(64 * QW) void attn_fwd_kernel(AttnArgs a) {
     tile_store<NT>(rv, smem[0] + KT * 128, tid);
   }
   __syncthreads();
+  // N = 197 is 12.3 sixteen-row MFMA tiles, not 16: a wave whose 16*QG queries all lie past Lq has nothing to do (no
+  // barrier follows in the resident form), and 16-key sub-tiles past Lk are skipped instead of multiplied and masked
+  const bool idle = (blockIdx.x * QW * QG + wave * QG) * 16 >= a.Lq;
+  if (RES && idle) return;
   for (int kt = 0; kt < nkt; ++kt) {
     const uint32_t ktile = lds_addr(smem[RES ? kt : (kt & 1)]), vtile = ktile + KT * 128;
     if (!RES && kt + 1 < nkt) {             // next tile's HBM loads fly under this tile's MFMAs
       tile_load<NT>(rk, Kp, a.k_rs, (kt + 1) * KT, a.Lk, tid);
       tile_load<NT>(rv, Vp, a.v_rs, (kt + 1) * KT, a.Lk, tid);
     }
+    const int nsub = idle ? 0 : min(4, (a.Lk - kt * KT + 15) >> 4);      // valid 16-key sub-tiles of this tile (wave-uniform)
+    float4 bbv[QG][4], mmv[4];
+    load_bias_mask<QG>(a, h, b, q, kt * KT, g, nsub, bbv, mmv);
     f32x4 st[QG][4];
 #pragma unroll
     for (int gq = 0; gq < QG; ++gq)
@@ -159,7 +202,7 @@ __global__ __launch_bounds__(64 * QW) void attn_fwd_kernel(AttnArgs a) {
     for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
-        if (a.dbg & 8) continue;
+        if ((a.dbg & 8) || nt >= nsub) continue;
         const bf16x8 kfr = frag_rows(ktile, nt * 16 + fi, ks * 4 + g);
 #pragma unroll
         for (int gq = 0; gq < QG; ++gq) st[gq][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr, qf[gq][ks], st[gq][nt], 0, 0, 0);
@@ -170,7 +213,8 @@ __global__ __launch_bounds__(64 * QW) void attn_fwd_kernel(AttnArgs a) {
       float mx = NEG_BIG;
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) {
-        st[gq][nt] = add_bias_mask(st[gq][nt], a, h, b, q[gq], kt * KT + nt * 16 + g * 4, sc2);
+        if (nt >= nsub) continue;
+        st[gq][nt] = apply_bias_mask(st[gq][nt], bbv[gq][nt], mmv[nt], kt * KT + nt * 16 + g * 4, a.Lk, sc2);
         mx = fmaxf(fmaxf(mx, fmaxf(st[gq][nt][0], st[gq][nt][1])), fmaxf(st[gq][nt][2], st[gq][nt][3]));
       }
       mx = group_max(mx);
@@ -178,15 +222,18 @@ __global__ __launch_bounds__(64 * QW) void attn_fwd_kernel(AttnArgs a) {
       const float alpha = exp2f(m_i[gq] - m_new);
       float rs = 0.f;
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt)
+      for (int nt = 0; nt < 4; ++nt) {
+        if (nt >= nsub) continue;           // skipped sub-tiles keep P = 0 (st was zero-initialised)
 #pragma unroll
         for (int r = 0; r < 4; ++r) { st[gq][nt][r] = (a.dbg & 2) ? (st[gq][nt][r] - m_new) * 0.001f : exp2f(st[gq][nt][r] - m_new); rs += st[gq][nt][r]; }
+      }
       l_i[gq] = l_i[gq] * alpha + group_sum(rs);
       m_i[gq] = m_new;
       if (a.drop.thr16) {      // normalisation uses the undropped sum; only the P that multiplies V is dropped
         const uint32_t e0 = (uint32_t)(((long)b * a.H + h) * a.Lq + q[gq]) * (uint32_t)lkp + (uint32_t)(kt * KT + g * 4);
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
+          if (nt >= nsub) continue;
           float dm[4];
           drop_mul4(a.drop, e0 + nt * 16, dm);
           st[gq][nt][0] *= dm[0]; st[gq][nt][1] *= dm[1]; st[gq][nt][2] *= dm[2]; st[gq][nt][3] *= dm[3];
@@ -201,7 +248,7 @@ __global__ __launch_bounds__(64 * QW) void attn_fwd_kernel(AttnArgs a) {
     for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
-        if (a.dbg & 4) continue;
+        if ((a.dbg & 4) || 2 * s2 >= nsub) continue;
         const bf16x8 vfr = frag_cols(vtile, s2, dt, lane);
 #pragma unroll
         for (int gq = 0; gq < QG; ++gq) o[gq][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfr, pf[gq][s2], o[gq][dt], 0, 0, 0);
@@ -267,12 +314,15 @@ __global__ __launch_bounds__(64 * QW) void attn_bwd_dq_kernel(AttnArgs a) {
   const int nkt = (a.Lk + KT - 1) / KT;
   TileRegs<NT> rk, rv;
   if (RES) {
-    for (int kt = 0; kt < nkt; ++kt) {
-      tile_load<NT>(rk, Kp, a.k_rs, kt * KT, a.Lk, tid);
-      tile_load<NT>(rv, Vp, a.v_rs, kt * KT, a.Lk, tid);
-      tile_store<NT>(rk, smem[kt], tid);
-      tile_store<NT>(rv, smem[kt] + KT * 128, tid);
-    }
+    // all (<= 4) key tiles are requested before the first one is written to LDS: one exposed HBM/L2 latency per
+    // workgroup instead of one per tile
+    TileRegs<NT> rka[4], rva[4];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+      if (kt < nkt) { tile_load<NT>(rka[kt], Kp, a.k_rs, kt * KT, a.Lk, tid); tile_load<NT>(rva[kt], Vp, a.v_rs, kt * KT, a.Lk, tid); }
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+      if (kt < nkt) { tile_store<NT>(rka[kt], smem[kt], tid); tile_store<NT>(rva[kt], smem[kt] + KT * 128, tid); }
   } else {
     tile_load<NT>(rk, Kp, a.k_rs, 0, a.Lk, tid);
     tile_load<NT>(rv, Vp, a.v_rs, 0, a.Lk, tid);
@@ -280,15 +330,25 @@ __global__ __launch_bounds__(64 * QW) void attn_bwd_dq_kernel(AttnArgs a) {
     tile_store<NT>(rv, smem[0] + KT * 128, tid);
   }
   __syncthreads();
+  const bool idle = (blockIdx.x * QW * QG + wave * QG) * 16 >= a.Lq;       // see attn_fwd_kernel
+  if (RES && idle) return;
   for (int kt = 0; kt < nkt; ++kt) {
     const uint32_t ktile = lds_addr(smem[RES ? kt : (kt & 1)]), vtile = ktile + KT * 128;
     if (!RES && kt + 1 < nkt) {
       tile_load<NT>(rk, Kp, a.k_rs, (kt + 1) * KT, a.Lk, tid);
       tile_load<NT>(rv, Vp, a.v_rs, (kt + 1) * KT, a.Lk, tid);
     }
+    const int nsub = idle ? 0 : min(4, (a.Lk - kt * KT + 15) >> 4);
+    float4 bbv[QG][4], mmv[4];
+    load_bias_mask<QG>(a, h, b, q, kt * KT, g, nsub, bbv, mmv);
     f32x4 ds[QG][4];
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
+      if (nt >= nsub) {
+#pragma unroll
+        for (int gq = 0; gq < QG; ++gq) ds[gq][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        continue;
+      }
       f32x4 s[QG], dp[QG];
 #pragma unroll
       for (int gq = 0; gq < QG; ++gq) { s[gq] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[gq] = f32x4{0.f, 0.f, 0.f, 0.f}; }
@@ -304,7 +364,7 @@ __global__ __launch_bounds__(64 * QW) void attn_bwd_dq_kernel(AttnArgs a) {
       const int key0 = kt * KT + nt * 16 + g * 4;
 #pragma unroll
       for (int gq = 0; gq < QG; ++gq) {
-        s[gq] = add_bias_mask(s[gq], a, h, b, q[gq], key0, sc2);
+        s[gq] = apply_bias_mask(s[gq], bbv[gq][nt], mmv[nt], key0, a.Lk, sc2);
         if (a.drop.thr16) {
           float dm[4];
           drop_mul4(a.drop, (uint32_t)(((long)b * a.H + h) * a.Lq + q[gq]) * (uint32_t)lkp + (uint32_t)key0, dm);
@@ -324,6 +384,7 @@ __global__ __launch_bounds__(64 * QW) void attn_bwd_dq_kernel(AttnArgs a) {
       for (int gq = 0; gq < QG; ++gq) dsf[gq] = pack8(ds[gq][2 * s2], ds[gq][2 * s2 + 1]);
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
+        if (2 * s2 >= nsub) continue;
         const bf16x8 ktr = frag_cols(ktile, s2, dt, lane);
 #pragma unroll
         for (int gq = 0; gq < QG; ++gq) dq[gq][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktr, dsf[gq], dq[gq][dt], 0, 0, 0);
@@ -403,14 +464,25 @@ __global__ __launch_bounds__(64 * KW) void attn_bwd_dkv_kernel(AttnArgs a) {
       }
     };
     if (RES) {
-      for (int it = 0; it < nit; ++it) { fetch(it); commit(it); }
+      // (<= 4 query tiles) all requested before the first LDS write, as in the forward kernel
+      TileRegs<NT> rqa[4], rdoa[4];
+      float rla[4], rda[4];
+#pragma unroll
+      for (int it = 0; it < 4; ++it)
+        if (it < nit) { fetch(it); rqa[it] = rq; rdoa[it] = rdo; rla[it] = rl; rda[it] = rd; }
+#pragma unroll
+      for (int it = 0; it < 4; ++it)
+        if (it < nit) { rq = rqa[it]; rdo = rdoa[it]; rl = rla[it]; rd = rda[it]; commit(it); }
     } else {
       fetch(0);
       commit(0);
     }
     __syncthreads();
+    const bool idle = (blockIdx.x * KW * KG + wave * KG) * 16 >= a.Lk;      // all keys of this wave are padding
+    if (RES && idle) return;
     for (int it = 0; it < nit; ++it) {
       const int si = sb + it / nqt, qt = it % nqt;
+      const int nsub = idle ? 0 : min(4, (a.Lq - qt * KT + 15) >> 4);      // valid 16-query sub-tiles of this tile
       const int b = a.seq_ids ? a.seq_ids[si] : si;
       char* buf = smem[RES ? it : (it & 1)];
       const uint32_t qtile = lds_addr(buf), dotile = qtile + KT * 128;
@@ -420,9 +492,26 @@ __global__ __launch_bounds__(64 * KW) void attn_bwd_dkv_kernel(AttnArgs a) {
       float mk[KG];
 #pragma unroll
       for (int gk = 0; gk < KG; ++gk) mk[gk] = (a.mask ? a.mask[(long)b * a.mask_ld + key[gk]] : 0.f) * LOG2E;
+      float4 btv[KG][4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int gk = 0; gk < KG; ++gk) btv[gk][t] = float4{0.f, 0.f, 0.f, 0.f};
+      if (a.biasT) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int gk = 0; gk < KG; ++gk)
+            if (t < nsub) btv[gk][t] = *reinterpret_cast<const float4*>(a.biasT + ((long)h * a.Lk + key[gk]) * a.biasT_ld + qt * KT + t * 16 + g * 4);
+      }
       f32x4 p[KG][4], ds[KG][4];
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
+        if (t >= nsub) {
+#pragma unroll
+          for (int gk = 0; gk < KG; ++gk) { p[gk][t] = f32x4{0.f, 0.f, 0.f, 0.f}; ds[gk][t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+          continue;
+        }
         f32x4 s[KG], dp[KG];
 #pragma unroll
         for (int gk = 0; gk < KG; ++gk) { s[gk] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[gk] = f32x4{0.f, 0.f, 0.f, 0.f}; }
@@ -442,8 +531,7 @@ __global__ __launch_bounds__(64 * KW) void attn_bwd_dkv_kernel(AttnArgs a) {
         const float lsv[4] = {ls.x, ls.y, ls.z, ls.w}, dlv[4] = {dl.x, dl.y, dl.z, dl.w};
 #pragma unroll
         for (int gk = 0; gk < KG; ++gk) {
-          float4 bb{0.f, 0.f, 0.f, 0.f};
-          if (a.biasT) bb = *reinterpret_cast<const float4*>(a.biasT + ((long)h * a.Lk + key[gk]) * a.biasT_ld + qq0);
+          const float4 bb = btv[gk][t];
           const float bbv[4] = {bb.x, bb.y, bb.z, bb.w};
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
@@ -464,6 +552,7 @@ __global__ __launch_bounds__(64 * KW) void attn_bwd_dkv_kernel(AttnArgs a) {
         for (int gk = 0; gk < KG; ++gk) { pf[gk] = pack8(p[gk][2 * s2], p[gk][2 * s2 + 1]); dsf[gk] = pack8(ds[gk][2 * s2], ds[gk][2 * s2 + 1]); }
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
+          if (2 * s2 >= nsub) continue;
           const bf16x8 dotr = frag_cols(dotile, s2, dt, lane), qtr = frag_cols(qtile, s2, dt, lane);
 #pragma unroll
           for (int gk = 0; gk < KG; ++gk) {
