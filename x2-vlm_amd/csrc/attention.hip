@@ -132,10 +132,13 @@ __device__ __forceinline__ void load_bias_mask(const AttnArgs& a, int h, int b, 
 // QW waves per workgroup, QG groups of 16 queries per wave (K / V^T fragments read from LDS once serve QG MFMAs).
 // RES: all K / V tiles of the (batch, head) are resident in LDS (Lk <= 256): one load phase and one barrier per
 // workgroup instead of one per key tile - these kernels are latency-bound, not MFMA-bound, at N = 197 / 30.
-template <int QW, int QG, bool RES>
+// NS: LDS slots.  Resident form: one per key tile (4 covers Lk <= 256; 1 for Lk <= 64, the 30-token text sequences: 16 KB
+// per workgroup instead of 32-64 KB lets 10 of the 2-wave workgroups share a CU instead of 5, and these launches are a
+// serial load -> multiply -> store chain per workgroup whose only latency hiding is other workgroups).
+template <int QW, int QG, bool RES, int NS = (RES ? 4 : 2)>
 __global__ __launch_bounds__(64 * QW) void attn_fwd_kernel(AttnArgs a) {
   constexpr int NT = 64 * QW;
-  __shared__ __attribute__((aligned(16))) char smem[RES ? 4 : 2][2 * KT * 128];   // {K tile, V tile} per slot
+  __shared__ __attribute__((aligned(16))) char smem[NS][2 * KT * 128];   // {K tile, V tile} per slot
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fi = lane & 15, g = lane >> 4;
   const int h = blockIdx.y, b = blockIdx.z, bk = a.kv_idx ? a.kv_idx[b] : b;
@@ -166,12 +169,12 @@ __global__ __launch_bounds__(64 * QW) void attn_fwd_kernel(AttnArgs a) {
   if (RES) {
     // all (<= 4) key tiles are requested before the first one is written to LDS: one exposed HBM/L2 latency per
     // workgroup instead of one per tile
-    TileRegs<NT> rka[4], rva[4];
+    TileRegs<NT> rka[NS], rva[NS];
 #pragma unroll
-    for (int kt = 0; kt < 4; ++kt)
+    for (int kt = 0; kt < NS; ++kt)
       if (kt < nkt) { tile_load<NT>(rka[kt], Kp, a.k_rs, kt * KT, a.Lk, tid); tile_load<NT>(rva[kt], Vp, a.v_rs, kt * KT, a.Lk, tid); }
 #pragma unroll
-    for (int kt = 0; kt < 4; ++kt)
+    for (int kt = 0; kt < NS; ++kt)
       if (kt < nkt) { tile_store<NT>(rka[kt], smem[kt], tid); tile_store<NT>(rva[kt], smem[kt] + KT * 128, tid); }
   } else {
     tile_load<NT>(rk, Kp, a.k_rs, 0, a.Lk, tid);
@@ -274,10 +277,10 @@ __global__ __launch_bounds__(64 * QW) void attn_fwd_kernel(AttnArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------ backward: dQ (+ dS)
-template <int QW, int QG, bool RES>
+template <int QW, int QG, bool RES, int NS = (RES ? 4 : 2)>
 __global__ __launch_bounds__(64 * QW) void attn_bwd_dq_kernel(AttnArgs a) {
   constexpr int NT = 64 * QW;
-  __shared__ __attribute__((aligned(16))) char smem[RES ? 4 : 2][2 * KT * 128];
+  __shared__ __attribute__((aligned(16))) char smem[NS][2 * KT * 128];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fi = lane & 15, g = lane >> 4;
   const int h = blockIdx.y, b = blockIdx.z, bk = a.kv_idx ? a.kv_idx[b] : b;
@@ -316,12 +319,12 @@ __global__ __launch_bounds__(64 * QW) void attn_bwd_dq_kernel(AttnArgs a) {
   if (RES) {
     // all (<= 4) key tiles are requested before the first one is written to LDS: one exposed HBM/L2 latency per
     // workgroup instead of one per tile
-    TileRegs<NT> rka[4], rva[4];
+    TileRegs<NT> rka[NS], rva[NS];
 #pragma unroll
-    for (int kt = 0; kt < 4; ++kt)
+    for (int kt = 0; kt < NS; ++kt)
       if (kt < nkt) { tile_load<NT>(rka[kt], Kp, a.k_rs, kt * KT, a.Lk, tid); tile_load<NT>(rva[kt], Vp, a.v_rs, kt * KT, a.Lk, tid); }
 #pragma unroll
-    for (int kt = 0; kt < 4; ++kt)
+    for (int kt = 0; kt < NS; ++kt)
       if (kt < nkt) { tile_store<NT>(rka[kt], smem[kt], tid); tile_store<NT>(rva[kt], smem[kt] + KT * 128, tid); }
   } else {
     tile_load<NT>(rk, Kp, a.k_rs, 0, a.Lk, tid);
@@ -411,10 +414,10 @@ __global__ __launch_bounds__(64 * QW) void attn_bwd_dq_kernel(AttnArgs a) {
 
 // ------------------------------------------------------------------------------------------ backward: dK, dV
 // KW waves, KG groups of 16 keys per wave; the workgroup walks every (sequence using this K/V batch, 64-query tile).
-template <int KW, int KG, bool RES>
+template <int KW, int KG, bool RES, int NS = (RES ? 4 : 2)>
 __global__ __launch_bounds__(64 * KW) void attn_bwd_dkv_kernel(AttnArgs a) {
   constexpr int NT = 64 * KW;
-  __shared__ __attribute__((aligned(16))) char smem[RES ? 4 : 2][2 * KT * 128 + 2 * KT * 4];   // {Q tile, dO tile, LSE[64], Delta[64]} per slot
+  __shared__ __attribute__((aligned(16))) char smem[NS][2 * KT * 128 + 2 * KT * 4];   // {Q tile, dO tile, LSE[64], Delta[64]} per slot
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fi = lane & 15, g = lane >> 4;
   const int h = blockIdx.y, bk = blockIdx.z;
@@ -465,13 +468,13 @@ __global__ __launch_bounds__(64 * KW) void attn_bwd_dkv_kernel(AttnArgs a) {
     };
     if (RES) {
       // (<= 4 query tiles) all requested before the first LDS write, as in the forward kernel
-      TileRegs<NT> rqa[4], rdoa[4];
-      float rla[4], rda[4];
+      TileRegs<NT> rqa[NS], rdoa[NS];
+      float rla[NS], rda[NS];
 #pragma unroll
-      for (int it = 0; it < 4; ++it)
+      for (int it = 0; it < NS; ++it)
         if (it < nit) { fetch(it); rqa[it] = rq; rdoa[it] = rdo; rla[it] = rl; rda[it] = rd; }
 #pragma unroll
-      for (int it = 0; it < 4; ++it)
+      for (int it = 0; it < NS; ++it)
         if (it < nit) { rq = rqa[it]; rdo = rdoa[it]; rl = rla[it]; rd = rda[it]; commit(it); }
     } else {
       fetch(0);
@@ -608,7 +611,8 @@ extern "C" int x2_attn_fwd(const AttnArgs* pa, void* stream) {
   const hipStream_t st = (hipStream_t)stream;
   // long query side and <= 4 key tiles: 8-wave workgroups with K/V resident in LDS (64 KB); otherwise key tiles are
   // streamed through a double buffer (short query side: the 64 KB would leave 2 waves / workgroup alone on a CU)
-  if (a.Lq <= 32) hipLaunchKernelGGL((attn_fwd_kernel<2, 1, false>), dim3(1, a.H, a.B), dim3(128), 0, st, a);
+  if (a.Lq <= 32 && a.Lk <= 64) hipLaunchKernelGGL((attn_fwd_kernel<2, 1, true, 1>), dim3(1, a.H, a.B), dim3(128), 0, st, a);
+  else if (a.Lq <= 32) hipLaunchKernelGGL((attn_fwd_kernel<2, 1, false>), dim3(1, a.H, a.B), dim3(128), 0, st, a);
   else if (a.Lq <= 64 || a.Lk > 256) hipLaunchKernelGGL((attn_fwd_kernel<4, 1, false>), dim3((a.Lq + 63) / 64, a.H, a.B), dim3(256), 0, st, a);
   else if (attn_variant() & 4) hipLaunchKernelGGL((attn_fwd_kernel<4, 2, true>), dim3((a.Lq + 127) / 128, a.H, a.B), dim3(256), 0, st, a);
   else hipLaunchKernelGGL((attn_fwd_kernel<8, 1, true>), dim3((a.Lq + 127) / 128, a.H, a.B), dim3(512), 0, st, a);
@@ -624,13 +628,16 @@ extern "C" int x2_attn_bwd(const AttnArgs* pa, void* stream) {
   X2_REQUIRE((a.kv_idx == nullptr) == (a.seq_off == nullptr), "x2_attn_bwd: kv_idx and seq_off/seq_ids come together");
   X2_REQUIRE(a.Bkv > 0, "x2_attn_bwd: Bkv");
   const hipStream_t st = (hipStream_t)stream;
-  if (a.Lq <= 32) hipLaunchKernelGGL((attn_bwd_dq_kernel<2, 1, false>), dim3(1, a.H, a.B), dim3(128), 0, st, a);
+  if (a.Lq <= 32 && a.Lk <= 64) hipLaunchKernelGGL((attn_bwd_dq_kernel<2, 1, true, 1>), dim3(1, a.H, a.B), dim3(128), 0, st, a);
+  else if (a.Lq <= 32) hipLaunchKernelGGL((attn_bwd_dq_kernel<2, 1, false>), dim3(1, a.H, a.B), dim3(128), 0, st, a);
   else if (a.Lq <= 64 || a.Lk > 256) hipLaunchKernelGGL((attn_bwd_dq_kernel<4, 1, false>), dim3((a.Lq + 63) / 64, a.H, a.B), dim3(256), 0, st, a);
   else if (attn_variant() & 2) hipLaunchKernelGGL((attn_bwd_dq_kernel<4, 2, true>), dim3((a.Lq + 127) / 128, a.H, a.B), dim3(256), 0, st, a);
   else hipLaunchKernelGGL((attn_bwd_dq_kernel<8, 1, true>), dim3((a.Lq + 127) / 128, a.H, a.B), dim3(512), 0, st, a);
   if (int e = x2_check_launch("x2_attn_bwd(dq)")) return e;
   const bool res = !a.seq_off && a.Lq > 64 && a.Lq <= 256;   // one sequence per K/V batch, 2..4 query tiles: resident Q/dO
-  if (a.Lk <= 32) {
+  if (a.Lk <= 32 && !a.seq_off && a.Lq <= 64) {          // text self-attention: one sequence, one query tile, 17 KB of LDS
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<2, 1, true, 1>), dim3(1, a.H, a.Bkv), dim3(128), 0, st, a);
+  } else if (a.Lk <= 32) {
     hipLaunchKernelGGL((attn_bwd_dkv_kernel<2, 1, false>), dim3(1, a.H, a.Bkv), dim3(128), 0, st, a);
   } else if (res && !(attn_variant() & 1)) {
     // 8 waves (128 keys) share the resident Q / dO image (133 KB: one workgroup per CU either way): 206 -> 189 us per
