@@ -144,7 +144,8 @@ int x2_scatter_add_rows(const float* src, const int* idx, float* dst, int R, lon
  * (xvlm.py:807, 831-832), last layers of itm_head / bbox_head (xvlm.py:163-169) and their backward */
 int x2_linear_f32(const float* A, const float* B, float* C, const float* bias, const float* alpha_ptr, float alpha,
                   int M, int N, int K, long sam, long sak, long sbn, long sbk, long ldc, int accumulate,
-                  int ksplit /* K slices adding atomically onto a defined C (needs accumulate) */, void* stream);
+                  int ksplit /* K slices; > 1: partial tiles through ws, added in slice order */,
+                  float* ws /* ksplit * M * N floats when ksplit > 1 */, void* stream);
 int x2_l2norm(const float* x, const float* dy, float* out, int R, int D, int bwd, void* stream);   /* F.normalize */
 /* F.cross_entropy / CrossEntropyLoss(ignore_index=-100): xvlm.py:812-813, 899; xbert.py:1660-1661.
  * out2 = {mean loss, number of counted rows}; backward writes (softmax - onehot) * gscale * g / count. */

@@ -85,11 +85,12 @@ extern "C" int x2_scatter_add_rows(const float* src, const int* idx, float* dst,
 // ------------------------------------------------------------------------------------ small fp32 linear
 // C[m][n] (+)= alpha * sum_k A[m*sam + k*sak] * B[n*sbn + k*sbk] (+ bias[n]); alpha read from device if alpha_ptr.
 // 64x64 tile, 256 threads x (4x4) outputs, K step 16 through LDS.  For the heads (M <= a few hundred): their
-// output grids are 1-12 workgroups, so the contraction is cut into gridDim.z slices that add their partial tile
-// with fp32 atomics (distinct addresses, a few thousand per launch) onto a zeroed / accumulating C.
+// output grids are 1-12 workgroups, so the contraction is cut into gridDim.z slices whose partial tiles go to
+// ws[z][m][n] and are added in slice order by linear_f32_reduce_kernel (deterministic: the ITC logits feed a loss
+// that tests compare bit for bit between runs).
 __global__ __launch_bounds__(256) void linear_f32_kernel(const float* __restrict__ A, const float* __restrict__ B, float* C,
                                                          const float* __restrict__ bias, const float* alpha_ptr, float alpha, int M, int N,
-                                                         int K, long sam, long sak, long sbn, long sbk, long ldc, int accumulate) {
+                                                         int K, long sam, long sak, long sbn, long sbk, long ldc, int accumulate, float* ws) {
   __shared__ float As[16][65], Bs[16][65];
   const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
   const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
@@ -124,19 +125,34 @@ __global__ __launch_bounds__(256) void linear_f32_kernel(const float* __restrict
     for (int j = 0; j < 4; ++j) {
       const int m = m0 + ty * 4 + i, n = n0 + tx * 4 + j;
       if (m < M && n < N) {
-        float v = al * acc[i][j] + ((bias && blockIdx.z == 0) ? bias[n] : 0.f);
-        if (split) atomicAdd(C + m * ldc + n, v);
-        else { if (accumulate) v += C[m * ldc + n]; C[m * ldc + n] = v; }
+        if (split) { ws[((long)blockIdx.z * M + m) * N + n] = al * acc[i][j]; continue; }
+        float v = al * acc[i][j] + (bias ? bias[n] : 0.f);
+        if (accumulate) v += C[m * ldc + n];
+        C[m * ldc + n] = v;
       }
     }
 }
-// ksplit > 1: C must hold zeros (or the values to accumulate onto) when the kernel starts
+__global__ __launch_bounds__(256) void linear_f32_reduce_kernel(const float* __restrict__ ws, float* C, const float* __restrict__ bias, int M,
+                                                                int N, long ldc, int accumulate, int slices) {
+  const long e = blockIdx.x * 256L + threadIdx.x;
+  if (e >= (long)M * N) return;
+  const int m = (int)(e / N), n = (int)(e % N);
+  float v = bias ? bias[n] : 0.f;
+  for (int z = 0; z < slices; ++z) v += ws[(long)z * M * N + e];
+  if (accumulate) v += C[m * ldc + n];
+  C[m * ldc + n] = v;
+}
+// ksplit > 1 needs ws of ksplit * M * N floats
 extern "C" int x2_linear_f32(const float* A, const float* B, float* C, const float* bias, const float* alpha_ptr, float alpha, int M,
-                             int N, int K, long sam, long sak, long sbn, long sbk, long ldc, int accumulate, int ksplit, void* stream) {
+                             int N, int K, long sam, long sak, long sbn, long sbk, long ldc, int accumulate, int ksplit, float* ws,
+                             void* stream) {
   X2_REQUIRE(M > 0 && N > 0 && K > 0 && ksplit >= 1 && ksplit <= 64, "x2_linear_f32: M=%d N=%d K=%d ksplit=%d", M, N, K, ksplit);
-  X2_REQUIRE(ksplit == 1 || accumulate, "x2_linear_f32: ksplit>1 adds atomically: pass accumulate=1 and a defined C");
+  X2_REQUIRE(ksplit == 1 || ws, "x2_linear_f32: ksplit=%d needs a workspace", ksplit);
   hipLaunchKernelGGL(linear_f32_kernel, dim3((N + 63) / 64, (M + 63) / 64, ksplit), dim3(256), 0, (hipStream_t)stream, A, B, C, bias,
-                     alpha_ptr, alpha, M, N, K, sam, sak, sbn, sbk, ldc, accumulate);
+                     alpha_ptr, alpha, M, N, K, sam, sak, sbn, sbk, ldc, accumulate, ws);
+  if (ksplit > 1)
+    hipLaunchKernelGGL(linear_f32_reduce_kernel, dim3((int)(((long)M * N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ws, C, bias, M, N,
+                       ldc, accumulate, ksplit);
   return x2_check_launch("x2_linear_f32");
 }
 

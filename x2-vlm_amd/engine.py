@@ -11,6 +11,7 @@ Reference behaviour reproduced: beit2.py:125-209, 378-436 (vision), xbert.py:189
 652-767 (text/fusion layers), xbert.py:785-824, 1644-1661 (MLM head).
 """
 import math
+import os
 
 import torch
 
@@ -187,16 +188,51 @@ def _begin_layer_backward():
     K.DEFERRED = [] if (SIDE.enabled and torch.cuda.is_available()) else None
 
 
+class _LayerPairs:
+    """Weight gradients of TWO consecutive layers per grouped launch when they fit its 8 problem slots (a vision block
+    or a text layer has 4): 216 tiles of 256x256 fill the 256 CUs without splitting the contraction, so there are no
+    partial tiles to write and re-add, and half the launches.  Layers with more problems (fusion: 7) go alone."""
+
+    enabled = os.environ.get("X2_PAIR_WGRAD", "1") == "1"
+
+    def __init__(self):
+        self.pending = []
+
+    def add(self, G, tn):
+        deferred, K.DEFERRED = K.DEFERRED, None
+        if len(tn) > 4 or not self.enabled:
+            self.flush()
+            self._launch([(G, tn, deferred)])
+            return
+        self.pending.append((G, tn, deferred))
+        if len(self.pending) == 2:
+            self.flush()
+
+    def flush(self):
+        if self.pending:
+            entries, self.pending = self.pending, []
+            self._launch(entries)
+
+    @staticmethod
+    def _launch(entries):
+        deferred = [d for _, _, ds in entries for d in (ds or ())]
+        tn = [pr for _, t, _ in entries for pr in t]
+
+        def work():
+            if deferred:
+                K.reduce_partials_multi(deferred)
+            K.gemm_tn_grouped(tn)
+        keep = [t for pr in tn for t in pr[:2]] + [G.flat for G, _, _ in entries] + [d[0] for d in deferred]
+        done = SIDE.launch(work, keep)
+        for G, _, _ in entries:
+            G.publish(done)
+
+
 def _finish_layer_backward(G, tn):
     """Side stream: the deferred reductions, then the layer's weight-gradient GEMMs; publish the arena."""
     deferred, K.DEFERRED = K.DEFERRED, None
+    _LayerPairs._launch([(G, tn, deferred)])
 
-    def work():
-        if deferred:
-            K.reduce_partials_multi(deferred)
-        K.gemm_tn_grouped(tn)
-    keep = [t for pr in tn for t in pr[:2]] + [G.flat] + [d[0] for d in (deferred or ())]
-    G.publish(SIDE.launch(work, keep))
 
 GRAD_READY_HOOK = None      # set by accelerator.GradientBuckets: f(flat_fp32_arena, key)
 STAGE_CALLS = {}            # key -> number of forward calls since the last reset (see GradientBuckets)
@@ -311,6 +347,7 @@ class VisionEncoderFn(torch.autograd.Function):
         dS = torch.empty(B, H, T, K.round_up(T, 64), device=dev, dtype=BF16)
         F4 = p["blocks.0.mlp.fc1.weight"].shape[0]
         dpath = meta.get("drop_path")
+        pairs = _LayerPairs()
         for i in reversed(range(meta["depth"])):
             b = "blocks.%d." % i
             rs1, rs2 = dpath[i] if dpath is not None else (None, None)
@@ -346,11 +383,12 @@ class VisionEncoderFn(torch.autograd.Function):
             dxn, _ = K.layernorm_bwd(dh1, x, mean1, rstd1, p[b + "norm1.weight"], G["norm1.weight"], G["norm1.bias"], dres=dx1)
             tn = [(dy2, act, G["mlp.fc2.weight"]), (dpre, h2, G["mlp.fc1.weight"]),
                   (dy1, att, G["attn.proj.weight"]), (dqkv, h1, G["attn.qkv.weight"])]
-            _finish_layer_backward(G, tn)
+            pairs.add(G, tn)
             for n in names:
                 if n.startswith(b):
                     out[n] = G.g[n[len(b):]]
             dx = dxn
+        pairs.flush()
         dpatch = K.assemble_tokens_bwd(dx.view(B, T, D), Gt["cls_token"].view(-1))
         K.colsum_bf16(dpatch, Gt["patch_embed.proj.bias"])
         # 36 output tiles only: split the 12k-long contraction over 8 workgroups per tile (fp32 atomics)
@@ -484,6 +522,7 @@ class BertLayersFn(torch.autograd.Function):
         out = {}
         if cross:
             Bi, T, Dv = enc_shape
+        pairs = _LayerPairs()
         for li, i in reversed(list(enumerate(range(meta["lo"], meta["hi"])))):
             b = "layer.%d." % i
             a = b + "attention."
@@ -559,10 +598,11 @@ class BertLayersFn(torch.autograd.Function):
             _, wqkvT = BANK.linear(p[a + "self.query.weight"], p[a + "self.key.weight"], p[a + "self.value.weight"])
             dh = K.gemm_nt(dqkv, wqkvT, resid=ds1, out_dtype=F32)
             tn += [(ds1b, att, G["attention.output.dense.weight"]), (dqkv, hb, G["a.qkv_weight"])]
-            _finish_layer_backward(G, tn)
+            pairs.add(G, tn)
             for n in names:
                 if n.startswith(b):
                     out[n] = G.g[n[len(b):]]
+        pairs.flush()
         SIDE.join()
         d_enc = denc.view(enc_shape) if denc is not None else None
         return (dh.view(S, L, Hd), d_enc, None) + tuple(out[n] for n in names)

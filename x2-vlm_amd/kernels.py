@@ -413,16 +413,16 @@ def linear_f32(A, B, *, bias=None, transA=False, transB=False, alpha=1.0, alpha_
     N = B.shape[1] if transB else B.shape[0]
     sam, sak = (A.stride(1), A.stride(0)) if transA else (A.stride(0), A.stride(1))
     sbn, sbk = (B.stride(1), B.stride(0)) if transB else (B.stride(0), B.stride(1))
-    # head-sized outputs (a handful of 64x64 tiles) with a long contraction: slice K over gridDim.z (atomic partial tiles)
+    # head-sized outputs (a handful of 64x64 tiles) with a long contraction: slice K over gridDim.z; the partial tiles
+    # pass through the stream workspace and are added in slice order (deterministic)
     tiles = ((M + 63) // 64) * ((N + 63) // 64)
     ksplit = 1 if tiles >= 64 or K < 128 else max(1, min(16, K // 64, 256 // tiles))
     if out is None:
         assert not accumulate
-        out = (torch.zeros if ksplit > 1 else torch.empty)(M, N, device=A.device, dtype=F32)
-    elif ksplit > 1 and not accumulate:
-        out.zero_()
+        out = torch.empty(M, N, device=A.device, dtype=F32)
+    ws = workspace(A.device, ksplit * M * N) if ksplit > 1 else None
     call("x2_linear_f32", ptr(A), ptr(B), ptr(out), ptr(bias), ptr(alpha_ptr), alpha, M, N, K, sam, sak, sbn, sbk,
-         out.stride(0), 1 if (accumulate or ksplit > 1) else 0, ksplit)
+         out.stride(0), 1 if accumulate else 0, ksplit, ptr(ws))
     return out
 
 
