@@ -46,3 +46,26 @@ for name, B, H, Lq, Lk, bias, mask in [("vision", 64, 12, 197, 197, True, False)
     print("%-12s fwd %6.1fus %5.0fTF   bwd(dq+dkv) %6.1fus %5.0fTF" % (name, t, fl / t / 1e6, tb, 2.5 * fl / tb / 1e6))
     if name == "vision":
         print("   fwd ablation: " + "  ".join("d%d %.1fus" % (g, timeit(lambda g=g: fwd(g))) for g in (0, 1, 2, 3, 4, 8, 12, 15)))
+
+# cross-attention of the fusion stack: 256 text rows on 64 images (the 4-pass batch: positives, MLM, 2 x hard negatives)
+def cross_case(S=256, Bi=64, H=12, L=30, T=197):
+    d = 64
+    g = torch.Generator().manual_seed(0)
+    ar = torch.arange(Bi)
+    kv = torch.cat([ar, torch.randint(0, Bi, (Bi,), generator=g), ar, ar]).to(torch.int32)
+    order = torch.argsort(kv, stable=True).to(torch.int32)
+    off = torch.zeros(Bi + 1, dtype=torch.int32); off[1:] = torch.cumsum(torch.bincount(kv, minlength=Bi), 0)
+    q = torch.randn(S * L, H * d, device=dev).bfloat16(); kvt = torch.randn(Bi * T, 2 * H * d, device=dev).bfloat16()
+    out = torch.empty_like(q); lse = torch.empty(S * H * L, device=dev); delta = torch.empty_like(lse)
+    dout = torch.randn_like(q); dq = torch.empty_like(q); dkv = torch.empty_like(kvt)
+    mask = torch.zeros(S, K.round_up(T, 64), device=dev)
+    kw = dict(mask=mask, kv_idx=kv.to(dev), seq_off=off.to(dev), seq_ids=order.to(dev))
+    HD = H * d
+    q3, k3, v3 = K.view3(q, S, L), K.view3(kvt, Bi, T, 0), K.view3(kvt, Bi, T, HD)
+    fwd = lambda: K.attn_fwd(q3, k3, v3, S, Bi, H, L, T, d ** -0.5, K.view3(out, S, L), lse, **kw)
+    bwd = lambda: K.attn_bwd(q3, k3, v3, K.view3(out, S, L), K.view3(dout, S, L), S, Bi, H, L, T, d ** -0.5, lse, delta,
+                             K.view3(dq, S, L), K.view3(dkv, Bi, T, 0), K.view3(dkv, Bi, T, HD), **kw)
+    return fwd, bwd
+
+fwd, bwd = cross_case()
+print("cross (256 rows on 64 images)  fwd %6.1fus   bwd(dq+dkv) %6.1fus   [X2_ATTN_VARIANT=%s]" % (timeit(fwd), timeit(bwd), os.environ.get("X2_ATTN_VARIANT", "0")))

@@ -5,6 +5,7 @@ isolates kernel arithmetic (fp32 accumulate) from input quantisation.
 Tolerances (relative to each tensor's max-abs): fp32-out kernels 1e-5; bf16-out kernels 6e-3 (one
 bf16 rounding of the output is 2^-9 = 3.9e-3 of the element, plus fp32 summation-order noise)."""
 import importlib
+import os
 import math
 
 import numpy as np
@@ -203,9 +204,12 @@ def run_attention(K, B, Bkv, H, Lq, Lk, use_bias, use_mask, kv_map, seed):
     qd, kd, vd, dod = (t.reshape(-1, H * d).to(dev) for t in (qh, kh, vh, doh))
     od = torch.empty_like(qd)
     lse = torch.empty(B * H * Lq, device=dev); delta = torch.empty_like(lse)
-    K.attn_fwd(K.view3(qd, B, Lq), K.view3(kd, Bkv, Lk), K.view3(vd, Bkv, Lk), B, Bkv, H, Lq, Lk, scale,
-               K.view3(od, B, Lq), lse, **{k_: v_ for k_, v_ in kw.items() if k_ not in ("biasT", "seq_off", "seq_ids")})
-    assert relerr(od.view(B, Lq, H * d), ref_out) < 8e-3
+    # per-row kernels (no CSR given), then the grouped kernel (one workgroup per shared K/V batch and head) when rows share K/V
+    for drop_keys in ((("biasT", "seq_off", "seq_ids"), ("biasT",)) if kv_map is not None else (("biasT",),)):
+        od.fill_(float("nan")); lse.fill_(float("nan"))
+        K.attn_fwd(K.view3(qd, B, Lq), K.view3(kd, Bkv, Lk), K.view3(vd, Bkv, Lk), B, Bkv, H, Lq, Lk, scale,
+                   K.view3(od, B, Lq), lse, **{k_: v_ for k_, v_ in kw.items() if k_ not in drop_keys})
+        assert relerr(od.view(B, Lq, H * d), ref_out) < 8e-3 and bool(torch.isfinite(lse).all())
     dq, dk, dv = torch.empty_like(qd), torch.empty_like(kd), torch.empty_like(vd)
     dS = torch.zeros(B, H, Lq, Lkp, device=dev, dtype=torch.bfloat16) if use_bias else None
     K.attn_bwd(K.view3(qd, B, Lq), K.view3(kd, Bkv, Lk), K.view3(vd, Bkv, Lk), K.view3(od, B, Lq), K.view3(dod, B, Lq),
@@ -229,9 +233,25 @@ def test_attention_text_self_mask(K):
     run_attention(K, B=2, Bkv=2, H=4, Lq=40, Lk=40, use_bias=False, use_mask=True, kv_map=None, seed=220)
 
 
-def test_attention_cross_shared_kv(K):
+@pytest.fixture(params=["0", "8"], ids=["per_row", "grouped"])
+def cross_variant(request, monkeypatch):
+    """The library reads X2_ATTN_VARIANT once per process: the grouped kernels are exercised in a child interpreter."""
+    return request.param
+
+
+def test_attention_cross_shared_kv(K, cross_variant):
+    if cross_variant == "8" and os.environ.get("X2_ATTN_VARIANT") != "8":
+        import subprocess, sys
+        env = dict(os.environ, X2_ATTN_VARIANT="8")
+        r = subprocess.run([sys.executable, "-m", "pytest", __file__, "-q", "-x", "-m", "gpu", "-k", "cross_shared_kv and grouped"],
+                           env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        return
     run_attention(K, B=6, Bkv=3, H=12, Lq=30, Lk=197, use_bias=False, use_mask=True, kv_map=[0, 2, 1, 1, 0, 1], seed=300)
     run_attention(K, B=4, Bkv=2, H=2, Lq=8, Lk=5, use_bias=False, use_mask=False, kv_map=[1, 0, 1, 1], seed=310)
+    # an image nobody attends to (zero gradient, nothing to do), and more rows per image than one 128-query pass holds
+    run_attention(K, B=4, Bkv=3, H=2, Lq=30, Lk=197, use_bias=False, use_mask=True, kv_map=[0, 2, 2, 0], seed=320)
+    run_attention(K, B=11, Bkv=2, H=3, Lq=30, Lk=70, use_bias=False, use_mask=True, kv_map=[0] * 9 + [1] * 2, seed=330)
 
 
 def test_attention_long_keys(K):

@@ -412,6 +412,207 @@ __global__ __launch_bounds__(64 * QW) void attn_bwd_dq_kernel(AttnArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------ grouped forms (shared K/V)
+// Cross-attention of the fusion stack: several text rows attend to the same image (the 4-pass batch: ~4 rows per image).
+// One workgroup per (image, head) keeps that image's K / V resident in LDS and walks the concatenated queries of all rows
+// that use it (CSR seq_off / seq_ids), 16 per wave and pass - the image's K / V leave L2 once per head instead of once
+// per text row, and the 30-query rows fill 8-wave workgroups.  The batch index is per lane (rows of different sequences
+// share a wave).
+template <int QW>
+__global__ __launch_bounds__(64 * QW) void attn_fwd_grouped_kernel(AttnArgs a) {
+  constexpr int NT = 64 * QW;
+  __shared__ __attribute__((aligned(16))) char smem[4][2 * KT * 128];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fi = lane & 15, g = lane >> 4;
+  const int h = blockIdx.y, bk = blockIdx.z;
+  const int sb = a.seq_off[bk], nrows = (a.seq_off[bk + 1] - sb) * a.Lq;
+  if (nrows == 0) return;
+  const bf16_t* Kp = a.K + bk * a.k_bs + h * HD;
+  const bf16_t* Vp = a.V + bk * a.v_bs + h * HD;
+  const float sc2 = a.scale * LOG2E;
+  const int lkp = (a.Lk + 63) & ~63;
+  const int nkt = (a.Lk + KT - 1) / KT;
+  {
+    TileRegs<NT> rka[4], rva[4];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+      if (kt < nkt) { tile_load<NT>(rka[kt], Kp, a.k_rs, kt * KT, a.Lk, tid); tile_load<NT>(rva[kt], Vp, a.v_rs, kt * KT, a.Lk, tid); }
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+      if (kt < nkt) { tile_store<NT>(rka[kt], smem[kt], tid); tile_store<NT>(rva[kt], smem[kt] + KT * 128, tid); }
+  }
+  __syncthreads();
+  for (int base = wave * 16; base < nrows; base += QW * 16) {        // no barrier below: waves run on their own
+    const bool qok = base + fi < nrows;
+    const int v = min(base + fi, nrows - 1), sq = v / a.Lq, q = v - sq * a.Lq;
+    const int b = a.seq_ids[sb + sq];
+    bf16x8 qf[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+      qf[ks] = *reinterpret_cast<const bf16x8*>(a.Q + b * a.q_bs + (long)q * a.q_rs + h * HD + ks * 32 + g * 8);
+    f32x4 o[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m_i = NEG_BIG, l_i = 0.f;
+    for (int kt = 0; kt < nkt; ++kt) {
+      const uint32_t ktile = lds_addr(smem[kt]), vtile = ktile + KT * 128;
+      const int nsub = min(4, (a.Lk - kt * KT + 15) >> 4);
+      float4 mm[4];
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+        mm[nt] = (a.mask && nt < nsub) ? *reinterpret_cast<const float4*>(a.mask + (long)b * a.mask_ld + kt * KT + nt * 16 + g * 4)
+                                       : float4{0.f, 0.f, 0.f, 0.f};
+      f32x4 st[4];
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) st[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          if (nt >= nsub) continue;
+          st[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(ktile, nt * 16 + fi, ks * 4 + g), qf[ks], st[nt], 0, 0, 0);
+        }
+      float mx = NEG_BIG;
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        if (nt >= nsub) continue;
+        st[nt] = apply_bias_mask(st[nt], float4{0.f, 0.f, 0.f, 0.f}, mm[nt], kt * KT + nt * 16 + g * 4, a.Lk, sc2);
+        mx = fmaxf(fmaxf(mx, fmaxf(st[nt][0], st[nt][1])), fmaxf(st[nt][2], st[nt][3]));
+      }
+      mx = group_max(mx);
+      const float m_new = fmaxf(m_i, mx), alpha = exp2f(m_i - m_new);
+      float rs = 0.f;
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        if (nt >= nsub) continue;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { st[nt][r] = exp2f(st[nt][r] - m_new); rs += st[nt][r]; }
+      }
+      l_i = l_i * alpha + group_sum(rs);
+      m_i = m_new;
+      if (a.drop.thr16) {
+        const uint32_t e0 = (uint32_t)(((long)b * a.H + h) * a.Lq + q) * (uint32_t)lkp + (uint32_t)(kt * KT + g * 4);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+          if (nt >= nsub) continue;
+          float dm[4];
+          drop_mul4(a.drop, e0 + nt * 16, dm);
+          st[nt][0] *= dm[0]; st[nt][1] *= dm[1]; st[nt][2] *= dm[2]; st[nt][3] *= dm[3];
+        }
+      }
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) o[dt] *= alpha;
+      const bf16x8 pf[2] = {pack8(st[0], st[1]), pack8(st[2], st[3])};
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          if (2 * s2 >= nsub) continue;
+          o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_cols(vtile, s2, dt, lane), pf[s2], o[dt], 0, 0, 0);
+        }
+    }
+    if (qok) {
+      const float inv = 1.0f / l_i;
+      bf16_t* op = a.Out + b * a.o_bs + (long)q * a.o_rs + h * HD + g * 4;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+        *reinterpret_cast<u32x2*>(op + dt * 16) = u32x2{pack_bf16(o[dt][0] * inv, o[dt][1] * inv), pack_bf16(o[dt][2] * inv, o[dt][3] * inv)};
+      if (g == 0) a.LSE[((long)b * a.H + h) * a.Lq + q] = m_i + log2f(l_i);
+    }
+  }
+}
+
+template <int QW>
+__global__ __launch_bounds__(64 * QW) void attn_bwd_dq_grouped_kernel(AttnArgs a) {
+  constexpr int NT = 64 * QW;
+  __shared__ __attribute__((aligned(16))) char smem[4][2 * KT * 128];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fi = lane & 15, g = lane >> 4;
+  const int h = blockIdx.y, bk = blockIdx.z;
+  const int sb = a.seq_off[bk], nrows = (a.seq_off[bk + 1] - sb) * a.Lq;
+  if (nrows == 0) return;
+  const bf16_t* Kp = a.K + bk * a.k_bs + h * HD;
+  const bf16_t* Vp = a.V + bk * a.v_bs + h * HD;
+  const float sc2 = a.scale * LOG2E;
+  const int lkp = (a.Lk + 63) & ~63;
+  const int nkt = (a.Lk + KT - 1) / KT;
+  {
+    TileRegs<NT> rka[4], rva[4];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+      if (kt < nkt) { tile_load<NT>(rka[kt], Kp, a.k_rs, kt * KT, a.Lk, tid); tile_load<NT>(rva[kt], Vp, a.v_rs, kt * KT, a.Lk, tid); }
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+      if (kt < nkt) { tile_store<NT>(rka[kt], smem[kt], tid); tile_store<NT>(rva[kt], smem[kt] + KT * 128, tid); }
+  }
+  __syncthreads();
+  for (int base = wave * 16; base < nrows; base += QW * 16) {
+    const bool qok = base + fi < nrows;
+    const int v = min(base + fi, nrows - 1), sq = v / a.Lq, q = v - sq * a.Lq;
+    const int b = a.seq_ids[sb + sq];
+    bf16x8 qf[2], dof[2];
+    float dl = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      qf[ks] = *reinterpret_cast<const bf16x8*>(a.Q + b * a.q_bs + (long)q * a.q_rs + h * HD + ks * 32 + g * 8);
+      dof[ks] = *reinterpret_cast<const bf16x8*>(a.dO + b * a.do_bs + (long)q * a.do_rs + h * HD + ks * 32 + g * 8);
+      const bf16x8 of = *reinterpret_cast<const bf16x8*>(a.O + b * a.o_bs + (long)q * a.o_rs + h * HD + ks * 32 + g * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) dl += bf2f((bf16_t)dof[ks][e]) * bf2f((bf16_t)of[e]);
+    }
+    const float delta = group_sum(dl);
+    const float lse = a.LSE[((long)b * a.H + h) * a.Lq + q];
+    if (qok && g == 0) a.Delta[((long)b * a.H + h) * a.Lq + q] = delta;
+    f32x4 dq[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int kt = 0; kt < nkt; ++kt) {
+      const uint32_t ktile = lds_addr(smem[kt]), vtile = ktile + KT * 128;
+      const int nsub = min(4, (a.Lk - kt * KT + 15) >> 4);
+      float4 mm[4];
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+        mm[nt] = (a.mask && nt < nsub) ? *reinterpret_cast<const float4*>(a.mask + (long)b * a.mask_ld + kt * KT + nt * 16 + g * 4)
+                                       : float4{0.f, 0.f, 0.f, 0.f};
+      f32x4 ds[4];
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        if (nt >= nsub) { ds[nt] = f32x4{0.f, 0.f, 0.f, 0.f}; continue; }
+        f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(ktile, nt * 16 + fi, ks * 4 + g), qf[ks], s, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(vtile, nt * 16 + fi, ks * 4 + g), dof[ks], dp, 0, 0, 0);
+        }
+        const int key0 = kt * KT + nt * 16 + g * 4;
+        s = apply_bias_mask(s, float4{0.f, 0.f, 0.f, 0.f}, mm[nt], key0, a.Lk, sc2);
+        if (a.drop.thr16) {
+          float dm[4];
+          drop_mul4(a.drop, (uint32_t)(((long)b * a.H + h) * a.Lq + q) * (uint32_t)lkp + (uint32_t)key0, dm);
+          dp[0] *= dm[0]; dp[1] *= dm[1]; dp[2] *= dm[2]; dp[3] *= dm[3];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ds[nt][r] = exp2f(s[r] - lse) * (dp[r] - delta);
+      }
+      const bf16x8 dsf[2] = {pack8(ds[0], ds[1]), pack8(ds[2], ds[3])};
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          if (2 * s2 >= nsub) continue;
+          dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_cols(ktile, s2, dt, lane), dsf[s2], dq[dt], 0, 0, 0);
+        }
+    }
+    if (qok) {
+      bf16_t* op = a.dQ + b * a.dq_bs + (long)q * a.dq_rs + h * HD + g * 4;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+        *reinterpret_cast<u32x2*>(op + dt * 16) = u32x2{pack_bf16(dq[dt][0] * a.scale, dq[dt][1] * a.scale),
+                                                         pack_bf16(dq[dt][2] * a.scale, dq[dt][3] * a.scale)};
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------ backward: dK, dV
 // KW waves, KG groups of 16 keys per wave; the workgroup walks every (sequence using this K/V batch, 64-query tile).
 template <int KW, int KG, bool RES, int NS = (RES ? 4 : 2)>
@@ -588,7 +789,10 @@ __global__ __launch_bounds__(64 * KW) void attn_bwd_dkv_kernel(AttnArgs a) {
 // `args` is the AttnArgs struct laid out as 8-byte slots (pointers, longs) followed by ints/floats;
 // the Python side fills it through ctypes.Structure with the same field order.
 // experiment switch (probes/bench_attn.py): X2_ATTN_VARIANT bit 0: dkv back to 4 waves per workgroup,
-// bit 1: dq with 2 query groups per wave, bit 2: fwd with 2 query groups per wave
+// bit 1: dq with 2 query groups per wave, bit 2: fwd with 2 query groups per wave,
+// bit 3: grouped (shared K/V) forward / dQ kernels for cross-attention instead of the per-row ones.  Measured on the
+// fusion shapes (256 rows on 64 images): 62 vs 68 us forward, 132 vs 147 us backward in isolation, but -3 % on the whole
+// step (64 KB workgroups co-reside worse with the other streams' kernels), so off by default
 static int attn_variant() {
   static int v = -1;
   if (v < 0) { const char* e = getenv("X2_ATTN_VARIANT"); v = e ? atoi(e) : 0; }
@@ -611,7 +815,10 @@ extern "C" int x2_attn_fwd(const AttnArgs* pa, void* stream) {
   const hipStream_t st = (hipStream_t)stream;
   // long query side and <= 4 key tiles: 8-wave workgroups with K/V resident in LDS (64 KB); otherwise key tiles are
   // streamed through a double buffer (short query side: the 64 KB would leave 2 waves / workgroup alone on a CU)
-  if (a.Lq <= 32 && a.Lk <= 64) hipLaunchKernelGGL((attn_fwd_kernel<2, 1, true, 1>), dim3(1, a.H, a.B), dim3(128), 0, st, a);
+  X2_REQUIRE(!a.seq_off || (a.seq_ids && a.Bkv > 0), "x2_attn_fwd: seq_off needs seq_ids and Bkv");
+  if (a.seq_off && a.Lk <= 256 && !a.bias && (attn_variant() & 8))       // rows sharing K/V: one workgroup per (K/V batch, head)
+    hipLaunchKernelGGL((attn_fwd_grouped_kernel<8>), dim3(1, a.H, a.Bkv), dim3(512), 0, st, a);
+  else if (a.Lq <= 32 && a.Lk <= 64) hipLaunchKernelGGL((attn_fwd_kernel<2, 1, true, 1>), dim3(1, a.H, a.B), dim3(128), 0, st, a);
   else if (a.Lq <= 32) hipLaunchKernelGGL((attn_fwd_kernel<2, 1, false>), dim3(1, a.H, a.B), dim3(128), 0, st, a);
   else if (a.Lq <= 64 || a.Lk > 256) hipLaunchKernelGGL((attn_fwd_kernel<4, 1, false>), dim3((a.Lq + 63) / 64, a.H, a.B), dim3(256), 0, st, a);
   else if (attn_variant() & 4) hipLaunchKernelGGL((attn_fwd_kernel<4, 2, true>), dim3((a.Lq + 127) / 128, a.H, a.B), dim3(256), 0, st, a);
@@ -628,7 +835,9 @@ extern "C" int x2_attn_bwd(const AttnArgs* pa, void* stream) {
   X2_REQUIRE((a.kv_idx == nullptr) == (a.seq_off == nullptr), "x2_attn_bwd: kv_idx and seq_off/seq_ids come together");
   X2_REQUIRE(a.Bkv > 0, "x2_attn_bwd: Bkv");
   const hipStream_t st = (hipStream_t)stream;
-  if (a.Lq <= 32 && a.Lk <= 64) hipLaunchKernelGGL((attn_bwd_dq_kernel<2, 1, true, 1>), dim3(1, a.H, a.B), dim3(128), 0, st, a);
+  if (a.seq_off && a.Lk <= 256 && !a.bias && !a.dS && (attn_variant() & 8))
+    hipLaunchKernelGGL((attn_bwd_dq_grouped_kernel<8>), dim3(1, a.H, a.Bkv), dim3(512), 0, st, a);
+  else if (a.Lq <= 32 && a.Lk <= 64) hipLaunchKernelGGL((attn_bwd_dq_kernel<2, 1, true, 1>), dim3(1, a.H, a.B), dim3(128), 0, st, a);
   else if (a.Lq <= 32) hipLaunchKernelGGL((attn_bwd_dq_kernel<2, 1, false>), dim3(1, a.H, a.B), dim3(128), 0, st, a);
   else if (a.Lq <= 64 || a.Lk > 256) hipLaunchKernelGGL((attn_bwd_dq_kernel<4, 1, false>), dim3((a.Lq + 63) / 64, a.H, a.B), dim3(256), 0, st, a);
   else if (attn_variant() & 2) hipLaunchKernelGGL((attn_bwd_dq_kernel<4, 2, true>), dim3((a.Lq + 127) / 128, a.H, a.B), dim3(256), 0, st, a);

@@ -491,7 +491,8 @@ class BertLayersFn(torch.autograd.Function):
                 att2 = torch.empty(M, Hd, device=dev, dtype=BF16)
                 lse2 = torch.empty(S * H * L, device=dev, dtype=F32)
                 K.attn_fwd(K.view3(q2, S, L), K.view3(kv, Bi, T, 0), K.view3(kv, Bi, T, Hd), S, Bi, H, L, T, scale,
-                           K.view3(att2, S, L), lse2, mask=meta["enc_mask"], kv_idx=meta["kv_idx"], drop=dr(meta, i, 2))
+                           K.view3(att2, S, L), lse2, mask=meta["enc_mask"], kv_idx=meta["kv_idx"], seq_off=meta.get("seq_off"),
+                           seq_ids=meta.get("seq_ids"), drop=dr(meta, i, 2))
                 wo2, _ = BANK.linear(p[c + "output.dense.weight"])
                 s2 = K.gemm_nt(att2, wo2, bias=p[c + "output.dense.bias"], resid=h1, out_dtype=F32, drop=dr(meta, i, 3))
                 h2b, h2, m2, r2 = K.layernorm_fwd(s2, p[c + "output.LayerNorm.weight"], p[c + "output.LayerNorm.bias"], eps, want_f32=True)
