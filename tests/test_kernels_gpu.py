@@ -233,17 +233,19 @@ def test_attention_text_self_mask(K):
     run_attention(K, B=2, Bkv=2, H=4, Lq=40, Lk=40, use_bias=False, use_mask=True, kv_map=None, seed=220)
 
 
-@pytest.fixture(params=["0", "8"], ids=["per_row", "grouped"])
-def cross_variant(request, monkeypatch):
-    """The library reads X2_ATTN_VARIANT once per process: the grouped kernels are exercised in a child interpreter."""
+@pytest.fixture(params=["0", "8", "16"], ids=["default", "grouped_fwd", "per_row_dq"])
+def cross_variant(request):
+    """X2_ATTN_VARIANT (read once per process by the library): default = per-row forward + grouped dQ; bit 3 = grouped
+    forward as well; bit 4 = per-row dQ.  Non-default variants run in a child interpreter."""
     return request.param
 
 
 def test_attention_cross_shared_kv(K, cross_variant):
-    if cross_variant == "8" and os.environ.get("X2_ATTN_VARIANT") != "8":
+    if cross_variant != os.environ.get("X2_ATTN_VARIANT", "0"):
         import subprocess, sys
-        env = dict(os.environ, X2_ATTN_VARIANT="8")
-        r = subprocess.run([sys.executable, "-m", "pytest", __file__, "-q", "-x", "-m", "gpu", "-k", "cross_shared_kv and grouped"],
+        env = dict(os.environ, X2_ATTN_VARIANT=cross_variant)
+        r = subprocess.run([sys.executable, "-m", "pytest", __file__, "-q", "-x", "-m", "gpu", "-k",
+                            "cross_shared_kv and " + {"0": "default", "8": "grouped_fwd", "16": "per_row_dq"}[cross_variant]],
                            env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
         return

@@ -523,7 +523,7 @@ __global__ __launch_bounds__(64 * QW) void attn_fwd_grouped_kernel(AttnArgs a) {
 }
 
 template <int QW>
-__global__ __launch_bounds__(64 * QW) void attn_bwd_dq_grouped_kernel(AttnArgs a) {
+__global__ __launch_bounds__(64 * QW, 32 / QW) void attn_bwd_dq_grouped_kernel(AttnArgs a) {
   constexpr int NT = 64 * QW;
   __shared__ __attribute__((aligned(16))) char smem[4][2 * KT * 128];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -790,7 +790,7 @@ __global__ __launch_bounds__(64 * KW) void attn_bwd_dkv_kernel(AttnArgs a) {
 // the Python side fills it through ctypes.Structure with the same field order.
 // experiment switch (probes/bench_attn.py): X2_ATTN_VARIANT bit 0: dkv back to 4 waves per workgroup,
 // bit 1: dq with 2 query groups per wave, bit 2: fwd with 2 query groups per wave,
-// bit 3: grouped (shared K/V) forward / dQ kernels for cross-attention instead of the per-row ones.  Measured on the
+// bit 3: grouped (shared K/V) forward kernel for cross-attention; bit 4: per-row dQ kernel instead of the grouped one.  Measured on the
 // fusion shapes (256 rows on 64 images): 62 vs 68 us forward, 132 vs 147 us backward in isolation, but -3 % on the whole
 // step (64 KB workgroups co-reside worse with the other streams' kernels), so off by default
 static int attn_variant() {
@@ -835,7 +835,7 @@ extern "C" int x2_attn_bwd(const AttnArgs* pa, void* stream) {
   X2_REQUIRE((a.kv_idx == nullptr) == (a.seq_off == nullptr), "x2_attn_bwd: kv_idx and seq_off/seq_ids come together");
   X2_REQUIRE(a.Bkv > 0, "x2_attn_bwd: Bkv");
   const hipStream_t st = (hipStream_t)stream;
-  if (a.seq_off && a.Lk <= 256 && !a.bias && !a.dS && (attn_variant() & 8))
+  if (a.seq_off && a.Lk <= 256 && !a.bias && !a.dS && !(attn_variant() & 16))
     hipLaunchKernelGGL((attn_bwd_dq_grouped_kernel<8>), dim3(1, a.H, a.Bkv), dim3(512), 0, st, a);
   else if (a.Lq <= 32 && a.Lk <= 64) hipLaunchKernelGGL((attn_bwd_dq_kernel<2, 1, true, 1>), dim3(1, a.H, a.B), dim3(128), 0, st, a);
   else if (a.Lq <= 32) hipLaunchKernelGGL((attn_bwd_dq_kernel<2, 1, false>), dim3(1, a.H, a.B), dim3(128), 0, st, a);

@@ -25,25 +25,38 @@ extern "C" int x2_embed_fwd(const long* ids, const float* word, const float* pos
   hipLaunchKernelGGL(embed_fwd_kernel, dim3(R), dim3(256), 0, (hipStream_t)stream, ids, word, pos, type0, out, R, L, D);
   return x2_check_launch("x2_embed_fwd");
 }
-// dword[ids[r]] += g[r] ; dpos[r % L] += g[r] ; dtype0 += g[r].  Block = 32 rows; type-0 partials kept in registers.
-__global__ __launch_bounds__(256) void embed_bwd_kernel(const long* __restrict__ ids, const float* __restrict__ g, float* dword,
-                                                        float* dpos, float* dtype0, int R, int L, int D) {
-  const int r0 = blockIdx.x * 32, r1 = min(R, r0 + 32);
-  for (int d = threadIdx.x * 4; d < D; d += 1024) {
-    float4 t{0.f, 0.f, 0.f, 0.f};
+// dword[ids[r]] += g[r] ; dpos[r % L] += g[r] ; dtype0 += g[r]   (rows ordered (sequence, position)).
+// Word rows: scatter with atomics (token ids rarely collide).  Position / type rows would be R/L-way and R-way contended
+// (3840 rows onto 30 and onto 1): they are summed down the batch by one thread per (position, 4 columns) instead, and
+// only the L per-position totals are added atomically onto the type-0 row.
+__global__ __launch_bounds__(256) void embed_bwd_word_kernel(const long* __restrict__ ids, const float* __restrict__ g, float* dword, int R,
+                                                             int D) {
+  const int r0 = blockIdx.x * 8, r1 = min(R, r0 + 8);
+  for (int d = threadIdx.x * 4; d < D; d += 1024)
     for (int r = r0; r < r1; ++r) {
       const float4 v = *reinterpret_cast<const float4*>(g + (long)r * D + d);
-      float* w = dword + ids[r] * D + d; float* p = dpos + (long)(r % L) * D + d;
+      float* w = dword + ids[r] * D + d;
       atomicAdd(w, v.x); atomicAdd(w + 1, v.y); atomicAdd(w + 2, v.z); atomicAdd(w + 3, v.w);
-      atomicAdd(p, v.x); atomicAdd(p + 1, v.y); atomicAdd(p + 2, v.z); atomicAdd(p + 3, v.w);
-      t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
     }
-    atomicAdd(dtype0 + d, t.x); atomicAdd(dtype0 + d + 1, t.y); atomicAdd(dtype0 + d + 2, t.z); atomicAdd(dtype0 + d + 3, t.w);
+}
+__global__ __launch_bounds__(256) void embed_bwd_pos_kernel(const float* __restrict__ g, float* dpos, float* dtype0, int R, int L, int D) {
+  const int l = blockIdx.x, d = (blockIdx.y * 256 + threadIdx.x) * 4;
+  if (d >= D) return;
+  float4 t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+  for (int r = l; r < R; r += L) {
+    const float4 v = *reinterpret_cast<const float4*>(g + (long)r * D + d);
+    t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
   }
+  float* p = dpos + (long)l * D + d;
+  p[0] += t.x; p[1] += t.y; p[2] += t.z; p[3] += t.w;          // one thread owns (l, d..d+3)
+  atomicAdd(dtype0 + d, t.x); atomicAdd(dtype0 + d + 1, t.y); atomicAdd(dtype0 + d + 2, t.z); atomicAdd(dtype0 + d + 3, t.w);
 }
 extern "C" int x2_embed_bwd(const long* ids, const float* g, float* dword, float* dpos, float* dtype0, int R, int L, int D, void* stream) {
   X2_REQUIRE(R > 0 && L > 0 && D % 4 == 0, "x2_embed_bwd: R=%d L=%d D=%d", R, L, D);
-  hipLaunchKernelGGL(embed_bwd_kernel, dim3((R + 31) / 32), dim3(256), 0, (hipStream_t)stream, ids, g, dword, dpos, dtype0, R, L, D);
+  hipLaunchKernelGGL(embed_bwd_word_kernel, dim3((R + 7) / 8), dim3(256), 0, (hipStream_t)stream, ids, g, dword, R, D);
+  hipLaunchKernelGGL(embed_bwd_pos_kernel, dim3(L < R ? L : R, (D / 4 + 255) / 256), dim3(256), 0, (hipStream_t)stream, g, dpos, dtype0, R, L,
+                     D);
   return x2_check_launch("x2_embed_bwd");
 }
 
