@@ -136,7 +136,7 @@ __device__ __forceinline__ void load_bias_mask(const AttnArgs& a, int h, int b, 
 // per workgroup instead of 32-64 KB lets 10 of the 2-wave workgroups share a CU instead of 5, and these launches are a
 // serial load -> multiply -> store chain per workgroup whose only latency hiding is other workgroups).
 template <int QW, int QG, bool RES, int NS = (RES ? 4 : 2)>
-__global__ __launch_bounds__(64 * QW) void attn_fwd_kernel(AttnArgs a) {
+__global__ __launch_bounds__(64 * QW, 4) void attn_fwd_kernel(AttnArgs a) {
   constexpr int NT = 64 * QW;
   __shared__ __attribute__((aligned(16))) char smem[NS][2 * KT * 128];   // {K tile, V tile} per slot
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -278,7 +278,7 @@ __global__ __launch_bounds__(64 * QW) void attn_fwd_kernel(AttnArgs a) {
 
 // ------------------------------------------------------------------------------------------ backward: dQ (+ dS)
 template <int QW, int QG, bool RES, int NS = (RES ? 4 : 2)>
-__global__ __launch_bounds__(64 * QW) void attn_bwd_dq_kernel(AttnArgs a) {
+__global__ __launch_bounds__(64 * QW, 4) void attn_bwd_dq_kernel(AttnArgs a) {
   constexpr int NT = 64 * QW;
   __shared__ __attribute__((aligned(16))) char smem[NS][2 * KT * 128];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -616,7 +616,10 @@ __global__ __launch_bounds__(64 * QW, 32 / QW) void attn_bwd_dq_grouped_kernel(A
 // ------------------------------------------------------------------------------------------ backward: dK, dV
 // KW waves, KG groups of 16 keys per wave; the workgroup walks every (sequence using this K/V batch, 64-query tile).
 template <int KW, int KG, bool RES, int NS = (RES ? 4 : 2)>
-__global__ __launch_bounds__(64 * KW) void attn_bwd_dkv_kernel(AttnArgs a) {
+// (second launch bound = waves per SIMD the register allocation must allow: these kernels hide their load -> MFMA -> exp
+// chains only behind other waves, and left alone hipcc spends 170-230 VGPRs on the short-sequence forms (2 waves per SIMD);
+// capped at 128 they run 1.3-1.5x faster.  The streamed 4-wave form needs more than 128: 35 spills under the cap.)
+__global__ __launch_bounds__(64 * KW, (KW == 4 && !RES) ? 1 : 4) void attn_bwd_dkv_kernel(AttnArgs a) {
   constexpr int NT = 64 * KW;
   __shared__ __attribute__((aligned(16))) char smem[NS][2 * KT * 128 + 2 * KT * 4];   // {Q tile, dO tile, LSE[64], Delta[64]} per slot
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
