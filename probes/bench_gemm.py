@@ -56,20 +56,6 @@ def main():
         fl = 2.0 * M * N * Kd
         print("  %-11s M=%5d N=%5d K=%4d %-5s " % (name, M, N, Kd, epi) + "  ".join("g%-2d %6.1fus %5.0fTF" % (g, t, fl / t / 1e6) for g, t in zip(knobs, res)))
     lib.x2_tune(3, 0)
-    print("double-buffered (knob6 = 0) vs 4-slot ring (knob6 = 1), automatic tile choice, interleaved rounds")
-    for name, M, N, Kd, epi in NT:
-        fn = nt_case(M, N, Kd, epi)
-        res = {0: [], 1: []}
-        for rep in range(3):
-            for g in (0, 1):
-                lib.x2_tune(6, g)
-                res[g].append(timeit(fn, 10))
-        lib.x2_tune(6, 0)
-        fl = 2.0 * M * N * Kd
-        print("  %-11s M=%5d N=%5d K=%4d %-5s dbuf %6.1fus %4.0fTF   ring %6.1fus %4.0fTF" % (
-            name, M, N, Kd, epi, min(res[0]), fl / min(res[0]) / 1e6, min(res[1]), fl / min(res[1]) / 1e6))
-    if len(sys.argv) > 2 and sys.argv[2] == "ring":
-        return
     print("write-through (sc1) output stores: knob2 = 0 plain, 16 sc1 (interleaved rounds)")
     for name, M, N, Kd, epi in NT:
         fn = nt_case(M, N, Kd, epi)
