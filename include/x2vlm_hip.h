@@ -116,6 +116,8 @@ int x2_cast_transpose_bf16(const float* src, void* dst, void* dstT, int R, int C
  * optimizer step): desc = count rows of 7 int64 {src, dst, dstT, R, C, ldt, roff}: src [R][C] fp32 -> rows roff.. of
  * dst [*][C] and columns roff.. of dstT [C][ldt]; R, C, ldt, roff multiples of 4 */
 int x2_cast_transpose_multi(const int64_t* desc, int count, void* stream);
+/* many small fp32 vectors packed in one launch (stacked q/k/v biases): desc = count rows {src or 0 = zeros, dst, n} */
+int x2_copy_f32_multi(const int64_t* desc, int count, void* stream);
 /* PatchEmbed input rows (beit2.py:225-232): image (B,3,R,R) -> bf16 [B*(R/ps)^2][3*ps*ps] */
 int x2_patchify(const float* image, void* cols, int B, int R, int ps, void* stream);
 /* torch.cat((cls_tokens, x), 1) (beit2.py:385-387) and its backward */

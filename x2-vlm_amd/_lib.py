@@ -39,6 +39,7 @@ _SIGS = {
     "x2_reduce_partials": [P, I, I, I, P, P, P, P],
     "x2_reduce_partials_multi": [P, I, P],
     "x2_cast_transpose_multi": [P, I, P],
+    "x2_copy_f32_multi": [P, I, P],
     "x2_layerscale_bwd": [P, P, P, P, P, P, P, I, I, P, I, P],
     "x2_cast_bf16": [P, P, L, P],
     "x2_cast_transpose_bf16": [P, P, P, I, I, I, P],

@@ -478,6 +478,34 @@ extern "C" int x2_cast_transpose_multi(const int64_t* desc, int count, void* str
   return x2_check_launch("x2_cast_transpose_multi");
 }
 
+// Many small fp32 vectors packed into one buffer in one launch (the stacked q/k/v biases of every layer of a tower, with
+// zero segments where the reference has no bias: BEiT's k).  desc rows of 3 int64: {src or 0 (= zeros), dst, n}.
+#define CPM_MAX 96
+struct CopyDesc { const float* s; float* d; int n; int blk0; };
+struct CopyGroup { CopyDesc e[CPM_MAX]; int count; };
+__global__ __launch_bounds__(256) void copy_f32_multi_kernel(CopyGroup g) {
+  int lo = 0, hi = g.count - 1;
+  while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if ((int)blockIdx.x >= g.e[mid].blk0) lo = mid; else hi = mid - 1; }
+  const CopyDesc d = g.e[lo];
+  const int i = (blockIdx.x - d.blk0) * 256 + threadIdx.x;
+  if (i < d.n) d.d[i] = d.s ? d.s[i] : 0.f;
+}
+extern "C" int x2_copy_f32_multi(const int64_t* desc, int count, void* stream) {
+  X2_REQUIRE(desc && count >= 1, "x2_copy_f32_multi: count=%d", count);
+  for (int i0 = 0; i0 < count; i0 += CPM_MAX) {
+    CopyGroup g; g.count = count - i0 < CPM_MAX ? count - i0 : CPM_MAX;
+    int blocks = 0;
+    for (int i = 0; i < g.count; ++i) {
+      const int64_t* q = desc + (size_t)(i0 + i) * 3;
+      X2_REQUIRE(q[1] && q[2] > 0, "x2_copy_f32_multi[%d]: dst=%p n=%ld", i0 + i, (void*)q[1], (long)q[2]);
+      g.e[i] = CopyDesc{(const float*)q[0], (float*)q[1], (int)q[2], blocks};
+      blocks += ((int)q[2] + 255) / 256;
+    }
+    hipLaunchKernelGGL(copy_f32_multi_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g);
+  }
+  return x2_check_launch("x2_copy_f32_multi");
+}
+
 // ---------------------------------------------------------------------------------- patches / tokens
 // image fp32 (B,3,R,R) -> patch rows bf16 [B*g*g][3*ps*ps], column = c*ps*ps + py*ps + px (Conv2d weight order)
 __global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ img, bf16_t* __restrict__ cols, int B, int R, int ps) {

@@ -80,6 +80,44 @@ class WeightBank:
             self._c[key] = (vers, (plain, tr))
         K.cast_transpose_multi(desc)
 
+    def prepare_vectors(self, groups):
+        """Stacked fp32 bias vectors (tuples of 1-D parameters; an int n stands for n zeros), all built by one launch
+        into one buffer; `vector(*items)` then returns the cached stack."""
+        todo, total = [], 0
+        for items in groups:
+            key = ("vec",) + tuple(it if isinstance(it, int) else id(it) for it in items)
+            vers = tuple(0 if isinstance(it, int) else (it._version, it.data_ptr()) for it in items)
+            ent = self._c.get(key)
+            if ent is not None and ent[0] == vers:
+                continue
+            n = sum(it if isinstance(it, int) else it.numel() for it in items)
+            todo.append((key, vers, items, n))
+            total += (n + 3) // 4 * 4
+        if not todo:
+            return
+        dev = next(it for _, _, items, _ in todo for it in items if not isinstance(it, int)).device
+        flat = torch.empty(total, device=dev, dtype=F32)
+        desc, o = [], 0
+        for key, vers, items, n in todo:
+            out = flat[o:o + n]
+            oo = o
+            for it in items:
+                m = it if isinstance(it, int) else it.numel()
+                desc.append((0 if isinstance(it, int) else it.data_ptr(), flat.data_ptr() + 4 * oo, m))
+                oo += m
+            o += (n + 3) // 4 * 4
+            self._c[key] = (vers, out)
+        K.copy_f32_multi(desc)
+
+    def vector(self, *items):
+        key = ("vec",) + tuple(it if isinstance(it, int) else id(it) for it in items)
+        vers = tuple(0 if isinstance(it, int) else (it._version, it.data_ptr()) for it in items)
+
+        def build():
+            dev = next(it for it in items if not isinstance(it, int)).device
+            return torch.cat([torch.zeros(it, device=dev, dtype=F32) if isinstance(it, int) else it.detach().reshape(-1) for it in items])
+        return self._get(key, vers, build)
+
     def vocab(self, w):
         """word embeddings [V,Hd] -> (bf16 [Vp,Hd] zero-padded rows, bf16 [Hd,Vp]), Vp = V rounded to 64."""
         def build():
@@ -284,6 +322,7 @@ class VisionEncoderFn(torch.autograd.Function):
         scale = (D // H) ** -0.5
         BANK.prepare([(p["patch_embed.proj.weight"],)] + [(p["blocks.%d.%s.weight" % (i, n)],) for i in range(meta["depth"])
                                                             for n in ("attn.qkv", "attn.proj", "mlp.fc1", "mlp.fc2")])
+        BANK.prepare_vectors([(p["blocks.%d.attn.q_bias" % i], D, p["blocks.%d.attn.v_bias" % i]) for i in range(meta["depth"])])
         cols = K.patchify(image.contiguous(), ps)
         wpe, _ = BANK.linear(p["patch_embed.proj.weight"])
         patch = K.gemm_nt(cols, wpe, bias=p["patch_embed.proj.bias"], out_dtype=F32)
@@ -295,8 +334,7 @@ class VisionEncoderFn(torch.autograd.Function):
             rs1, rs2 = dpath[i] if dpath is not None else (None, None)
             h1, _, mean1, rstd1 = K.layernorm_fwd(x, p[b + "norm1.weight"], p[b + "norm1.bias"], meta["eps"])
             wqkv, _ = BANK.linear(p[b + "attn.qkv.weight"])
-            qkv_bias = torch.cat([p[b + "attn.q_bias"].detach(), torch.zeros(D, device=x.device, dtype=F32),
-                                  p[b + "attn.v_bias"].detach()])          # no k bias: beit2.py:129
+            qkv_bias = BANK.vector(p[b + "attn.q_bias"], D, p[b + "attn.v_bias"])          # no k bias: beit2.py:129
             qkv = K.gemm_nt(h1, wqkv, bias=qkv_bias)
             bias, biasT = K.relpos_bias(p[b + "attn.relative_position_bias_table"].detach(), meta["rel_index"])
             att = torch.empty(M, D, device=x.device, dtype=BF16)
@@ -464,12 +502,19 @@ class BertLayersFn(torch.autograd.Function):
                 groups += [(p[c + "self.query.weight"],), (p[c + "self.key.weight"], p[c + "self.value.weight"]),
                            (p[c + "output.dense.weight"],)]
         BANK.prepare(groups)
+        vecs = []
+        for i in range(meta["lo"], meta["hi"]):
+            a, c = "layer.%d.attention." % i, "layer.%d.crossattention." % i
+            vecs.append((p[a + "self.query.bias"], p[a + "self.key.bias"], p[a + "self.value.bias"]))
+            if cross and i >= meta["fusion_at"]:
+                vecs.append((p[c + "self.key.bias"], p[c + "self.value.bias"]))
+        BANK.prepare_vectors(vecs)
         saved = []
         for i in range(meta["lo"], meta["hi"]):
             b = "layer.%d." % i
             a = b + "attention."
             wqkv, _ = BANK.linear(p[a + "self.query.weight"], p[a + "self.key.weight"], p[a + "self.value.weight"])
-            bqkv = torch.cat([p[a + "self.query.bias"].detach(), p[a + "self.key.bias"].detach(), p[a + "self.value.bias"].detach()])
+            bqkv = BANK.vector(p[a + "self.query.bias"], p[a + "self.key.bias"], p[a + "self.value.bias"])
             qkv = K.gemm_nt(hb, wqkv, bias=bqkv)
             att = torch.empty(M, Hd, device=dev, dtype=BF16)
             lse = torch.empty(S * H * L, device=dev, dtype=F32)
@@ -485,7 +530,7 @@ class BertLayersFn(torch.autograd.Function):
                 c = b + "crossattention."
                 wq, _ = BANK.linear(p[c + "self.query.weight"])
                 wkv, _ = BANK.linear(p[c + "self.key.weight"], p[c + "self.value.weight"])
-                bkv = torch.cat([p[c + "self.key.bias"].detach(), p[c + "self.value.bias"].detach()])
+                bkv = BANK.vector(p[c + "self.key.bias"], p[c + "self.value.bias"])
                 q2 = K.gemm_nt(h1b, wq, bias=p[c + "self.query.bias"])
                 kv = K.gemm_nt(encb, wkv, bias=bkv)
                 att2 = torch.empty(M, Hd, device=dev, dtype=BF16)

@@ -111,6 +111,12 @@ def cast_transpose_multi(desc):
     call("x2_cast_transpose_multi", (C.c_int64 * len(flat))(*flat), len(desc))
 
 
+def copy_f32_multi(desc):
+    """desc: tuples (src_ptr or 0 for zeros, dst_ptr, n)."""
+    flat = [v for d in desc for v in d]
+    call("x2_copy_f32_multi", (C.c_int64 * len(flat))(*flat), len(desc))
+
+
 def _rows(t):
     assert t.dim() == 2 and t.stride(1) == 1, "expected a row-major 2-D tensor (got strides %s)" % (t.stride(),)
     return t.stride(0)
@@ -340,8 +346,9 @@ def relpos_bias(table, index, want_T=True):
     N = index.shape[0]
     H = table.shape[1]
     ld = round_up(N, 64)
-    bias = torch.zeros(H, N, ld, device=table.device, dtype=F32)
-    biasT = torch.zeros(H, N, ld, device=table.device, dtype=F32) if want_T else None
+    # pad columns stay undefined: the attention kernels select on key < Lk / query < Lq before using a bias value
+    bias = torch.empty(H, N, ld, device=table.device, dtype=F32)
+    biasT = torch.empty(H, N, ld, device=table.device, dtype=F32) if want_T else None
     call("x2_relpos_bias", ptr(table), ptr(index), ptr(bias), ptr(biasT), N, H, ld, ld)
     return bias, biasT
 
