@@ -49,7 +49,8 @@ class OracleConfig:
 
 
 def config_from_case(c):
-    return OracleConfig(image_res=c["image_res"], vision_layers=c["vision_layers"], hidden=c["hidden"],
+    vw = c.get("vision_width", 768)
+    return OracleConfig(image_res=c["image_res"], vision_width=vw, vision_heads=vw // 64, vision_layers=c["vision_layers"], hidden=c["hidden"],
                         heads=c["heads"], ffn=c["ffn"], vocab=c["vocab"], text_layers=c["text_layers"],
                         fusion_at=c["fusion_at"], embed_dim=c["embed_dim"], frames=c["frames"],
                         max_pos=c["max_pos"])

@@ -26,6 +26,10 @@ CASES = {
     "base_full": dict(image_res=224, vision_layers=12, hidden=768, heads=12, ffn=3072, vocab=30522,
                       max_pos=512, text_layers=18, fusion_at=12, embed_dim=256, batch=4, seq_len=30,
                       max_masks=12, ragged=False, region=False, frames=0, wseed=31, bseed=32),
+    # the geometry of X2VLM-large at 384 px (BEiT2-large: D=1024, 16 heads, N=577; BERT-large widths) on a shallow stack
+    "large_shallow": dict(image_res=384, vision_layers=2, vision_width=1024, hidden=1024, heads=16, ffn=4096, vocab=30522,
+                          max_pos=512, text_layers=3, fusion_at=2, embed_dim=256, batch=2, seq_len=30,
+                          max_masks=12, ragged=True, region=False, frames=0, wseed=61, bseed=62),
     # BASELINE.json configs[1]: full X2VLM-base at the headline per-GPU batch 64 (ragged captions)
     "base_full_b64": dict(image_res=224, vision_layers=12, hidden=768, heads=12, ffn=3072, vocab=30522,
                           max_pos=512, text_layers=18, fusion_at=12, embed_dim=256, batch=64, seq_len=30,
@@ -40,9 +44,10 @@ def model_config(case, workdir):
     import os
     c = CASES[case]
     os.makedirs(workdir, exist_ok=True)
-    vis = os.path.join(workdir, "config_beit2_base.json")
+    vw = c.get("vision_width", 768)
+    vis = os.path.join(workdir, "config_beit2_%s.json" % ("large" if vw == 1024 else "base"))   # the builders key on the file name
     with open(vis, "w") as f:
-        json.dump({"ckpt": "", "vision_width": 768, "patch_size": 16}, f)
+        json.dump({"ckpt": "", "vision_width": vw, "patch_size": 16}, f)
     tdir = os.path.join(workdir, "bert-base-uncased-%s" % case)
     os.makedirs(tdir, exist_ok=True)
     with open(os.path.join(tdir, "config.json"), "w") as f:
