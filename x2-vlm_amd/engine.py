@@ -10,8 +10,10 @@ statistics, softmax, losses and every reduction.
 Reference behaviour reproduced: beit2.py:125-209, 378-436 (vision), xbert.py:189-216, 322-625,
 652-767 (text/fusion layers), xbert.py:785-824, 1644-1661 (MLM head).
 """
+import itertools
 import math
 import os
+import weakref
 
 import torch
 
@@ -23,6 +25,19 @@ BF16, F32 = torch.bfloat16, torch.float32
 
 # ----------------------------------------------------------------------------- bf16 weight copies
 
+_SERIAL = itertools.count(1)
+
+
+def _tok(w):
+    """Identity of a parameter OBJECT for cache keys.  id() is not one: when a model is dropped and another built (every
+    parity test does), a new Parameter can land on the same address with the same storage pointer and version, and a
+    cache keyed on id() then serves the previous model's weights."""
+    t = w.__dict__.get("_x2_serial")
+    if t is None:
+        t = w.__dict__["_x2_serial"] = next(_SERIAL)
+    return t
+
+
 class WeightBank:
     """bf16 (and transposed bf16) copies of the fp32 master weights, rebuilt only when a
     parameter's version counter moved (i.e. once per optimizer step)."""
@@ -30,31 +45,38 @@ class WeightBank:
     def __init__(self):
         self._c = {}
 
-    def _get(self, key, vers, build):
+    def _get(self, key, vers, build, owners=()):
         ent = self._c.get(key)
         if ent is None or ent[0] != vers:
-            ent = (vers, build())
+            ent = (vers, build(), tuple(weakref.ref(w) for w in owners))
             self._c[key] = ent
         return ent[1]
 
+    def _purge(self):
+        """Drop the copies of parameters that no longer exist."""
+        dead = [k for k, e in self._c.items() if any(r() is None for r in e[2])]
+        for k in dead:
+            del self._c[k]
+
     def linear(self, *ws):
         """(W [N,K] bf16, W^T [K,N] bf16) of one weight or of several stacked along N."""
-        key = tuple(id(w) for w in ws)
+        key = tuple(_tok(w) for w in ws)
         vers = tuple((w._version, w.data_ptr()) for w in ws)
 
         def build():
             w2 = [w.detach().reshape(w.shape[0], -1) for w in ws]
             src = w2[0] if len(w2) == 1 else torch.cat(w2, 0)
             return K.cast_transpose_bf16(src.contiguous())
-        return self._get(key, vers, build)
+        return self._get(key, vers, build, ws)
 
     def prepare(self, groups):
         """Build every stale (W, W^T) pair of `groups` (tuples of weights, as `linear` takes them) with ONE
         multi-tensor launch and one allocation, instead of one cast launch (+ a concatenation) per weight when the
         layer first asks for it: a tower's ~50-100 weights are all re-cast once per optimizer step."""
+        self._purge()
         todo = []
         for ws in groups:
-            key = tuple(id(w) for w in ws)
+            key = tuple(_tok(w) for w in ws)
             vers = tuple((w._version, w.data_ptr()) for w in ws)
             ent = self._c.get(key)
             if ent is not None and ent[0] == vers:
@@ -77,7 +99,7 @@ class WeightBank:
             for w in ws:
                 desc.append((w.data_ptr(), plain.data_ptr(), tr.data_ptr(), w.shape[0], C_, R, roff))
                 roff += w.shape[0]
-            self._c[key] = (vers, (plain, tr))
+            self._c[key] = (vers, (plain, tr), tuple(weakref.ref(w) for w in ws))
         K.cast_transpose_multi(desc)
 
     def prepare_vectors(self, groups):
@@ -85,7 +107,7 @@ class WeightBank:
         into one buffer; `vector(*items)` then returns the cached stack."""
         todo, total = [], 0
         for items in groups:
-            key = ("vec",) + tuple(it if isinstance(it, int) else id(it) for it in items)
+            key = ("vec",) + tuple(it if isinstance(it, int) else _tok(it) for it in items)
             vers = tuple(0 if isinstance(it, int) else (it._version, it.data_ptr()) for it in items)
             ent = self._c.get(key)
             if ent is not None and ent[0] == vers:
@@ -106,17 +128,17 @@ class WeightBank:
                 desc.append((0 if isinstance(it, int) else it.data_ptr(), flat.data_ptr() + 4 * oo, m))
                 oo += m
             o += (n + 3) // 4 * 4
-            self._c[key] = (vers, out)
+            self._c[key] = (vers, out, tuple(weakref.ref(it) for it in items if not isinstance(it, int)))
         K.copy_f32_multi(desc)
 
     def vector(self, *items):
-        key = ("vec",) + tuple(it if isinstance(it, int) else id(it) for it in items)
+        key = ("vec",) + tuple(it if isinstance(it, int) else _tok(it) for it in items)
         vers = tuple(0 if isinstance(it, int) else (it._version, it.data_ptr()) for it in items)
 
         def build():
             dev = next(it for it in items if not isinstance(it, int)).device
             return torch.cat([torch.zeros(it, device=dev, dtype=F32) if isinstance(it, int) else it.detach().reshape(-1) for it in items])
-        return self._get(key, vers, build)
+        return self._get(key, vers, build, [it for it in items if not isinstance(it, int)])
 
     def vocab(self, w):
         """word embeddings [V,Hd] -> (bf16 [Vp,Hd] zero-padded rows, bf16 [Hd,Vp]), Vp = V rounded to 64."""
@@ -126,7 +148,7 @@ class WeightBank:
             src = torch.zeros(Vp, Hd, device=w.device, dtype=F32)
             src[:V] = w.detach()
             return K.cast_transpose_bf16(src)
-        return self._get(("vocab", id(w)), (w._version, w.data_ptr()), build)
+        return self._get(("vocab", _tok(w)), (w._version, w.data_ptr()), build, (w,))
 
     def invalidate(self):
         """Forget every copy (bench.py does this each step: a real training step re-casts the weights
@@ -183,6 +205,7 @@ class SideStream:
 
     def __init__(self):
         self.streams = {}          # one side stream per launching stream (vision and text stages run concurrently)
+        self.held = {}             # launching stream -> tensors the side stream still reads (released by join())
         self.enabled = True
 
     @property
@@ -206,8 +229,10 @@ class SideStream:
         with torch.cuda.stream(side):
             fn()
             done.record()
-        for t in tensors:
-            t.record_stream(side)
+        # Keep the operands alive until join() instead of Tensor.record_stream(): a step makes ~440 such registrations, each
+        # a host call plus an event the caching allocator must poll before it may reuse the block.  Once the launching stream
+        # has waited for the side stream, dropping the references frees the blocks for that stream in stream order.
+        self.held.setdefault(raw_stream(), []).append(tensors)
         return done
 
     def join(self):
@@ -216,6 +241,7 @@ class SideStream:
             key = raw_stream()
             if key in self.streams:
                 torch.cuda.current_stream().wait_stream(self.streams[key])
+            self.held.pop(key, None)
 
 
 SIDE = SideStream()
