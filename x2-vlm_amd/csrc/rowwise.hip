@@ -157,7 +157,7 @@ extern "C" int x2_reduce_partials_multi(const int64_t* desc, int count, void* st
 // reduce_partials_kernel then adds the partial rows into dw/db/dcol.
 #define LNB_ROWS 16
 template <int NV>
-__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+__global__ __launch_bounds__(256, NV <= 3 ? 4 : 1) void layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
                                                             const float* __restrict__ w, const float* dres, float* dx, bf16_t* dxb,
                                                             float* ws, int rows, int D, int period,
