@@ -619,7 +619,7 @@ template <int KW, int KG, bool RES, int NS = (RES ? 4 : 2)>
 // (second launch bound = waves per SIMD the register allocation must allow: these kernels hide their load -> MFMA -> exp
 // chains only behind other waves, and left alone hipcc spends 170-230 VGPRs on the short-sequence forms (2 waves per SIMD);
 // capped at 128 they run 1.3-1.5x faster.  The streamed 4-wave form needs more than 128: 35 spills under the cap.)
-__global__ __launch_bounds__(64 * KW, (KW == 4 && !RES) ? 1 : 4) void attn_bwd_dkv_kernel(AttnArgs a) {
+__global__ __launch_bounds__(64 * KW, (KW == 4 && !RES) ? 3 : 4) void attn_bwd_dkv_kernel(AttnArgs a) {
   constexpr int NT = 64 * KW;
   __shared__ __attribute__((aligned(16))) char smem[NS][2 * KT * 128 + 2 * KT * 4];   // {Q tile, dO tile, LSE[64], Delta[64]} per slot
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
