@@ -1,0 +1,80 @@
+"""Host logic of engine.WeightBank without a GPU (the cast kernels are replaced by recorders).
+
+Regression guard for a stale-cache bug: the bank used to key on id(parameter); when a model is dropped and another
+built, a new Parameter can reuse the address (and storage pointer and version) of a dead one, and the new model was then
+served the previous model's bf16 weights."""
+import gc
+import importlib
+
+import pytest
+import torch
+
+eng = importlib.import_module("x2-vlm_amd.engine")
+
+
+@pytest.fixture
+def bank(monkeypatch):
+    calls = {"multi": 0, "single": 0, "vec": 0}
+    monkeypatch.setattr(eng.K, "cast_transpose_multi", lambda desc: calls.__setitem__("multi", calls["multi"] + 1))
+    monkeypatch.setattr(eng.K, "copy_f32_multi", lambda desc: calls.__setitem__("vec", calls["vec"] + 1))
+
+    def single(src):
+        calls["single"] += 1
+        return src.to(torch.bfloat16), src.t().contiguous().to(torch.bfloat16)
+    monkeypatch.setattr(eng.K, "cast_transpose_bf16", single)
+    b = eng.WeightBank()
+    b.calls = calls
+    return b
+
+
+def test_prepare_builds_once_per_version(bank):
+    w = [torch.nn.Parameter(torch.randn(8, 4)) for _ in range(3)]
+    groups = [(w[0], w[1]), (w[2],)]
+    bank.prepare(groups)
+    assert bank.calls["multi"] == 1 and len(bank._c) == 2
+    plain, tr = bank.linear(w[0], w[1])                      # hit: no single-weight cast
+    assert plain.shape == (16, 4) and tr.shape == (4, 16) and bank.calls["single"] == 0
+    bank.prepare(groups)
+    assert bank.calls["multi"] == 1                          # nothing stale
+    with torch.no_grad():
+        w[2].add_(1.0)                                       # optimizer step: version moves
+    bank.prepare(groups)
+    assert bank.calls["multi"] == 2
+    odd = torch.nn.Parameter(torch.randn(6, 5))              # not 4-aligned: left to the one-at-a-time path
+    bank.prepare([(odd,)])
+    assert bank.calls["multi"] == 2
+    bank.linear(odd)
+    assert bank.calls["single"] == 1
+
+
+def test_keys_are_object_serials_not_addresses(bank):
+    seen = set()
+    for _ in range(50):                                      # CPython reuses the freed object's address most of the time
+        p = torch.nn.Parameter(torch.zeros(4, 4))
+        tok = eng._tok(p)
+        assert tok not in seen and eng._tok(p) == tok        # stable per object, never reused
+        seen.add(tok)
+        del p
+    a = torch.nn.Parameter(torch.ones(4, 4))
+    bank.linear(a)
+    key_a = next(iter(bank._c))
+    del a
+    gc.collect()
+    b = torch.nn.Parameter(torch.full((4, 4), 2.0))          # may well sit where `a` was, same version, same storage slot
+    plain, _ = bank.linear(b)
+    assert float(plain.float().mean()) == 2.0 and bank.calls["single"] == 2
+    bank._purge()
+    assert key_a not in bank._c and len(bank._c) == 1        # the dead parameter's copies are dropped
+
+
+def test_vector_cache(bank):
+    q, v = torch.nn.Parameter(torch.arange(4.0)), torch.nn.Parameter(torch.arange(4.0) + 10)
+    got = bank.vector(q, 4, v)                               # lazy path: torch.cat with a zero segment (BEiT has no k bias)
+    assert torch.equal(got, torch.tensor([0., 1, 2, 3, 0, 0, 0, 0, 10, 11, 12, 13]))
+    assert bank.vector(q, 4, v) is got
+    bank.prepare_vectors([(q, 4, v)])
+    assert bank.calls["vec"] == 0                            # already current
+    with torch.no_grad():
+        q.mul_(2.0)
+    bank.prepare_vectors([(q, 4, v)])
+    assert bank.calls["vec"] == 1
