@@ -9,6 +9,9 @@ Pinned: tests/test_oracle_golden.py checks every function here against golden ve
 by the real reference in the build container (tests/golden/make_golden.py, fixtures
 tests/golden/*.npz): losses, activations, logits, bbox coordinates and per-parameter gradients.
 
+Also here: rerank_scores (Retrieval.py:113-160), pinned by tests/golden/tiny_retrieval.npz.  NOT covered by any golden
+vector: the apex DDP / AMP semantics around the step (un-vendored third-party code): parity unpinned there, see DESIGN.md 6.
+
 Deviations from the pinned third-party stack, all result-neutral:
   * image (encoder) attention mask uses transformers==4.12.5's fp32 constant (1-m)*-1e9
     (modeling_utils.invert_attention_mask); the golden run used transformers 5's finfo.min.
