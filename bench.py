@@ -220,21 +220,24 @@ def main():
                                  "concurrently on other HIP streams (a launch also waits for CUs they hold); "
                                  "'isolated' below = same kernel timed in one extra single-stream step, the figure a "
                                  "rocprofv3 kernel trace of `bench.py --serialize` reproduces"}}
-        # one extra step on a single stream: per-kernel durations without co-running kernels
-        if not args.serialize:
-            model.overlap_towers = False
-            eng.SIDE.enabled = False
-            step(); torch.cuda.synchronize()
+    # two extra steps on a single stream: per-kernel durations without co-running kernels.  EVERY rank runs them (the
+    # step contains collectives: ITC all-gather, gradient all-reduce); only rank 0 times its GEMM launches.
+    if not args.serialize:
+        model.overlap_towers = False
+        eng.SIDE.enabled = False
+        step(); torch.cuda.synchronize()
+        if rank == 0:
             K.GEMM_TIMER = []
-            step(); torch.cuda.synchronize()
+        step(); torch.cuda.synchronize()
+        if rank == 0:
             recs, K.GEMM_TIMER = K.GEMM_TIMER, None
             ims = sum(a.elapsed_time(b) for a, b, f, nm in recs if nm == "gemm_nt")
             ifl = sum(f for a, b, f, nm in recs if nm == "gemm_nt")
             inn = sum(1 for r in recs if r[3] == "gemm_nt")
             roof["also"]["isolated"] = {"avg_launch_us": round(1e3 * ims / inn, 1), "achieved": round(ifl / ims / 1e9, 1),
                                         "frac": round(ifl / ims / 1e9 / PEAK_TFLOPS, 4)}
-            model.overlap_towers = True
-            eng.SIDE.enabled = True
+        model.overlap_towers = True
+        eng.SIDE.enabled = True
     if world > 1:
         dist.barrier()
     if rank == 0:
