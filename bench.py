@@ -211,7 +211,7 @@ def main():
                 "kernel": "gemm_nt_kernel (forward linears + input gradients)", "launches_per_step": n // args.steps,
                 "avg_launch_us": round(1e3 * ms / n, 1), "gflop_per_launch": round(fl / n / 1e9, 2),
                 "nt_gemm_ms_per_step": round(ms / args.steps, 2),
-                "also": {"gemm_tn_kernel (weight gradients, side stream)": {
+                "also": {"gemm_tn256_kernel (weight gradients, side stream; two layers per grouped launch)": {
                              "launches_per_step": tn_n // args.steps, "avg_launch_us": round(1e3 * tn_ms / max(tn_n, 1), 1),
                              "achieved": round(tn_fl / max(tn_ms, 1e-9) / 1e9, 1)},
                          "whole_step_tflops": round(pairs_s / world * F_MIN_GFLOP / 1e3, 1),

@@ -25,7 +25,7 @@ extern "C" {
 const char* x2_last_error(void);
 int x2_abi_version(void);          /* == 1 */
 int x2_device_cus(void);           /* compute units of the current HIP device, 0 if none */
-int x2_tune(int key, int value);   /* A/B knobs for probes/bench_gemm.py (key 0: NT tile-raster GROUP_M) */
+int x2_tune(int key, int value);   /* kernel-variant knobs for probes/ and tests (0 = automatic); keys listed in csrc/gemm.hip */
 
 /* ---- dense contractions (csrc/gemm.hip) -------------------------------------------------------------
  * F.linear of beit2.py:131 (fused qkv), :160 (proj), :62/:66 (MLP); xbert.py:338-350 (Q/K/V, cross K/V from

@@ -337,7 +337,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_w8_kernel(GemmNT p) {
   nt_epilogue<4>(p, acc, smem, wave, lane, m0 + wm * 64, n0 + wn * 64);
 }
 
-// tuning knobs for A/B measurements (probes/bench_gemm.py): [0] GROUP_M of the NT raster, [1] NT tile choice
+// knobs for A/B measurements and for the tests that pin a kernel variant (0 = automatic everywhere):
+//   [0] GROUP_M of the NT tile raster            [1] 2: NT on the 8-wave 256x128 kernel
+//   [2] NT ablation bits (1 no operand loads in the loop, 4 no epilogue, 16 sc1 stores)
+//   [3] NT tile: 1 = 128x128, 2 = 192x128, 3 = 64x128        [4] NT start stagger (x 4 us)
+//   [5] TN: 1 = always 128x128 tiles, 2 = 256x256 tiles whenever the contraction lengths allow
 static int g_tune[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 extern "C" int x2_tune(int key, int value) {
   if (key < 0 || key >= 8) return X2_ERR_ARG;
