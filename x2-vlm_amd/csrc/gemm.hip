@@ -33,7 +33,7 @@ struct GemmNT {
   DropSpec drop;            // hidden dropout on (acc + bias) before the residual add (xbert.py:429, 513)
   const float* rowscale;    // [M] per-row factor before the residual add: DropPath keep/(1-p) per sample (beit2.py:206-207)
   float* colsum;            // [N] += column sums of the stored C (bias gradient of the layer below, fused)
-  int dbg;                  // ablation switches for probes/bench_gemm.py: 1 = no operand loads in the K loop, 2 = no MFMA, 4 = no epilogue
+  int dbg;                  // ablation switches for probes/bench_gemm.py: 4 = no epilogue, 16 = sc1 output stores
   int stagger;              // experiment: odd workgroups start `stagger` x 4 us late (de-phases the two workgroups of a CU)
 };
 
@@ -339,7 +339,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_w8_kernel(GemmNT p) {
 
 // knobs for A/B measurements and for the tests that pin a kernel variant (0 = automatic everywhere):
 //   [0] GROUP_M of the NT tile raster            [1] 2: NT on the 8-wave 256x128 kernel
-//   [2] NT ablation bits (1 no operand loads in the loop, 4 no epilogue, 16 sc1 stores)
+//   [2] NT ablation bits (4 no epilogue, 16 sc1 stores)
 //   [3] NT tile: 1 = 128x128, 2 = 192x128, 3 = 64x128        [4] NT start stagger (x 4 us)
 //   [5] TN: 1 = always 128x128 tiles, 2 = 256x256 tiles whenever the contraction lengths allow
 static int g_tune[8] = {0, 0, 0, 0, 0, 0, 0, 0};
