@@ -23,8 +23,23 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-F_MIN_GFLOP = 183.5      # fwd+bwd FLOPs per pair actually executed (K/V de-duplicated), SURVEY.md 8(d), L=30
 PEAK_TFLOPS = 2500.0     # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
+
+# BASELINE.json configs[1] / [3] / [4] on ONE GPU.  f_min = fwd+bwd GFLOP per pair (clip) actually executed, cross-attention
+# K/V projected once per image (SURVEY.md 8(d), L = 30).  The default (`base`) is the configuration the metric is quoted on.
+CONFIGS = {
+    "base": dict(size="base", res=224, batch=64, frames=0, f_min=183.5, unit="pairs/s",
+                 metric="image-text pairs/sec (fwd+bwd) X2VLM-base 224px bs=64/GPU",
+                 workload="X2VLM-base (BEiT2-base + BERT-base 12+6) pre-training step fwd+bwd, ITC+ITM+MLM, 224px"),
+    "large": dict(size="large", res=384, batch=32, frames=0, f_min=1315.7, unit="pairs/s",
+                  metric="image-text pairs/sec (fwd+bwd) X2VLM-large 384px bs=32/GPU",
+                  workload="X2VLM-large (BEiT2-large 24 blocks + BERT-large-12l 12+6, 593M) pre-training step fwd+bwd, "
+                           "ITC+ITM+MLM, 384px"),
+    "video": dict(size="base", res=224, batch=8, frames=8, f_min=921.1, unit="clips/s",
+                  metric="video-text clips/sec (fwd+bwd) X2VLM-base 8x8-frame 224px clips/GPU",
+                  workload="X2VLM-base video path (avgpool over 8 frames + frame position embedding) pre-training step "
+                           "fwd+bwd, ITC+ITM+MLM, 224px"),
+}
 
 
 def _pmc_traffic():
@@ -41,10 +56,10 @@ def _pmc_traffic():
 PMC_TRAFFIC = _pmc_traffic()
 
 
-def synthetic_batch(rank, B, L, res, vocab=30522, masks=12):
+def synthetic_batch(rank, B, L, res, vocab=30522, masks=12, frames=0):
     """per-rank generator seed 1234+rank."""
     g = torch.Generator().manual_seed(1234 + rank)
-    image = torch.randn(B, 3, res, res, generator=g)
+    image = torch.randn(*((B, frames) if frames else (B,)), 3, res, res, generator=g)
     ids = torch.randint(1000, 30000, (B, L), generator=g)
     ids[:, 0], ids[:, -1] = 101, 102
     atts = torch.ones(B, L, dtype=torch.long)
@@ -53,18 +68,21 @@ def synthetic_batch(rank, B, L, res, vocab=30522, masks=12):
                 text_ids_masked=ids.scatter(1, pos, 103))
 
 
-def cpu_baseline(seconds=20.0):
+def cpu_baseline(conf, seconds=20.0):
     """The oracle (CPU fp32 restatement, pinned to the reference's golden vectors) on the host cores:
-    X2VLM-base, B=4 sample of the same workload."""
+    a B=4 (base) / B=2 (large, video) sample of the same workload."""
     from oracle import x2vlm_oracle as O
     synthetic = importlib.import_module("x2-vlm_amd.synthetic")
     cores = os.cpu_count() or 1
     threads = min(cores, 64)
     torch.set_num_threads(threads)
-    cfg = O.OracleConfig()
+    if conf["size"] == "large":
+        cfg = O.OracleConfig(image_res=conf["res"], vision_width=1024, vision_heads=16, vision_layers=24, hidden=1024, heads=16, ffn=4096)
+    else:
+        cfg = O.OracleConfig(image_res=conf["res"], frames=conf["frames"])
     sd = O.make_params(cfg, 0, synthetic.synth_tensor)
-    B = 4
-    b = synthetic_batch(0, B, 30, 224)
+    B = 4 if conf is CONFIGS["base"] else 2
+    b = synthetic_batch(0, B, 30, conf["res"], frames=conf["frames"])
     neg = synthetic.synth_negatives(0, B)
     n, t0, first = 0, time.time(), None
     while True:
@@ -81,8 +99,9 @@ def cpu_baseline(seconds=20.0):
         if time.time() - t0 > seconds or n >= 8:
             break
     dt = time.time() - t0
-    return {"value": round(B * n / dt, 3), "unit": "pairs/s", "cores": threads, "kind": "port",
-            "sample": "oracle fp32, X2VLM-base, B=4, %d timed steps after 1 warm-up (%.1fs), %d torch threads" % (n, dt, threads)}
+    return {"value": round(B * n / dt, 3), "unit": conf["unit"], "cores": threads, "kind": "port",
+            "sample": "oracle fp32, %s, B=%d, %d timed steps after 1 warm-up (%.1fs), %d torch threads"
+                      % (conf["workload"].split(" pre-training")[0], B, n, dt, threads)}
 
 
 def main():
@@ -90,7 +109,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="base",
+                    help="base = the headline metric (BASELINE.json configs[1]); large / video = configs[3] / [4] on one GPU")
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the configuration's own)")
     ap.add_argument("--seq-len", type=int, default=30)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eval-mode", action="store_true", help="model.eval(): dropout / DropPath off (not the headline number)")
@@ -101,6 +122,8 @@ def main():
                     help="profiling aid: one HIP stream only (no concurrent text tower / weight-gradient stream), so that "
                          "per-kernel durations are not inflated by co-running kernels")
     args = ap.parse_args()
+    conf = CONFIGS[args.config]
+    args.batch = args.batch or conf["batch"]
 
     rank = int(os.environ.get("RANK", 0))
     local = int(os.environ.get("LOCAL_RANK", 0))
@@ -124,7 +147,9 @@ def main():
     if os.environ.get("X2_FAULT_DUMP"):
         import faulthandler
         faulthandler.dump_traceback_later(int(os.environ["X2_FAULT_DUMP"]), exit=True)
-    cfg = cfgs.pretrain_config(tempfile.mkdtemp(), "base", 224)
+    cfg = cfgs.pretrain_config(tempfile.mkdtemp(), conf["size"], conf["res"])
+    if conf["frames"]:
+        cfg.update(video_encoding="avgpool", frame_len=conf["frames"], add_frame_pos=True)
     if args.tiny:
         cfg.update(vision_num_hidden_layers=2, text_num_hidden_layers=3, text_fusion_start_at=2)
     model = mp.XVLM(config=cfg, load_vision_params=False, load_text_params=False, pretraining=True).to(dev)
@@ -133,7 +158,7 @@ def main():
         model.overlap_towers = False
         importlib.import_module("x2-vlm_amd.engine").SIDE.enabled = False
     ddp = acc.GradientBuckets(model, world) if world > 1 else None
-    batch = {k: v.to(dev) for k, v in synthetic_batch(rank, args.batch, args.seq_len, 224).items()}
+    batch = {k: v.to(dev) for k, v in synthetic_batch(rank, args.batch, args.seq_len, conf["res"], frames=conf["frames"]).items()}
 
     eng = importlib.import_module("x2-vlm_amd.engine")
 
@@ -214,8 +239,8 @@ def main():
                 "also": {"gemm_tn256_kernel (weight gradients, side stream; two layers per grouped launch)": {
                              "launches_per_step": tn_n // args.steps, "avg_launch_us": round(1e3 * tn_ms / max(tn_n, 1), 1),
                              "achieved": round(tn_fl / max(tn_ms, 1e-9) / 1e9, 1)},
-                         "whole_step_tflops": round(pairs_s / world * F_MIN_GFLOP / 1e3, 1),
-                         "whole_step_frac": round(pairs_s / world * F_MIN_GFLOP / 1e3 / PEAK_TFLOPS, 4),
+                         "whole_step_tflops": round(pairs_s / world * conf["f_min"] / 1e3, 1),
+                         "whole_step_frac": round(pairs_s / world * conf["f_min"] / 1e3 / PEAK_TFLOPS, 4),
                          "note": "launch durations are taken while the text tower and the weight-gradient GEMMs run "
                                  "concurrently on other HIP streams (a launch also waits for CUs they hold); "
                                  "'isolated' below = same kernel timed in one extra single-stream step, the figure a "
@@ -241,13 +266,12 @@ def main():
     if world > 1:
         dist.barrier()
     if rank == 0:
-        out = {"metric": "image-text pairs/sec (fwd+bwd) X2VLM-base 224px bs=64/GPU", "value": round(pairs_s, 1),
-               "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        out = {"metric": conf["metric"], "value": round(pairs_s, 1),
+               "unit": conf["unit"], "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(1e3 * dt / args.steps, 2),
                "host_enqueue_ms_per_step": round(1e3 * host_dt / args.steps, 2), "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-               "config": {"workload": "X2VLM-base (BEiT2-base + BERT-base 12+6) pre-training step fwd+bwd, ITC+ITM+MLM, "
-                                      "224px, %d-token captions, 12 masks" % args.seq_len,
+               "config": {"workload": conf["workload"] + ", %d-token captions, 12 masks" % args.seq_len, "name": args.config,
                           "per_gpu_batch": args.batch, "global_batch": args.batch * world,
                           "parallelism": "dp%d" % world, "streams": "single (--serialize)" if args.serialize else "concurrent",
                           "optimizer_in_step": bool(args.with_optimizer), "mode": "eval (dropout/DropPath off)" if args.eval_mode else
@@ -255,7 +279,7 @@ def main():
                           "losses": {k: round(float(v), 4) for k, v in loss.items()}},
                "roofline": roof}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline"] = cpu_baseline(conf)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -34,6 +34,15 @@ CASES = {
     "base_full_b64": dict(image_res=224, vision_layers=12, hidden=768, heads=12, ffn=3072, vocab=30522,
                           max_pos=512, text_layers=18, fusion_at=12, embed_dim=256, batch=64, seq_len=30,
                           max_masks=12, ragged=True, region=False, frames=0, wseed=41, bseed=42),
+    # BASELINE.json configs[3]: full X2VLM-large (BEiT2-large 24 blocks, BERT-large-12l 18 layers, 593 M params) at 384 px;
+    # CPU-feasible batch (the per-GPU batch 32 is covered by the bench and by property checks)
+    "large_full": dict(image_res=384, vision_layers=24, vision_width=1024, hidden=1024, heads=16, ffn=4096, vocab=30522,
+                       max_pos=512, text_layers=18, fusion_at=12, embed_dim=256, batch=2, seq_len=30,
+                       max_masks=12, ragged=True, region=False, frames=0, wseed=71, bseed=72),
+    # BASELINE.json configs[4]: full X2VLM-base video path, 8-frame 224 px clips (avgpool + frame position embedding)
+    "video_full": dict(image_res=224, vision_layers=12, hidden=768, heads=12, ffn=3072, vocab=30522,
+                       max_pos=512, text_layers=18, fusion_at=12, embed_dim=256, batch=2, seq_len=30,
+                       max_masks=12, ragged=True, region=False, frames=8, wseed=81, bseed=82),
 }
 
 

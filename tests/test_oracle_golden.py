@@ -30,7 +30,9 @@ def close(a, b, rtol, what, floor=1e-6):
 
 @pytest.mark.parametrize("case", ["tiny", "tiny_region", "tiny_video", "base_shallow", "large_shallow",
                                   pytest.param("base_full", marks=pytest.mark.slow),
-                                  pytest.param("base_full_b64", marks=pytest.mark.slow)])
+                                  pytest.param("base_full_b64", marks=pytest.mark.slow),
+                                  pytest.param("large_full", marks=pytest.mark.slow),
+                                  pytest.param("video_full", marks=pytest.mark.slow)])
 def test_oracle_matches_reference(case, synthetic):
     c = CASES[case]
     gold = np.load(os.path.join(GOLD, case + ".npz"))
