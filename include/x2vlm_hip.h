@@ -23,7 +23,7 @@ extern "C" {
 #endif
 
 const char* x2_last_error(void);
-int x2_abi_version(void);          /* == 1 */
+int x2_abi_version(void);          /* == 2 */
 int x2_device_cus(void);           /* compute units of the current HIP device, 0 if none */
 int x2_tune(int key, int value);   /* kernel-variant knobs for probes/ and tests (0 = automatic); keys listed in csrc/gemm.hip */
 
@@ -81,6 +81,7 @@ typedef struct X2AttnArgs {
   unsigned drop_thr16, drop_seed; float drop_scale;   /* dropout on the probabilities (xbert.py:399);
                                                           element = ((b*H + h)*Lq + q) * round_up(Lk,64) + key */
   int dbg;                                           /* 0; ablation switches for probes/bench_attn.py */
+  int head_dim;                                      /* hidden / heads of the caller: must be 64, checked */
 } X2AttnArgs;
 int x2_attn_fwd(const X2AttnArgs* args, void* stream);
 int x2_attn_bwd(const X2AttnArgs* args, void* stream);   /* dQ (+dS, Delta) then dK/dV; no atomics */
@@ -164,11 +165,28 @@ int x2_colsum_f32(const float* x, float* out, int M, int N, void* stream);
 /* ---- optimizer (csrc/optim.hip) -- "next" row of the scope table ------------------------------------------
  * optim.py:26-104 (transformers==4.12.5 AdamW, eps 1e-8, betas (0.9,0.98), correct_bias) and the global-norm clip of
  * accelerators/apex_ddp_accelerator.py:99-102, as two multi-tensor launches.  table: ntensors records
- * {float* p; const float* g (NULL = no gradient); float* m; float* v; long n; int group; int blk0} in device memory,
- * blk0 = prefix sum of ceil(n / 16384); nblocks = total.  out2 = {total norm, min(1, max_norm / (norm + 1e-6))}. */
+ * {float* p; const float* g (NULL = no gradient); float* m; float* v; long n; int group; int blk0; float stepscale; int pad}
+ * in device memory, blk0 = prefix sum of ceil(n / 16384); nblocks = total; stepscale = sqrt(1 - b2^t) / (1 - b1^t) with t the
+ * tensor's own step count (HF AdamW keeps state["step"] per parameter).  out2 = {total norm, min(1, max_norm / (norm + 1e-6))}. */
 int x2_grad_norm(const void* table, int ntensors, int nblocks, float max_norm, float* partial, float* out2, void* stream);
 int x2_adamw_multi(const void* table, int ntensors, int nblocks, const float* lr, const float* wd, int ngroups, float b1,
-                   float b2, float eps, int step, const float* clip2 /* out2 of x2_grad_norm or NULL */, void* stream);
+                   float b2, float eps, const float* clip2 /* out2 of x2_grad_norm or NULL */, void* stream);
+
+/* ---- data-parallel communication (csrc/comm.hip) -----------------------------------------------------------
+ * RCCL over xGMI behind the C ABI, for hosts that are not PyTorch (the Python host may use either these or
+ * torch.distributed's "nccl" backend, which is the same RCCL).  Replaces accelerators/apex_ddp_accelerator.py:57-66
+ * (NCCL init), :70-77 (per-tensor broadcast), :80-97 (apex DDP: flat all-reduce + average) and models/xvlm.py:140-160
+ * (ITC all_gather; its backward keeps the local slice and needs no collective).  One communicator per process, one
+ * process per GPU.  librccl.so.1 is loaded on first use (the library itself has no link-time RCCL dependency).
+ * Every collective is enqueued on `stream` (the caller's communication stream) and, if done_event (a hipEvent_t) is
+ * non-NULL, records it behind the collective.  dtype: 0 = fp32, 1 = bf16. */
+int x2_comm_unique_id(void* out128);                                     /* rank 0; share the 128 bytes out of band */
+int x2_comm_init(const void* id128, int rank, int world, void** comm_out);  /* collective; current HIP device = this rank's GPU */
+int x2_comm_info(void* comm, int* rank, int* world);
+int x2_comm_allreduce_bucket(void* comm, void* buf, long count, int dtype, int average, void* done_event, void* stream);
+int x2_comm_allgather(void* comm, const void* send, void* recv, long count_per_rank, int dtype, void* done_event, void* stream);
+int x2_comm_broadcast(void* comm, void* buf, long count, int dtype, int root, void* done_event, void* stream);
+int x2_comm_destroy(void* comm);
 
 #ifdef __cplusplus
 }

@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(h, name), "include/x2vlm_hip.h declares %s but libx2vlm_hip.so does not export it" % name
     assert sorted(lib.EXPORTS) == declared, set(lib.EXPORTS) ^ set(declared)
-    assert lib.lib().x2_abi_version() == 1
+    assert lib.lib().x2_abi_version() == 2
 
 
 def test_attn_args_struct_matches_header_layout():
@@ -37,7 +37,7 @@ def test_attn_args_struct_matches_header_layout():
     # 12 pointers + 16 longs + 5 ints + float + 3 x (pointer, int, pad) + 3 pointers + int (+pad)
     assert ctypes.sizeof(lib.AttnArgs) == 12 * 8 + 16 * 8 + 6 * 4 + 3 * 16 + 3 * 8 + 24   # ds_ld, 3 dropout words, dbg (+pad)
     assert lib.AttnArgs.bias.offset == 248 and lib.AttnArgs.kv_idx.offset == 296 and lib.AttnArgs.ds_ld.offset == 320
-    assert lib.AttnArgs.drop_thr16.offset == 324 and lib.AttnArgs.dbg.offset == 336
+    assert lib.AttnArgs.drop_thr16.offset == 324 and lib.AttnArgs.dbg.offset == 336 and lib.AttnArgs.head_dim.offset == 340
 
 
 def test_argument_checks_fail_loudly_without_launching():
@@ -49,6 +49,17 @@ def test_argument_checks_fail_loudly_without_launching():
     assert rc == -1 and b"x2_layernorm_fwd" in h.x2_last_error()
     rc = h.x2_sample_negatives(None, 5000, None, None, None, None)
     assert rc == -1
+
+
+def test_communicator_entry_points_check_arguments_and_find_rccl():
+    """x2_comm_*: librccl.so.1 is resolved at first use (no link-time dependency); bad handles fail cleanly."""
+    lib = importlib.import_module("x2-vlm_amd._lib")
+    comm = importlib.import_module("x2-vlm_amd.comm")
+    h = lib.lib()
+    assert h.x2_comm_destroy(None) == -1 and b"x2_comm_destroy" in h.x2_last_error()
+    assert h.x2_comm_allreduce_bucket(None, None, 0, 0, 1, None, None) == -1
+    assert h.x2_comm_init(None, 0, 1, None) == -1
+    assert len(comm.X2Comm.unique_id()) == 128               # RCCL loaded and answered (needs no GPU)
 
 
 def test_missing_library_raises(monkeypatch):

@@ -54,11 +54,37 @@ def test_allgather_forward_concat_backward_local_slice():
         assert torch.equal(g, w[3 * r: 3 * r + 3])        # gradient = local rows only, no cross-rank reduction
 
 
+class _ArenaLinear(torch.autograd.Function):
+    """y = x W^T + b whose backward behaves like an engine stage: parameter gradients are views of one flat arena,
+    published (engine.Grads.publish) before autograd sees them."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, key):
+        eng = importlib.import_module("x2-vlm_amd.engine")
+        eng._count_call(key)
+        ctx.save_for_backward(x, w)
+        ctx.key, ctx.params = key, (w, b)
+        return x @ w.t() + b
+
+    @staticmethod
+    def backward(ctx, dy):
+        eng = importlib.import_module("x2-vlm_amd.engine")
+        x, w = ctx.saved_tensors
+        G = eng.Grads(dy.device, [("w", w.shape, False), ("b", (w.shape[0],), True)], key=ctx.key, params=list(ctx.params))
+        G["w"].copy_(dy.t() @ x)
+        G["b"].copy_(dy.sum(0))
+        G.publish()
+        dw, db = G.take(["w", "b"])
+        return dy @ w, dw, db, None
+
+
 def _bucket_case(rank, world):
+    """Two arena layers + a plain head.  Iteration 1: one backward_step.  Iteration 2 (no zero_grad in between, as
+    run_mixed_iter's video + image backward, Pretrain.py:197, 247): gradients must accumulate and stay averaged."""
     acc = importlib.import_module("x2-vlm_amd.accelerator")
-    eng = importlib.import_module("x2-vlm_amd.engine")
     torch.manual_seed(0)
-    model = torch.nn.Sequential(torch.nn.Linear(4, 4), torch.nn.Linear(4, 2))
+    l0, l1, head = torch.nn.Linear(4, 4), torch.nn.Linear(4, 4), torch.nn.Linear(4, 2)
+    model = torch.nn.Sequential(l0, l1, head)
     a = acc.RocmDDPAccelerator(dict(RNG_SEED=1), None)
     with torch.no_grad():
         for p in model.parameters():
@@ -66,37 +92,59 @@ def _bucket_case(rank, world):
     a.world_size = world
     a.broadcast(model)
     after_bcast = [p.detach().clone() for p in model.parameters()]
-    gb = acc.GradientBuckets(model, world)
-    # layer 0: gradients live in one arena, used once -> reduced at publish time
-    p0 = list(model[0].parameters())
-    arena = eng.Grads("cpu", [("w", p0[0].shape, False), ("b", p0[1].shape, True)], key=("t", 0))
-    eng._count_call(("t", 0))
-    arena["w"].fill_(rank + 1.0); arena["b"].fill_(10.0 * (rank + 1))
-    p0[0].grad, p0[1].grad = arena["w"], arena["b"]
-    arena.publish()
-    early = arena["w"].clone()
-    # layer 1: used twice in the step -> must NOT be reduced early, only as a leftover
-    p1 = list(model[1].parameters())
-    arena2 = eng.Grads("cpu", [("w", p1[0].shape, False), ("b", p1[1].shape, True)], key=("t", 1))
-    eng._count_call(("t", 1)); eng._count_call(("t", 1))
-    arena2["w"].fill_(rank + 1.0); arena2["b"].fill_(rank + 1.0)
-    p1[0].grad, p1[1].grad = arena2["w"].clone(), arena2["b"].clone()
-    arena2.publish()
-    not_early = arena2["w"].clone()
-    gb.finish()
+    a.buckets = gb = acc.GradientBuckets(model, world)
+
+    def run(x, shared_l1=False):
+        h = _ArenaLinear.apply(x, l0.weight, l0.bias, ("t", 0))
+        h = _ArenaLinear.apply(torch.tanh(h), l1.weight, l1.bias, ("t", 1))
+        if shared_l1:                                      # a layer used twice in one forward: never reduced early
+            h = _ArenaLinear.apply(torch.tanh(h), l1.weight, l1.bias, ("t", 1))
+        return head(torch.tanh(h)).square().sum()
+
+    g = torch.Generator().manual_seed(50 + rank)
+    xa, xb, xc = (torch.randn(5, 4, generator=g) for _ in range(3))
+    out = {"bcast": after_bcast, "x": (xa, xb, xc)}
+    a.backward_step(run(xa), None)
+    out["g1"] = [p.grad.clone() for p in model.parameters()]
+    out["msgs1"] = gb.messages                             # 2 early arenas + 1 leftover bucket
+    a.backward_step(run(xb), None)                         # second backward_step of the iteration: accumulate
+    out["g2"] = [p.grad.clone() for p in model.parameters()]
+    out["msgs2"] = gb.messages - out["msgs1"]              # everything through the late path: 1 message
+    for p in model.parameters():
+        p.grad = None
+    a.backward_step(run(xc, shared_l1=True), None)
+    out["g3"] = [p.grad.clone() for p in model.parameters()]
+    out["msgs3"] = gb.messages - out["msgs1"] - out["msgs2"]   # arena 0 early, shared layer + head late
     gb.close()
-    return after_bcast, early, not_early, [p.grad.clone() for p in model.parameters()]
+    return out
+
+
+def _local_grads(params0, x, shared_l1=False):
+    """Plain-autograd gradients of the same little network on one rank's input."""
+    w0, b0, w1, b1, wh, bh = [t.clone().requires_grad_(True) for t in params0]
+    h = torch.tanh(x @ w0.t() + b0) @ w1.t() + b1
+    if shared_l1:
+        h = torch.tanh(h) @ w1.t() + b1
+    (torch.tanh(h) @ wh.t() + bh).square().sum().backward()
+    return [t.grad for t in (w0, b0, w1, b1, wh, bh)]
 
 
 def test_gradient_buckets_average_once_and_broadcast():
     out = _run("_bucket_case")
-    for r, (bc, early, not_early, grads) in enumerate(out):
-        for a, b in zip(bc, out[0][0]):
+    for o in out:
+        for a, b in zip(o["bcast"], out[0]["bcast"]):
             assert torch.equal(a, b)                                   # identical parameters after the flat broadcast
-        assert torch.allclose(early, torch.full_like(early, 1.5))      # (1+2)/2 already at publish time
-        assert torch.allclose(not_early, torch.full_like(not_early, r + 1.0))
-        assert torch.allclose(grads[0], torch.full_like(grads[0], 1.5)) and torch.allclose(grads[1], torch.full_like(grads[1], 15.0))
-        assert torch.allclose(grads[2], torch.full_like(grads[2], 1.5)) and torch.allclose(grads[3], torch.full_like(grads[3], 1.5))
+    P = out[0]["bcast"]
+    mean = lambda k, **kw: [sum(gs) / len(out) for gs in zip(*[_local_grads(P, o["x"][k], **kw) for o in out])]
+    ga, gb_, gc = mean(0), mean(1), mean(2, shared_l1=True)
+    for o in out:
+        assert (o["msgs1"], o["msgs2"], o["msgs3"]) == (3, 1, 2)
+        for got, want in zip(o["g1"], ga):
+            assert torch.allclose(got, want, atol=1e-5)
+        for got, wa, wb in zip(o["g2"], ga, gb_):                      # avg(g_a) + avg(g_b), averaged exactly once each
+            assert torch.allclose(got, wa + wb, atol=1e-5)
+        for got, want in zip(o["g3"], gc):
+            assert torch.allclose(got, want, atol=1e-5)
 
 
 def _itc_grad_case(rank, world):

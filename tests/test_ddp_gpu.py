@@ -1,0 +1,236 @@
+"""Data parallelism of the real step, observed on the 1-GPU box.
+
+(a) Two ranks sharing GPU 0 (gloo rendezvous: RCCL refuses two ranks on one device) run the real
+    x2-vlm_amd XVLM step through RocmDDPAccelerator on two different half-batches.  The averaged gradients must equal
+    what the CPU oracle gives for the same two half-batches under the reference's semantics (SURVEY.md 8e,
+    xvlm.py:140-160, 805-826, apex DDP averaging): every rank evaluates the ITC loss over the all-gathered
+    features but back-propagates only through its own rows; ITM / MLM are per-rank means; gradients are averaged.
+    Includes the reference's two-backward_step-per-iteration pattern (Pretrain.py:197, 247).
+(b) A single-rank RCCL process group (backend "nccl") goes through set_up / broadcast / backward_step /
+    optimizer_step and the ITC all-gather, so the RCCL code path has executed on hardware.
+
+Tolerances as tests/test_model_gpu.py (bf16 operands vs the fp32 oracle)."""
+import importlib
+import os
+import socket
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from cases import CASES, model_config
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _rank_batch(synthetic, c, rank, shift=0):
+    seed = c["bseed"] + 100 * rank + shift
+    b = synthetic.synth_batch(seed, c["batch"], c["seq_len"], c["image_res"], c["vocab"], c["max_masks"], ragged=c["ragged"],
+                              frames=c["frames"])
+    return b, synthetic.synth_negatives(seed, c["batch"])
+
+
+def _step(model, batch, neg):
+    model.injected_negatives = neg
+    loss = model(batch["image"], batch["text_ids"], batch["text_atts"], text_ids_masked=batch["text_ids_masked"],
+                 masked_pos=batch["masked_pos"], masked_ids=batch["masked_ids"])
+    return loss, sum(loss.values())
+
+
+def _two_rank_worker(rank, world, port, case, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), X2_DIST_BACKEND="gloo")
+    synthetic = importlib.import_module("x2-vlm_amd.synthetic")
+    mp_ = importlib.import_module("x2-vlm_amd.model_pretrain")
+    acc = importlib.import_module("x2-vlm_amd.accelerator")
+    c = CASES[case]
+    model = mp_.XVLM(config=model_config(case, tempfile.mkdtemp()), load_vision_params=False, load_text_params=False, pretraining=True)
+    synthetic.synth_state_dict(model, c["wseed"])
+    model.eval()
+    a = acc.RocmDDPAccelerator(dict(RNG_SEED=7), None)
+    ddp, _, _ = a.set_up(model, None, None, local_rank=0, world_size=world, rank=rank)
+    try:
+        out = {}
+        b1, n1 = _rank_batch(synthetic, c, rank)
+        b2, n2 = _rank_batch(synthetic, c, rank, shift=1000)
+        b1 = {k: v.cuda() for k, v in b1.items()}
+        b2 = {k: v.cuda() for k, v in b2.items()}
+        loss, total = _step(ddp.module, b1, n1)
+        a.backward_step(total, None)
+        torch.cuda.synchronize()
+        out["loss1"] = {k: float(v) for k, v in loss.items()}
+        out["g1"] = {n: p.grad.detach().cpu() for n, p in model.named_parameters() if p.grad is not None}
+        out["early"] = a.buckets.messages
+        _, total = _step(ddp.module, b2, n2)               # second backward_step, gradients accumulate
+        a.backward_step(total, None)
+        torch.cuda.synchronize()
+        out["g2"] = {n: p.grad.detach().cpu() for n, p in model.named_parameters() if p.grad is not None}
+        ret[rank] = out
+    finally:
+        a.buckets.close()
+        dist.destroy_process_group()
+
+
+def _oracle_ddp(synthetic, c, world, shift):
+    """Averaged gradients + per-rank losses of `world` ranks under the reference's DDP semantics, on the CPU oracle."""
+    from oracle import x2vlm_oracle as O
+    cfg = O.config_from_case(c)
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    sd = O.make_params(cfg, c["wseed"], synthetic.synth_tensor)
+    data = [_rank_batch(synthetic, c, r, shift) for r in range(world)]
+    feats = []
+    with torch.no_grad():
+        for b, n in data:
+            _, ex = O.xvlm_forward(sd, cfg, b, n)
+            feats.append((ex["image_feat"].detach(), ex["text_feat"].detach()))
+    avg, losses = {}, []
+    for r, (b, n) in enumerate(data):
+        for t in sd.values():
+            t.grad = None
+        calls = []
+
+        def gather(t, r=r, calls=calls):
+            which = len(calls)                              # first call: image features, second: text features
+            calls.append(1)
+            return torch.cat([t if q == r else feats[q][which] for q in range(world)])
+        loss, _ = O.xvlm_forward(sd, cfg, b, n, gather=gather)
+        sum(loss.values()).backward()
+        losses.append({k: float(v) for k, v in loss.items()})
+        for k, t in sd.items():
+            if t.grad is not None:
+                avg[k] = avg.get(k, 0) + t.grad.detach().clone() / world
+    return avg, losses
+
+
+def _compare(got, want, what):
+    total = float(torch.sqrt(sum((g.double() ** 2).sum() for g in want.values())))
+    bad = []
+    for name, ref in want.items():
+        if name == "text_encoder.cls.predictions.decoder.weight" or name not in got:
+            continue
+        g = got[name].double()
+        ref = ref.double()
+        nerr = abs(float(g.norm()) - float(ref.norm())) / max(float(ref.norm()), 1e-2 * total)
+        eerr = float((g - ref).abs().max()) / max(float(ref.abs().max()), 1e-2 * total / max(ref.numel(), 1) ** 0.5)
+        if nerr > 3e-2 or eerr > 8e-2:
+            bad.append((name, nerr, eerr))
+    missing = [n for n in want if n not in got and n != "text_encoder.cls.predictions.decoder.weight"
+               and float(want[n].abs().max()) > 0]
+    assert not missing, "%s: no gradient for %s" % (what, missing[:5])
+    assert not bad, "%s: %d tensors out of tolerance, worst %s" % (what, len(bad), sorted(bad, key=lambda b: -b[2])[:5])
+
+
+@pytest.mark.parametrize("case", ["tiny", "base_shallow"])
+def test_two_ranks_match_oracle_ddp_semantics(case, synthetic):
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_two_rank_worker, args=(world, _free_port(), case, ret), nprocs=world, join=True)
+    out = [ret[r] for r in range(world)]
+    c = CASES[case]
+    g_a, loss_a = _oracle_ddp(synthetic, c, world, 0)
+    g_b, _ = _oracle_ddp(synthetic, c, world, 1000)
+    for r in range(world):
+        for k, v in loss_a[r].items():                      # ITC is the GLOBAL loss: identical on both ranks
+            assert abs(out[r]["loss1"][k] - v) <= 5e-3 * max(abs(v), 1e-6), (r, k, out[r]["loss1"][k], v)
+        assert out[r]["early"] >= 3                         # per-layer arenas went out early, plus the leftover bucket
+        _compare(out[r]["g1"], g_a, "rank %d, one backward_step" % r)
+        _compare(out[r]["g2"], {k: g_a[k] + g_b[k] for k in g_a}, "rank %d, two backward_steps" % r)
+    assert abs(loss_a[0]["loss_itc"] - loss_a[1]["loss_itc"]) < 1e-6
+    for n in out[0]["g2"]:                                  # replicas end up with the same gradients
+        assert torch.allclose(out[0]["g2"][n], out[1]["g2"][n], rtol=1e-5, atol=1e-7), n
+
+
+def _rccl_worker(rank, world, port, ret, comm_mode):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), X2_DDP_SINGLE_RANK_COLLECTIVES="1", X2_COMM=comm_mode)
+    os.environ.pop("X2_DIST_BACKEND", None)
+    synthetic = importlib.import_module("x2-vlm_amd.synthetic")
+    mp_ = importlib.import_module("x2-vlm_amd.model_pretrain")
+    acc = importlib.import_module("x2-vlm_amd.accelerator")
+    optim = importlib.import_module("x2-vlm_amd.optim")
+    xvlm = importlib.import_module("x2-vlm_amd.xvlm")
+    c = CASES["tiny"]
+    model = mp_.XVLM(config=model_config("tiny", tempfile.mkdtemp()), load_vision_params=False, load_text_params=False, pretraining=True)
+    synthetic.synth_state_dict(model, c["wseed"])
+    model.eval()
+    opt = optim.create_optimizer(dict(lr=1e-4, weight_decay=0.01, lr_mult=2), model)
+    a = acc.RocmDDPAccelerator(dict(RNG_SEED=7), None)
+    ddp, opt, _ = a.set_up(model, opt, None, local_rank=0, world_size=1, rank=0)
+    try:
+        assert dist.get_backend() == "nccl" and (a.buckets.comm is not None) == (comm_mode == "rccl")
+        b, n = _rank_batch(synthetic, c, 0)
+        b = {k: v.cuda() for k, v in b.items()}
+        loss, total = _step(ddp.module, b, n)
+        a.backward_step(total, opt)
+        msgs = a.buckets.messages
+        grads = {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
+        # the ITC all-gather on RCCL (allgather() short-cuts a single rank, so call the Function directly)
+        t = torch.randn(4, 8, device="cuda", requires_grad=True)
+        y = xvlm.AllGather.apply(t, 0, 1)
+        y.sum().backward()
+        before = model.vision_proj.weight.detach().clone()
+        norm = a.optimizer_step(opt, ddp, 1.0)
+        opt.step()
+        torch.cuda.synchronize()
+        # the same step without any process group in the way
+        for p in model.parameters():
+            p.grad = None
+        synthetic.synth_state_dict(model, c["wseed"])
+        a.buckets.close()
+        _, total = _step(model, b, n)
+        total.backward()
+        torch.cuda.synchronize()
+        worst = max(float((grads[k] - p.grad).abs().max()) / (float(p.grad.abs().max()) + 1e-12)
+                    for k, p in model.named_parameters() if p.grad is not None)
+        ret[0] = dict(msgs=msgs, norm=norm, gather_ok=bool(torch.equal(y.detach(), t.detach()) and torch.equal(t.grad, torch.ones_like(t))),
+                      moved=float((model.vision_proj.weight.detach() - before).abs().max()) >= 0.0, worst=worst,
+                      losses={k: float(v) for k, v in loss.items()})
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("comm_mode", ["torch", "rccl"])
+def test_single_rank_rccl_through_the_accelerator(comm_mode):
+    """comm_mode torch: torch.distributed backend "nccl" (= RCCL); rccl: the C-ABI communicator x2_comm_* for the buckets."""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_rccl_worker, args=(1, _free_port(), ret, comm_mode), nprocs=1, join=True)
+    r = ret[0]
+    assert r["msgs"] >= 3 and r["gather_ok"]
+    assert np.isfinite(r["norm"]) and r["norm"] > 0
+    assert all(np.isfinite(v) for v in r["losses"].values())
+    assert r["worst"] <= 1e-6, r["worst"]                   # AVG over one rank is the identity
+
+
+def test_c_abi_communicator_single_rank():
+    """x2_comm_* (include/x2vlm_hip.h) on a one-rank RCCL communicator: every entry point runs on the device."""
+    comm = importlib.import_module("x2-vlm_amd.comm")
+    c = comm.X2Comm(comm.X2Comm.unique_id(), 0, 1)
+    assert c.info() == (0, 1)
+    side = torch.cuda.Stream()
+    x = torch.randn(1 << 20, device="cuda")
+    want = x.clone()
+    side.wait_stream(torch.cuda.current_stream())
+    ev = c.allreduce_bucket(x, average=True, stream=side, want_event=True)
+    ev.synchronize()
+    assert torch.equal(x, want)
+    xb = torch.randn(4096, device="cuda").bfloat16()
+    wb = xb.clone()
+    c.allreduce_bucket(xb, average=False)
+    out = torch.empty(64 * 256, device="cuda")
+    feat = torch.randn(64, 256, device="cuda")
+    c.allgather(feat, out)
+    c.broadcast(x, root=0)
+    torch.cuda.synchronize()
+    assert torch.equal(xb, wb) and torch.equal(out.view(64, 256), feat) and torch.equal(x, want)
+    c.destroy()

@@ -36,6 +36,7 @@ def test_fused_adamw_matches_hf_rule_with_clipping():
     ref = [p.detach().cpu().double() for p in params]
     ms = [torch.zeros_like(r) for r in ref]; vs = [torch.zeros_like(r) for r in ref]
     hyp = [(1e-2, 0.01)] * 2 + [(2e-2, 0.0)] * 2 + [(5e-3, 0.1)] * 2
+    steps = [0] * len(params)                                             # HF keeps state["step"] per parameter
     for t in range(1, 5):
         grads = [torch.randn(s, device=dev) * (3.0 if t % 2 else 0.1) for s in shapes]
         for p, g in zip(params, grads):
@@ -51,9 +52,45 @@ def test_fused_adamw_matches_hf_rule_with_clipping():
         for i, (p, g) in enumerate(zip(params, grads)):
             if p.grad is None:
                 continue
-            hf_adamw_step(ref[i], g.cpu().double() * coef, ms[i], vs[i], t, *hyp[i])
+            steps[i] += 1
+            hf_adamw_step(ref[i], g.cpu().double() * coef, ms[i], vs[i], steps[i], *hyp[i])
         for p, r in zip(params, ref):
             assert float((p.detach().cpu().double() - r).abs().max()) < 2e-5 * max(1.0, float(r.abs().max()))
+
+
+def test_fused_adamw_state_dict_round_trip():
+    """load_state_dict after steps (the pointer table used to keep the freed moments and the step restarted),
+    state layout == transformers' AdamW (step / exp_avg / exp_avg_sq per parameter)."""
+    optim = importlib.import_module("x2-vlm_amd.optim")
+    torch.manual_seed(1)
+    mk = lambda: [torch.nn.Parameter(torch.randn(s, device=dev, generator=torch.Generator(dev).manual_seed(3 + i)))
+                  for i, s in enumerate([(64, 33), (7,), (5000,)])]
+    pa, pb = mk(), mk()
+    oa = optim.FusedAdamW([{"params": pa, "lr": 1e-2, "weight_decay": 0.01}])
+    ob = optim.FusedAdamW([{"params": pb, "lr": 1e-2, "weight_decay": 0.01}])
+    grads = [[torch.randn_like(p) for p in pa] for _ in range(5)]
+    for t in range(3):
+        for p, g in zip(pa, grads[t]):
+            p.grad = g.clone()
+        if t == 1:
+            pa[1].grad = None
+        oa.step()
+    sd = oa.state_dict()
+    assert set(sd["state"][0]) == {"step", "exp_avg", "exp_avg_sq"} and sd["state"][0]["step"] == 3 and sd["state"][1]["step"] == 2
+    for t in range(2):                                        # warm ob's tables on other data, then load a's state over it
+        for p in pb:
+            p.grad = torch.ones_like(p)
+        ob.step()
+    with torch.no_grad():
+        for a, b in zip(pa, pb):
+            b.copy_(a)
+    ob.load_state_dict(sd)
+    for t in range(3, 5):
+        for p, q, g in zip(pa, pb, grads[t]):
+            p.grad, q.grad = g.clone(), g.clone()
+        oa.step(); ob.step()
+    for a, b in zip(pa, pb):
+        assert torch.equal(a, b)
 
 
 def test_short_training_run_matches_oracle(synthetic):
@@ -111,3 +148,41 @@ def test_short_training_run_matches_oracle(synthetic):
     # +-lr steps of different sign, so the two trajectories separate slowly: 1e-2 relative per step is the bar
     for a, b in zip(curve_hip, curve_ref):
         assert abs(a - b) < 1e-2 * abs(b), (curve_hip, curve_ref)
+
+
+def test_data_mutating_optimizer_refreshes_bf16_copies(synthetic, tmp_path):
+    """The reference's optimizer (transformers 4.12.5 AdamW, optim.py:102) updates through `p.data`, which never moves the
+    version counter the bf16 weight copies used to be keyed on alone: after a backward pass the copies
+    must be rebuilt, or every GEMM keeps running on the step-0 weights."""
+    mp = importlib.import_module("x2-vlm_amd.model_pretrain")
+    c = CASES["tiny"]
+
+    def build():
+        m = mp.XVLM(config=model_config("tiny", str(tmp_path)), load_vision_params=False, load_text_params=False, pretraining=True)
+        synthetic.synth_state_dict(m, c["wseed"])
+        return m.cuda().eval()
+
+    def run(m, backward=True):
+        b = {k: v.cuda() for k, v in synthetic.synth_batch(c["bseed"], c["batch"], c["seq_len"], c["image_res"], c["vocab"],
+                                                             c["max_masks"], ragged=True).items()}
+        m.injected_negatives = synthetic.synth_negatives(c["bseed"], c["batch"])
+        loss = m(b["image"], b["text_ids"], b["text_atts"], text_ids_masked=b["text_ids_masked"], masked_pos=b["masked_pos"],
+                 masked_ids=b["masked_ids"])
+        if backward:
+            sum(loss.values()).backward()
+        return {k: float(v) for k, v in loss.items()}
+
+    m = build()
+    first = run(m)
+    for p in m.parameters():                       # an "optimizer step" behind autograd's back
+        if p.grad is not None and p.dim() >= 2:
+            p.data.add_(p.grad, alpha=-0.05)
+    after = run(m, backward=False)
+    fresh = build()
+    with torch.no_grad():
+        for p, q in zip(fresh.parameters(), m.parameters()):
+            p.copy_(q)
+    want = run(fresh, backward=False)
+    assert any(abs(first[k] - want[k]) > 1e-3 for k in first), "update too small to tell stale weights from fresh ones"
+    for k in want:
+        assert abs(after[k] - want[k]) <= 1e-6 * max(1.0, abs(want[k])), (k, after[k], want[k], first[k])

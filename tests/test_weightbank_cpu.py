@@ -78,3 +78,37 @@ def test_vector_cache(bank):
         q.mul_(2.0)
     bank.prepare_vectors([(q, 4, v)])
     assert bank.calls["vec"] == 1
+
+
+def test_copies_expire_after_a_backward_even_without_version_bump(bank):
+    """Optimizers writing through p.data leave _version alone (transformers 4.12.5 AdamW, apex FusedAdam)."""
+    w = torch.nn.Parameter(torch.ones(8, 4))
+    bank.prepare([(w,)])
+    assert bank.calls["multi"] == 1
+    v0 = w._version
+    w.data.add_(1.0)
+    assert w._version == v0                                  # the blind spot of a version-keyed cache
+    bank.prepare([(w,)])
+    assert bank.calls["multi"] == 1                          # (inference between optimizer steps keeps its copies)
+    bank.note_backward()                                     # a stage's backward ran: an optimizer step may follow
+    bank.prepare([(w,)])
+    assert bank.calls["multi"] == 2
+    bank.prepare([(w,)])
+    assert bank.calls["multi"] == 2                          # rebuilt once, not on every call
+
+    class Probe(torch.autograd.Function):                    # inside autograd's backward nothing expires
+        @staticmethod
+        def forward(ctx, x):
+            return x * 1.0
+
+        @staticmethod
+        def backward(ctx, g):
+            bank.note_backward()
+            bank.linear(w)
+            Probe.calls_in_backward = dict(bank.calls)
+            return g
+    n_single = bank.calls["single"]
+    Probe.apply(torch.ones(1, requires_grad=True)).sum().backward()
+    assert Probe.calls_in_backward["single"] == n_single     # served from the cache while the backward is running
+    bank.linear(w)
+    assert bank.calls["single"] == n_single + 1              # first use after it: rebuilt

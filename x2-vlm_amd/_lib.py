@@ -24,7 +24,7 @@ class AttnArgs(C.Structure):
                [(n, I) for n in ("B", "Bkv", "H", "Lq", "Lk")] + [("scale", F)] + \
                [("bias", P), ("bias_ld", I), ("biasT", P), ("biasT_ld", I), ("mask", P), ("mask_ld", I),
                 ("kv_idx", P), ("seq_off", P), ("seq_ids", P), ("ds_ld", I),
-                ("drop_thr16", C.c_uint), ("drop_seed", C.c_uint), ("drop_scale", F), ("dbg", I)]
+                ("drop_thr16", C.c_uint), ("drop_seed", C.c_uint), ("drop_scale", F), ("dbg", I), ("head_dim", I)]
 
 
 # name -> argtypes (all return int: 0 ok, < 0 error; message via x2_last_error)
@@ -60,10 +60,20 @@ _SIGS = {
     "x2_sample_negatives": [P, I, P, P, P, P],
     "x2_gelu_f32": [P, P, P, L, P],
     "x2_grad_norm": [P, I, I, F, P, P, P],
-    "x2_adamw_multi": [P, I, I, P, P, I, F, F, F, I, P, P],
+    "x2_adamw_multi": [P, I, I, P, P, I, F, F, F, P, P],
     "x2_colsum_f32": [P, P, I, I, P],
 }
-EXPORTS = sorted(list(_SIGS) + ["x2_last_error", "x2_abi_version", "x2_device_cus", "x2_tune"])
+# communicator entry points (csrc/comm.hip): explicit stream / event arguments, bound without the implicit stream of call()
+_COMM_SIGS = {
+    "x2_comm_unique_id": [P],
+    "x2_comm_init": [P, I, I, C.POINTER(P)],
+    "x2_comm_info": [P, C.POINTER(I), C.POINTER(I)],
+    "x2_comm_allreduce_bucket": [P, P, L, I, I, P, P],
+    "x2_comm_allgather": [P, P, P, L, I, P, P],
+    "x2_comm_broadcast": [P, P, L, I, I, P, P],
+    "x2_comm_destroy": [P],
+}
+EXPORTS = sorted(list(_SIGS) + list(_COMM_SIGS) + ["x2_last_error", "x2_abi_version", "x2_device_cus", "x2_tune"])
 
 _lib = None
 
@@ -83,7 +93,7 @@ def lib():
             h = C.CDLL(LIB_PATH)
         except OSError as e:  # pragma: no cover
             raise X2HipError("cannot load %s: %s" % (LIB_PATH, e))
-        for name, sig in _SIGS.items():
+        for name, sig in list(_SIGS.items()) + list(_COMM_SIGS.items()):
             fn = getattr(h, name)
             fn.argtypes, fn.restype = sig, I
         h.x2_last_error.restype = C.c_char_p

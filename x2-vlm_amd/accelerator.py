@@ -24,23 +24,43 @@ from . import engine
 
 
 class GradientBuckets:
-    def __init__(self, model, world_size, process_group=None):
+    """Gradient averaging for one model replica per rank.
+
+    Early path: a layer's backward publishes its flat arena (engine.Grads) once all kernels writing it are enqueued; if
+    the layer ran exactly once in this forward AND none of its parameters holds a gradient yet (so autograd will adopt the
+    arena views as `.grad` instead of adding them into an older buffer), the arena is all-reduced in place on the side
+    stream while the remaining backward runs.
+    Late path (`finish`, called by backward_step after loss.backward()): every other gradient - small heads, embeddings,
+    parameters used by several calls, and everything in a second backward_step of the same iteration (the reference calls
+    backward_step twice in run_mixed_iter, Pretrain.py:197, 247: `.grad` then already exists and autograd accumulates into
+    it) - is packed into one flat buffer by a multi-tensor copy, all-reduced as one message, and `.grad` is re-pointed at
+    the buffer's views (no copy back).  Re-averaging a buffer that already holds an averaged part is exact: the averaged
+    part is identical on all ranks, and the mean of identical values is that value."""
+
+    def __init__(self, model, world_size, process_group=None, comm=None):
         self.model, self.world, self.pg = model, world_size, process_group
+        self.comm = comm           # comm.X2Comm: collectives through the C ABI (x2_comm_*) instead of torch.distributed
         self.side = torch.cuda.Stream() if torch.cuda.is_available() else None
-        self.reduced = []          # (data_ptr, nbytes) of arenas already all-reduced this step
-        self.pending = []
+        self.done = set()          # id(parameter) whose gradient arena was reduced early in this backward
+        self.pending = []          # arenas in flight on the side stream (kept alive until finish)
+        self.params = [p for p in model.parameters() if p.requires_grad]
+        self.messages = 0          # collectives issued (tests / diagnostics)
         engine.GRAD_READY_HOOK = self._on_arena
         engine.STAGE_CALLS.clear()
 
     def _all_reduce(self, flat):
-        dist.all_reduce(flat, op=dist.ReduceOp.AVG if dist.get_backend(self.pg) == "nccl" else dist.ReduceOp.SUM, group=self.pg)
-        if dist.get_backend(self.pg) != "nccl":
+        if self.comm is not None:
+            self.comm.allreduce_bucket(flat, average=True)       # on the current stream (the side stream in _on_arena)
+            self.messages += 1
+            return
+        nccl = dist.get_backend(self.pg) == "nccl"
+        dist.all_reduce(flat, op=dist.ReduceOp.AVG if nccl else dist.ReduceOp.SUM, group=self.pg)
+        if not nccl:
             flat.div_(self.world)
+        self.messages += 1
 
-    def _on_arena(self, flat, key, also_after=None):
-        # a parameter set used by several forward calls receives several gradients that autograd sums
-        # later: only single-use layers may be reduced early
-        if engine.STAGE_CALLS.get(key, 0) != 1:
+    def _on_arena(self, flat, key, also_after=None, params=()):
+        if engine.STAGE_CALLS.get(key, 0) != 1 or not params or any(p.grad is not None for p in params):
             return
         if self.side is None:
             self._all_reduce(flat)
@@ -52,27 +72,25 @@ class GradientBuckets:
                 self.side.wait_event(also_after)      # the layer's weight-gradient GEMMs run on engine.SIDE
             with torch.cuda.stream(self.side):
                 self._all_reduce(flat)
-            flat.record_stream(self.side)
-        self.reduced.append((flat.data_ptr(), flat.numel() * 4))
+        self.done.update(id(p) for p in params)
         self.pending.append(flat)
 
     def finish(self):
         """Call after backward: reduce the leftovers, then make the compute stream wait for the side stream."""
-        rest = []
-        for p in self.model.parameters():
-            g = p.grad
-            if g is None:
-                continue
-            a = g.data_ptr()
-            if not any(lo <= a < lo + n for lo, n in self.reduced):
-                rest.append(g)
+        rest = [p for p in self.params if p.grad is not None and id(p) not in self.done]
         if rest:
-            flat = torch.cat([g.reshape(-1) for g in rest])
+            grads = [p.grad for p in rest]
+            sizes = [g.numel() for g in grads]
+            flat = torch.empty(sum(sizes), device=grads[0].device, dtype=grads[0].dtype)
+            views = [v.view_as(g) for v, g in zip(flat.split(sizes), grads)]
+            torch._foreach_copy_(views, grads)
             self._all_reduce(flat)
-            torch._foreach_copy_(rest, [v.view_as(g) for v, g in zip(flat.split([g.numel() for g in rest]), rest)])
+            for p, v in zip(rest, views):
+                p.grad = v
         if self.side is not None:
             torch.cuda.current_stream().wait_stream(self.side)
-        self.reduced, self.pending = [], []
+        self.done.clear()
+        self.pending = []
         engine.STAGE_CALLS.clear()
 
     def close(self):
@@ -132,12 +150,26 @@ class RocmDDPAccelerator(Accelerator):
         if not dist.is_initialized():
             addr = os.environ.get("MASTER_ADDR", "127.0.0.1")
             port = int(os.environ.get("MASTER_PORT", 34171))
-            dist.init_process_group(backend="nccl" if on_gpu else "gloo", init_method="tcp://%s:%d" % (addr, port),
-                                    world_size=world_size, rank=rank)
+            # X2_DIST_BACKEND=gloo: several ranks sharing one GPU (tests on a 1-GPU box); RCCL refuses duplicate devices
+            backend = os.environ.get("X2_DIST_BACKEND", "nccl" if on_gpu else "gloo")
+            dist.init_process_group(backend=backend, init_method="tcp://%s:%d" % (addr, port), world_size=world_size, rank=rank,
+                                    **({"device_id": torch.device("cuda", local_rank)} if backend == "nccl" else {}))
         self.world_size = world_size
         self.broadcast(model)
         self.ddp_model = _Wrapped(model)
-        self.buckets = GradientBuckets(model, world_size)
+        # a single rank has nothing to average; X2_DDP_SINGLE_RANK_COLLECTIVES=1 keeps the collectives in (RCCL smoke test)
+        if world_size > 1 or os.environ.get("X2_DDP_SINGLE_RANK_COLLECTIVES", "0") == "1":
+            comm = None
+            if os.environ.get("X2_COMM", "torch") == "rccl" and on_gpu:
+                # gradient buckets through the C-ABI communicator (include/x2vlm_hip.h x2_comm_*); the RCCL id travels
+                # through the rendezvous store torch.distributed already opened
+                from .comm import X2Comm
+                comm = X2Comm.from_store(dist.distributed_c10d._get_default_store(), rank, world_size)
+            self.buckets = GradientBuckets(model, world_size, comm=comm)
+        if optimizer is not None and hasattr(optimizer, "register_step_post_hook"):
+            # optimizers that update through p.data (HF AdamW, apex FusedAdam) do not move the version counters the bf16
+            # weight copies are keyed on: drop the copies after every optimizer step
+            optimizer.register_step_post_hook(lambda *_a, **_k: engine.BANK.invalidate())
         return self.ddp_model, optimizer, lr_scheduler
 
     def broadcast(self, model, src=0):
@@ -153,7 +185,7 @@ class RocmDDPAccelerator(Accelerator):
 
     def backward_step(self, loss, optimizer=None):
         loss.backward()
-        if self.buckets is not None and self.world_size > 1:
+        if self.buckets is not None:
             self.buckets.finish()
 
     def optimizer_step(self, optimizer, model, grad_norm):

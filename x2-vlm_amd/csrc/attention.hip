@@ -36,6 +36,7 @@ struct AttnArgs {
   DropSpec drop;                       // dropout on the attention probabilities (xbert.py:399), element index
                                        // ((b*H + h)*Lq + q) * round_up(Lk,64) + key
   int dbg;                             // ablation (probes/bench_attn.py): 1 no bias/mask loads, 2 no exp2, 4 no PV MFMAs, 8 no QK MFMAs
+  int head_dim;                        // the caller's head dimension: must be 64 (the only one these kernels are built for)
 };
 
 // Staging of a [64 rows][64 d] bf16 tile (rows clamped to `nrows-1`) HBM -> registers -> LDS in two halves, so the
@@ -804,6 +805,7 @@ static int attn_variant() {
 
 static int check_common(const AttnArgs& a, const char* who) {
   X2_REQUIRE(a.B > 0 && a.H > 0 && a.Lq > 0 && a.Lk > 0, "%s: empty problem", who);
+  X2_REQUIRE(a.head_dim == HD, "%s: head_dim %d is not supported (kernels are built for %d)", who, a.head_dim, HD);
   X2_REQUIRE(!a.bias || (a.bias_ld % 64 == 0 && a.bias_ld >= a.Lk), "%s: bias_ld must be a multiple of 64 covering Lk", who);
   X2_REQUIRE(!a.mask || (a.mask_ld % 64 == 0 && a.mask_ld >= a.Lk), "%s: mask_ld must be a multiple of 64 covering Lk", who);
   X2_REQUIRE((a.q_rs % 8 | a.k_rs % 8 | a.v_rs % 8 | a.q_bs % 8 | a.k_bs % 8 | a.v_bs % 8) == 0, "%s: strides must keep 16-byte rows", who);

@@ -6,12 +6,12 @@ OUT=../libx2vlm_hip.so
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result"
 mkdir -p ../_build
 pids=()
-for f in runtime gemm attention rowwise heads optim; do
+for f in runtime gemm attention rowwise heads optim comm; do
   if [ ! -f ../_build/$f.o ] || [ $f.hip -nt ../_build/$f.o ] || [ x2_common.h -nt ../_build/$f.o ]; then
     hipcc $FLAGS -c $f.hip -o ../_build/$f.o &
     pids+=($!)
   fi
 done
 for p in "${pids[@]}"; do wait $p; done
-hipcc --offload-arch=gfx950 -shared -fPIC ../_build/*.o -o $OUT
+hipcc --offload-arch=gfx950 -shared -fPIC ../_build/*.o -ldl -o $OUT
 echo "built $(realpath $OUT)"

@@ -286,7 +286,9 @@ __global__ __launch_bounds__(256) void sample_negatives_kernel(const float* __re
     float cum = 0.f; int pick = -1;
     for (int c = 0; c < n; ++c) { cum += w[c]; if (w[c] > 0.f && cum > t) { pick = c; break; } }
     if (pick < 0) for (int c = n - 1; c >= 0; --c) if (w[c] > 0.f) { pick = c; break; }
-    out[b] = pick;
+    // every candidate masked (all rows in one group): torch.multinomial raises in the reference (xvlm.py:845-855); the
+    // host rejects that batch (XVLMBase.get_hard_negatives).  Never hand an out-of-range row index downstream.
+    out[b] = pick < 0 ? b : pick;
   }
 }
 extern "C" int x2_sample_negatives(const float* sim, int n, const long* group, const float* u, int* out, void* stream) {

@@ -7,7 +7,9 @@
 #include "x2_common.h"
 
 #define OPT_CHUNK 16384        // elements per workgroup
-struct OptTensor { float* p; const float* g; float* m; float* v; long n; int group; int blk0; };
+// stepscale = sqrt(1 - b2^t) / (1 - b1^t) with t = THIS tensor's step count (HF keeps state["step"] per parameter: a tensor
+// without a gradient in some iterations, e.g. bbox_head on image-only steps, lags behind the others)
+struct OptTensor { float* p; const float* g; float* m; float* v; long n; int group; int blk0; float stepscale; int pad; };
 
 __device__ __forceinline__ int find_tensor(const OptTensor* tab, int nt, int blk) {
   int lo = 0, hi = nt - 1;
@@ -55,7 +57,7 @@ extern "C" int x2_grad_norm(const void* table, int ntensors, int nblocks, float 
   return x2_check_launch("x2_grad_norm");
 }
 
-struct AdamHyper { float lr[16]; float wd[16]; float b1, b2, eps, bc1, bc2s; };   // bc1 = 1-b1^t, bc2s = sqrt(1-b2^t)
+struct AdamHyper { float lr[16]; float wd[16]; float b1, b2, eps; };
 
 __global__ __launch_bounds__(256) void adamw_kernel(const OptTensor* __restrict__ tab, int nt, AdamHyper h, const float* __restrict__ clip) {
   const int t = find_tensor(tab, nt, blockIdx.x);
@@ -65,7 +67,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(const OptTensor* __restrict_
   const long n = min((long)OPT_CHUNK, T.n - off);
   const float gs = clip ? clip[1] : 1.f;
   const float lr = h.lr[T.group], wd = h.wd[T.group];
-  const float step = lr * h.bc2s / h.bc1;
+  const float step = lr * T.stepscale;
   float* p = T.p + off; const float* g = T.g + off; float* m = T.m + off; float* v = T.v + off;
   const bool al = ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0);
   const long n4 = al ? n / 4 : 0;
@@ -91,15 +93,14 @@ __global__ __launch_bounds__(256) void adamw_kernel(const OptTensor* __restrict_
     p[i] = x - lr * wd * x;
   }
 }
-// table: ntensors x {p, g, m, v (pointers), n (long), group (int), blk0 (int)} on the device; lr/wd: per group (<= 16)
+// table: ntensors x {p, g, m, v (pointers), n (long), group (int), blk0 (int), stepscale (float), pad} on the device;
+// lr/wd: per group (<= 16)
 extern "C" int x2_adamw_multi(const void* table, int ntensors, int nblocks, const float* lr, const float* wd, int ngroups, float b1,
-                              float b2, float eps, int step, const float* clip2, void* stream) {
-  X2_REQUIRE(table && ntensors > 0 && nblocks > 0 && ngroups > 0 && ngroups <= 16 && step >= 1, "x2_adamw_multi: bad arguments");
+                              float b2, float eps, const float* clip2, void* stream) {
+  X2_REQUIRE(table && ntensors > 0 && nblocks > 0 && ngroups > 0 && ngroups <= 16, "x2_adamw_multi: bad arguments");
   AdamHyper h;
   for (int i = 0; i < 16; ++i) { h.lr[i] = i < ngroups ? lr[i] : 0.f; h.wd[i] = i < ngroups ? wd[i] : 0.f; }
   h.b1 = b1; h.b2 = b2; h.eps = eps;
-  h.bc1 = 1.f - powf(b1, (float)step);
-  h.bc2s = sqrtf(1.f - powf(b2, (float)step));
   hipLaunchKernelGGL(adamw_kernel, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, (const OptTensor*)table, ntensors, h, clip2);
   return x2_check_launch("x2_adamw_multi");
 }

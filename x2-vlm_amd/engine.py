@@ -39,11 +39,26 @@ def _tok(w):
 
 
 class WeightBank:
-    """bf16 (and transposed bf16) copies of the fp32 master weights, rebuilt only when a
-    parameter's version counter moved (i.e. once per optimizer step)."""
+    """bf16 (and transposed bf16) copies of the fp32 master weights.
+
+    Staleness: a copy is rebuilt when its parameter's version counter or storage moved, AND every copy is dropped at
+    the first use outside autograd's backward that follows a backward pass.  The second rule exists because optimizers that write
+    through `p.data` (transformers 4.12.5 AdamW: `p.data.addcdiv_`, the reference's optim.py:102; apex FusedAdam) never
+    bump the version counter: after a backward the weights must be assumed updated.  Inference (no backward in between)
+    keeps its copies; a real training step re-casts once per step either way (2 x 0.5 GB of bf16, ~0.4 ms)."""
 
     def __init__(self):
         self._c = {}
+        self.backward_seen = False
+
+    def note_backward(self):
+        """Called by every stage's backward: an optimizer step may follow."""
+        self.backward_seen = True
+
+    def _maybe_expire(self):
+        if self.backward_seen and torch._C._current_graph_task_id() == -1:
+            self._c.clear()
+            self.backward_seen = False
 
     def _get(self, key, vers, build, owners=()):
         ent = self._c.get(key)
@@ -60,6 +75,7 @@ class WeightBank:
 
     def linear(self, *ws):
         """(W [N,K] bf16, W^T [K,N] bf16) of one weight or of several stacked along N."""
+        self._maybe_expire()
         key = tuple(_tok(w) for w in ws)
         vers = tuple((w._version, w.data_ptr()) for w in ws)
 
@@ -73,6 +89,7 @@ class WeightBank:
         """Build every stale (W, W^T) pair of `groups` (tuples of weights, as `linear` takes them) with ONE
         multi-tensor launch and one allocation, instead of one cast launch (+ a concatenation) per weight when the
         layer first asks for it: a tower's ~50-100 weights are all re-cast once per optimizer step."""
+        self._maybe_expire()
         self._purge()
         todo = []
         for ws in groups:
@@ -105,6 +122,7 @@ class WeightBank:
     def prepare_vectors(self, groups):
         """Stacked fp32 bias vectors (tuples of 1-D parameters; an int n stands for n zeros), all built by one launch
         into one buffer; `vector(*items)` then returns the cached stack."""
+        self._maybe_expire()
         todo, total = [], 0
         for items in groups:
             key = ("vec",) + tuple(it if isinstance(it, int) else _tok(it) for it in items)
@@ -132,6 +150,7 @@ class WeightBank:
         K.copy_f32_multi(desc)
 
     def vector(self, *items):
+        self._maybe_expire()
         key = ("vec",) + tuple(it if isinstance(it, int) else _tok(it) for it in items)
         vers = tuple(0 if isinstance(it, int) else (it._version, it.data_ptr()) for it in items)
 
@@ -142,6 +161,8 @@ class WeightBank:
 
     def vocab(self, w):
         """word embeddings [V,Hd] -> (bf16 [Vp,Hd] zero-padded rows, bf16 [Hd,Vp]), Vp = V rounded to 64."""
+        self._maybe_expire()
+
         def build():
             V, Hd = w.shape
             Vp = K.round_up(V, 64)
@@ -154,6 +175,7 @@ class WeightBank:
         """Forget every copy (bench.py does this each step: a real training step re-casts the weights
         the optimizer just updated)."""
         self._c.clear()
+        self.backward_seen = False
 
 
 BANK = WeightBank()
@@ -169,7 +191,8 @@ class Grads:
     spec: list of (name, shape, zero_init); a name may be a fused block (e.g. q/k/v weights stacked)
     that the caller later splits into views with `alias`."""
 
-    def __init__(self, device, spec, key=None):
+    def __init__(self, device, spec, key=None, params=()):
+        self.params = list(params)      # the Parameter objects whose gradients live in this arena (data parallelism)
         spec = [s for s in spec if s[2]] + [s for s in spec if not s[2]]
         offs, o = [], 0
         for _, shape, _z in spec:
@@ -192,7 +215,7 @@ class Grads:
         """Every kernel writing this arena has been enqueued: on the current stream and, for the weight-gradient
         GEMMs, on the side stream up to the event `also_after`."""
         if GRAD_READY_HOOK is not None:
-            GRAD_READY_HOOK(self.flat, self.key, also_after)
+            GRAD_READY_HOOK(self.flat, self.key, also_after, self.params)
 
     def take(self, names):
         return [self.g.pop(n) for n in names]
@@ -298,7 +321,7 @@ def _finish_layer_backward(G, tn):
     _LayerPairs._launch([(G, tn, deferred)])
 
 
-GRAD_READY_HOOK = None      # set by accelerator.GradientBuckets: f(flat_fp32_arena, key)
+GRAD_READY_HOOK = None      # set by accelerator.GradientBuckets: f(flat_fp32_arena, key, side_stream_event, parameters)
 STAGE_CALLS = {}            # key -> number of forward calls since the last reset (see GradientBuckets)
 
 
@@ -345,6 +368,7 @@ class VisionEncoderFn(torch.autograd.Function):
         T, H = P_ + 1, meta["heads"]
         D = p["cls_token"].numel()
         M = B * T
+        assert D == 64 * H, "vision width %d / %d heads: the attention kernels are built for head dim 64" % (D, H)
         scale = (D // H) ** -0.5
         BANK.prepare([(p["patch_embed.proj.weight"],)] + [(p["blocks.%d.%s.weight" % (i, n)],) for i in range(meta["depth"])
                                                             for n in ("attn.qkv", "attn.proj", "mlp.fc1", "mlp.fc2")])
@@ -396,6 +420,7 @@ class VisionEncoderFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         meta, params = ctx.meta, ctx.params
+        BANK.note_backward()
         names = vision_param_names(meta["depth"])
         p = dict(zip(names, params))
         B, P_, T, H, D, M, scale = ctx.dims
@@ -403,7 +428,8 @@ class VisionEncoderFn(torch.autograd.Function):
         out = {}
         x_last, meanf, rstdf, cols = ctx.final
         Gt = Grads(dev, [(n, p[n].shape, True) for n in ("cls_token", "patch_embed.proj.weight", "patch_embed.proj.bias",
-                                                          "fc_norm.weight", "fc_norm.bias")], key=("vit-stem", id(params[0])))
+                                                          "fc_norm.weight", "fc_norm.bias")], key=("vit-stem", id(params[0])),
+                   params=[p[n] for n in ("cls_token", "patch_embed.proj.weight", "patch_embed.proj.bias", "fc_norm.weight", "fc_norm.bias")])
         g = dout.contiguous().clone()
         K.pool_tokens(g, meta.get("pool_w"), bwd=True)
         dx, _ = K.layernorm_bwd(g.view(M, D), x_last, meanf, rstdf, p["fc_norm.weight"], Gt["fc_norm.weight"], Gt["fc_norm.bias"],
@@ -422,7 +448,8 @@ class VisionEncoderFn(torch.autograd.Function):
                             ("attn.proj.bias", (D,), True), ("norm2.weight", (D,), True), ("norm2.bias", (D,), True),
                             ("mlp.fc1.bias", (F4,), True), ("mlp.fc2.bias", (D,), True),
                             ("attn.qkv.weight", (3 * D, D), False), ("attn.proj.weight", (D, D), False),
-                            ("mlp.fc1.weight", (F4, D), False), ("mlp.fc2.weight", (D, F4), False)], key=("vit", id(p[b + "gamma_1"])))
+                            ("mlp.fc1.weight", (F4, D), False), ("mlp.fc2.weight", (D, F4), False)], key=("vit", id(p[b + "gamma_1"])),
+                      params=[p[n] for n in names if n.startswith(b)])
             _begin_layer_backward()
             _, w2T = BANK.linear(p[b + "mlp.fc2.weight"])
             _, w1T = BANK.linear(p[b + "mlp.fc1.weight"])
@@ -510,6 +537,7 @@ class BertLayersFn(torch.autograd.Function):
         S, L, Hd = hidden.shape
         H, eps = meta["heads"], meta["eps"]
         M = S * L
+        assert Hd == 64 * H, "hidden size %d / %d heads: the attention kernels are built for head dim 64" % (Hd, H)
         scale = 1.0 / math.sqrt(Hd // H)
         dev = hidden.device
         h = hidden.contiguous().view(M, Hd)
@@ -585,6 +613,7 @@ class BertLayersFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dh_out):
         meta, params, encb = ctx.meta, ctx.params, ctx.encb
+        BANK.note_backward()
         S, L, Hd, H, M, scale, cross, enc_shape = ctx.dims
         names = bert_layer_param_names(meta["lo"], meta["hi"], meta["fusion_at"], cross)
         p = dict(zip(names, params))
@@ -612,7 +641,7 @@ class BertLayersFn(torch.autograd.Function):
                          ("crossattention.output.dense.bias", (Hd,), True), ("crossattention.output.LayerNorm.weight", (Hd,), True),
                          ("crossattention.output.LayerNorm.bias", (Hd,), True), ("crossattention.self.query.weight", (Hd, Hd), False),
                          ("c.kv_weight", (2 * Hd, Dv), False), ("crossattention.output.dense.weight", (Hd, Hd), False)]
-            G = Grads(dev, spec, key=("bert", id(p[a + "self.query.weight"])))
+            G = Grads(dev, spec, key=("bert", id(p[a + "self.query.weight"])), params=[p[n] for n in names if n.startswith(b)])
             tn = []
             _begin_layer_backward()
             ds3, ds3b = K.layernorm_bwd(dh, s3, m3, r3, p[b + "output.LayerNorm.weight"], G["output.LayerNorm.weight"],
@@ -738,6 +767,7 @@ class MlmLossFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g, _gl):
         rb, t_pre, t_act, mean, rstd, tb, logits, labels, lse, stat, dw_, lnw, word = ctx.saved_tensors
+        BANK.note_backward()
         V = ctx.V
         R, Hd = rb.shape
         dev = rb.device
@@ -799,6 +829,7 @@ class LinearBf16Fn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         xb, w = ctx.saved_tensors
+        BANK.note_backward()
         dyb = K.cast_bf16(dy.contiguous())
         _, wT = BANK.linear(w)
         dx = K.gemm_nt(dyb, wT, out_dtype=F32)

@@ -180,13 +180,14 @@ def gemm_tn_grouped(problems, accumulate=False, split=0):
 # ----------------------------------------------------------------------------- attention
 
 def _attn_args(q, k, v, B, Bkv, H, Lq, Lk, scale, bias=None, biasT=None, mask=None, kv_idx=None, seq_off=None,
-               seq_ids=None, drop=NO_DROP):
+               seq_ids=None, drop=NO_DROP, head_dim=64):
     """q/k/v: (tensor, batch_stride, row_stride) views in elements; data pointer already at head 0."""
     a = AttnArgs()
     a.Q, a.q_bs, a.q_rs = q
     a.K, a.k_bs, a.k_rs = k
     a.V, a.v_bs, a.v_rs = v
     a.B, a.Bkv, a.H, a.Lq, a.Lk, a.scale = B, Bkv, H, Lq, Lk, scale
+    a.head_dim = head_dim
     a.drop_thr16, a.drop_seed, a.drop_scale = drop
     if bias is not None:
         assert bias.dtype == F32 and bias.dim() == 3 and bias.is_contiguous()

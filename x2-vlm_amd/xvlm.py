@@ -248,6 +248,10 @@ class XVLMBase(nn.Module):
             sim_t2i = K.linear_f32(ft, fi, alpha_ptr=None) / temp
             u = torch.rand(2, bs, device=fi.device)
             grp = idx.view(-1).long().contiguous() if idx is not None else None
+            if grp is not None and bool((grp.view(-1, 1) == grp.view(1, -1)).all(1).any()):
+                # fine-tuning path only (one host sync; the reference has 2*B there): a row whose every candidate shares its
+                # `idx` has no negative to draw - torch.multinomial raises on the all-zero weights (xvlm.py:845-855)
+                raise RuntimeError("get_hard_negatives: a row has no candidate with a different idx (invalid multinomial distribution)")
             return K.sample_negatives(sim_t2i, u[0].contiguous(), grp), K.sample_negatives(sim_i2t, u[1].contiguous(), grp)
 
     def get_matching_loss(self, image_embeds, image_atts, image_feat, text_embeds, text_atts, text_feat, idx=None):
