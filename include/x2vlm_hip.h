@@ -23,7 +23,7 @@ extern "C" {
 #endif
 
 const char* x2_last_error(void);
-int x2_abi_version(void);          /* == 2 */
+int x2_abi_version(void);          /* == 3 */
 int x2_device_cus(void);           /* compute units of the current HIP device, 0 if none */
 int x2_tune(int key, int value);   /* kernel-variant knobs for probes/ and tests (0 = automatic); keys listed in csrc/gemm.hip */
 
@@ -43,11 +43,14 @@ int x2_tune(int key, int value);   /* kernel-variant knobs for probes/ and tests
  * Dropout everywhere in this ABI: element e of a site is dropped iff u16(hash(e >> 1 ^ seed), e & 1) < thr16
  * (thr16 = round(p * 65536), 0 = off); survivors are multiplied by `scale`.  The backward regenerates the mask
  * from the same (thr16, seed, scale); kernels.dropout_keep() is the host mirror.
+ * drop_epoch (every dropout-capable entry point): NULL, or a device word holding a step counter that is mixed into the
+ * seed (seed' = hash(seed + 0x9E3779B1 * *drop_epoch)): a hipGraph-captured step, whose kernel arguments are frozen,
+ * increments the word once per replay and so draws new masks on every step.
  *   C = out_f32 ? float : bf16.  Forward linears pass B = W (N x K); input gradients pass B = W^T. */
 int x2_gemm_nt(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
                const float* bias, const float* gamma, const float* resid, int ldr, void* aux, int ldaux,
-               int act, int out_f32, unsigned drop_thr16, unsigned drop_seed, float drop_scale, const float* rowscale,
-               float* colsum, void* stream);      /* colsum[n] += sum_m C[m,n] (fused bias gradient), NULL = off */
+               int act, int out_f32, unsigned drop_thr16, unsigned drop_seed, float drop_scale, const unsigned* drop_epoch,
+               const float* rowscale, float* colsum, void* stream);      /* colsum[n] += sum_m C[m,n] (fused bias gradient), NULL = off */
 
 /* Weight gradients of one layer in one launch: for each problem  dW[N,K] (+)= dY[Mc,N]^T . X[Mc,K]  (fp32 out).
  * problems: count (<= 8) rows of 11 int64 {dY, X, dW, Mc, N, K, ld_dY, ld_X, ld_dW, n_ld, k_ld}; n_ld / k_ld are
@@ -82,6 +85,7 @@ typedef struct X2AttnArgs {
                                                           element = ((b*H + h)*Lq + q) * round_up(Lk,64) + key */
   int dbg;                                           /* 0; ablation switches for probes/bench_attn.py */
   int head_dim;                                      /* hidden / heads of the caller: must be 64, checked */
+  const unsigned* drop_epoch;                        /* device step counter mixed into drop_seed, or NULL */
 } X2AttnArgs;
 int x2_attn_fwd(const X2AttnArgs* args, void* stream);
 int x2_attn_bwd(const X2AttnArgs* args, void* stream);   /* dQ (+dS, Delta) then dK/dV; no atomics */
@@ -92,13 +96,14 @@ int x2_attn_bwd(const X2AttnArgs* args, void* stream);   /* dQ (+dS, Delta) then
  * fc_norm over patches (beit2.py:409-411). */
 int x2_layernorm_fwd(const float* x, const float* w, const float* b, void* y_bf16, float* y_f32, float* mean,
                      float* rstd, int rows, int D, float eps, int period, unsigned drop_thr16, unsigned drop_seed,
-                     float drop_scale, void* stream);                /* drop: dropout on the LN output (xbert.py:215) */
+                     float drop_scale, const unsigned* drop_epoch, void* stream);   /* drop: dropout on the LN output (xbert.py:215) */
 /* g = LN'(mask_in(dy)); dx = dres + g (fp32); dx_bf16 = mask_out(g); dw += , db += ; dcol += column sums of mask_out(g)
  * (= gradient and bias gradient of the linear whose dropped output was added to the residual before this LN) */
 int x2_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* w,
                      const float* dres, float* dx, void* dx_bf16, float* dw, float* db, float* dcol, int rows, int D,
                      int period, unsigned in_thr16, unsigned in_seed, float in_scale, unsigned out_thr16,
-                     unsigned out_seed, float out_scale, float* ws /* [ceil(rows/16)][3][D] */, int defer, void* stream);
+                     unsigned out_seed, float out_scale, const unsigned* drop_epoch, float* ws /* [ceil(rows/16)][3][D] */,
+                     int defer, void* stream);
 /* Column reductions are two-stage (per-workgroup partial rows in the caller's workspace `ws`, then a deterministic
  * add): fp32 atomics measured ~43 G adds/s on MI355X, slower than the HBM traffic of these kernels. */
 int x2_colsum_bf16(const void* y, float* out, int M, int N, int ld, float* ws /* [ceil(M/64)][N] */, int defer, void* stream);

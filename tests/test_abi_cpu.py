@@ -29,23 +29,23 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(h, name), "include/x2vlm_hip.h declares %s but libx2vlm_hip.so does not export it" % name
     assert sorted(lib.EXPORTS) == declared, set(lib.EXPORTS) ^ set(declared)
-    assert lib.lib().x2_abi_version() == 2
+    assert lib.lib().x2_abi_version() == 3
 
 
 def test_attn_args_struct_matches_header_layout():
     lib = importlib.import_module("x2-vlm_amd._lib")
     # 12 pointers + 16 longs + 5 ints + float + 3 x (pointer, int, pad) + 3 pointers + int (+pad)
-    assert ctypes.sizeof(lib.AttnArgs) == 12 * 8 + 16 * 8 + 6 * 4 + 3 * 16 + 3 * 8 + 24   # ds_ld, 3 dropout words, dbg (+pad)
+    assert ctypes.sizeof(lib.AttnArgs) == 12 * 8 + 16 * 8 + 6 * 4 + 3 * 16 + 3 * 8 + 24 + 8   # ds_ld, 3 dropout words, dbg, head_dim, epoch pointer
     assert lib.AttnArgs.bias.offset == 248 and lib.AttnArgs.kv_idx.offset == 296 and lib.AttnArgs.ds_ld.offset == 320
-    assert lib.AttnArgs.drop_thr16.offset == 324 and lib.AttnArgs.dbg.offset == 336 and lib.AttnArgs.head_dim.offset == 340
+    assert lib.AttnArgs.drop_thr16.offset == 324 and lib.AttnArgs.dbg.offset == 336 and lib.AttnArgs.head_dim.offset == 340 and lib.AttnArgs.drop_epoch.offset == 344
 
 
 def test_argument_checks_fail_loudly_without_launching():
     lib = importlib.import_module("x2-vlm_amd._lib")
     h = lib.lib()
-    rc = h.x2_gemm_nt(None, None, None, 128, 128, 100, 100, 100, 128, None, None, None, 0, None, 0, 0, 0, 0, 0, 1.0, None, None, None)
+    rc = h.x2_gemm_nt(None, None, None, 128, 128, 100, 100, 100, 128, None, None, None, 0, None, 0, 0, 0, 0, 0, 1.0, None, None, None, None)
     assert rc == -1 and b"multiple of 64" in h.x2_last_error()
-    rc = h.x2_layernorm_fwd(None, None, None, None, None, None, None, 4, 770, 1e-6, 0, 0, 0, 1.0, None)
+    rc = h.x2_layernorm_fwd(None, None, None, None, None, None, None, 4, 770, 1e-6, 0, 0, 0, 1.0, None, None)
     assert rc == -1 and b"x2_layernorm_fwd" in h.x2_last_error()
     rc = h.x2_sample_negatives(None, 5000, None, None, None, None)
     assert rc == -1

@@ -1,6 +1,7 @@
 """Fused multi-tensor AdamW + clip (x2-vlm_amd/optim.py) against the HuggingFace AdamW update rule the reference uses
 (transformers==4.12.5, optim.py:102), and a short training run of the tiny model: HIP step + fused optimizer vs the
 CPU oracle + the same rule -- the loss curves must coincide."""
+import copy
 import importlib
 import math
 import tempfile
@@ -75,7 +76,7 @@ def test_fused_adamw_state_dict_round_trip():
         if t == 1:
             pa[1].grad = None
         oa.step()
-    sd = oa.state_dict()
+    sd = copy.deepcopy(oa.state_dict())        # torch's load_state_dict does not copy tensors already on the right device
     assert set(sd["state"][0]) == {"step", "exp_avg", "exp_avg_sq"} and sd["state"][0]["step"] == 3 and sd["state"][1]["step"] == 2
     for t in range(2):                                        # warm ob's tables on other data, then load a's state over it
         for p in pb:

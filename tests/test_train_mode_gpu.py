@@ -47,6 +47,16 @@ def test_keep_rate_and_host_mirror(mods):
     idx = torch.arange(M).unsqueeze(1) * N + torch.arange(N).unsqueeze(0)
     ref = (A.float().cpu() @ B.float().cpu().t()) * K.dropout_keep(spec, idx)
     assert torch.equal(out, ref)
+    # device-resident epoch (hipGraph replays): same kernel arguments, the mask follows the counter in device memory
+    epoch = torch.tensor([5], dtype=torch.int32, device=dev)
+    spec_e = spec[:3] + (epoch,)
+    outs = []
+    for e in (5, 6, 5):
+        epoch.fill_(e)
+        o = K.gemm_nt(A, B, out_dtype=torch.float32, drop=spec_e).cpu()
+        assert torch.equal(o, (A.float().cpu() @ B.float().cpu().t()) * K.dropout_keep(spec_e, idx))
+        outs.append(o)
+    assert torch.equal(outs[0], outs[2]) and not torch.equal(outs[0], outs[1]) and not torch.equal(outs[0], out)
 
 
 def test_bert_layers_with_dropout_match_oracle_with_same_masks(mods, synthetic):

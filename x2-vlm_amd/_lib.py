@@ -24,17 +24,17 @@ class AttnArgs(C.Structure):
                [(n, I) for n in ("B", "Bkv", "H", "Lq", "Lk")] + [("scale", F)] + \
                [("bias", P), ("bias_ld", I), ("biasT", P), ("biasT_ld", I), ("mask", P), ("mask_ld", I),
                 ("kv_idx", P), ("seq_off", P), ("seq_ids", P), ("ds_ld", I),
-                ("drop_thr16", C.c_uint), ("drop_seed", C.c_uint), ("drop_scale", F), ("dbg", I), ("head_dim", I)]
+                ("drop_thr16", C.c_uint), ("drop_seed", C.c_uint), ("drop_scale", F), ("dbg", I), ("head_dim", I), ("drop_epoch", P)]
 
 
 # name -> argtypes (all return int: 0 ok, < 0 error; message via x2_last_error)
 _SIGS = {
-    "x2_gemm_nt": [P, P, P, I, I, I, I, I, I, P, P, P, I, P, I, I, I, U, U, F, P, P, P],
+    "x2_gemm_nt": [P, P, P, I, I, I, I, I, I, P, P, P, I, P, I, I, I, U, U, F, P, P, P, P],
     "x2_gemm_tn_grouped": [P, I, I, I, P, L, P],
     "x2_attn_fwd": [C.POINTER(AttnArgs), P],
     "x2_attn_bwd": [C.POINTER(AttnArgs), P],
-    "x2_layernorm_fwd": [P, P, P, P, P, P, P, I, I, F, I, U, U, F, P],
-    "x2_layernorm_bwd": [P, P, P, P, P, P, P, P, P, P, P, I, I, I, U, U, F, U, U, F, P, I, P],
+    "x2_layernorm_fwd": [P, P, P, P, P, P, P, I, I, F, I, U, U, F, P, P],
+    "x2_layernorm_bwd": [P, P, P, P, P, P, P, P, P, P, P, I, I, I, U, U, F, U, U, F, P, P, I, P],
     "x2_colsum_bf16": [P, P, I, I, I, P, I, P],
     "x2_reduce_partials": [P, I, I, I, P, P, P, P],
     "x2_reduce_partials_multi": [P, I, P],

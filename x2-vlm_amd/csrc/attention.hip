@@ -37,6 +37,7 @@ struct AttnArgs {
                                        // ((b*H + h)*Lq + q) * round_up(Lk,64) + key
   int dbg;                             // ablation (probes/bench_attn.py): 1 no bias/mask loads, 2 no exp2, 4 no PV MFMAs, 8 no QK MFMAs
   int head_dim;                        // the caller's head dimension: must be 64 (the only one these kernels are built for)
+  const uint32_t* drop_epoch;          // device step counter mixed into drop.seed (x2_common.h drop_at_epoch), or NULL
 };
 
 // Staging of a [64 rows][64 d] bf16 tile (rows clamped to `nrows-1`) HBM -> registers -> LDS in two halves, so the
@@ -138,6 +139,7 @@ __device__ __forceinline__ void load_bias_mask(const AttnArgs& a, int h, int b, 
 // serial load -> multiply -> store chain per workgroup whose only latency hiding is other workgroups).
 template <int QW, int QG, bool RES, int NS = (RES ? 4 : 2)>
 __global__ __launch_bounds__(64 * QW, 4) void attn_fwd_kernel(AttnArgs a) {
+  const DropSpec drop_ = drop_at_epoch(a.drop, a.drop_epoch);
   constexpr int NT = 64 * QW;
   __shared__ __attribute__((aligned(16))) char smem[NS][2 * KT * 128];   // {K tile, V tile} per slot
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -233,13 +235,13 @@ __global__ __launch_bounds__(64 * QW, 4) void attn_fwd_kernel(AttnArgs a) {
       }
       l_i[gq] = l_i[gq] * alpha + group_sum(rs);
       m_i[gq] = m_new;
-      if (a.drop.thr16) {      // normalisation uses the undropped sum; only the P that multiplies V is dropped
+      if (drop_.thr16) {      // normalisation uses the undropped sum; only the P that multiplies V is dropped
         const uint32_t e0 = (uint32_t)(((long)b * a.H + h) * a.Lq + q[gq]) * (uint32_t)lkp + (uint32_t)(kt * KT + g * 4);
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
           if (nt >= nsub) continue;
           float dm[4];
-          drop_mul4(a.drop, e0 + nt * 16, dm);
+          drop_mul4(drop_, e0 + nt * 16, dm);
           st[gq][nt][0] *= dm[0]; st[gq][nt][1] *= dm[1]; st[gq][nt][2] *= dm[2]; st[gq][nt][3] *= dm[3];
         }
       }
@@ -280,6 +282,7 @@ __global__ __launch_bounds__(64 * QW, 4) void attn_fwd_kernel(AttnArgs a) {
 // ------------------------------------------------------------------------------------------ backward: dQ (+ dS)
 template <int QW, int QG, bool RES, int NS = (RES ? 4 : 2)>
 __global__ __launch_bounds__(64 * QW, 4) void attn_bwd_dq_kernel(AttnArgs a) {
+  const DropSpec drop_ = drop_at_epoch(a.drop, a.drop_epoch);
   constexpr int NT = 64 * QW;
   __shared__ __attribute__((aligned(16))) char smem[NS][2 * KT * 128];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -369,9 +372,9 @@ __global__ __launch_bounds__(64 * QW, 4) void attn_bwd_dq_kernel(AttnArgs a) {
 #pragma unroll
       for (int gq = 0; gq < QG; ++gq) {
         s[gq] = apply_bias_mask(s[gq], bbv[gq][nt], mmv[nt], key0, a.Lk, sc2);
-        if (a.drop.thr16) {
+        if (drop_.thr16) {
           float dm[4];
-          drop_mul4(a.drop, (uint32_t)(((long)b * a.H + h) * a.Lq + q[gq]) * (uint32_t)lkp + (uint32_t)key0, dm);
+          drop_mul4(drop_, (uint32_t)(((long)b * a.H + h) * a.Lq + q[gq]) * (uint32_t)lkp + (uint32_t)key0, dm);
           dp[gq][0] *= dm[0]; dp[gq][1] *= dm[1]; dp[gq][2] *= dm[2]; dp[gq][3] *= dm[3];
         }
 #pragma unroll
@@ -421,6 +424,7 @@ __global__ __launch_bounds__(64 * QW, 4) void attn_bwd_dq_kernel(AttnArgs a) {
 // share a wave).
 template <int QW>
 __global__ __launch_bounds__(64 * QW) void attn_fwd_grouped_kernel(AttnArgs a) {
+  const DropSpec drop_ = drop_at_epoch(a.drop, a.drop_epoch);
   constexpr int NT = 64 * QW;
   __shared__ __attribute__((aligned(16))) char smem[4][2 * KT * 128];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -491,13 +495,13 @@ __global__ __launch_bounds__(64 * QW) void attn_fwd_grouped_kernel(AttnArgs a) {
       }
       l_i = l_i * alpha + group_sum(rs);
       m_i = m_new;
-      if (a.drop.thr16) {
+      if (drop_.thr16) {
         const uint32_t e0 = (uint32_t)(((long)b * a.H + h) * a.Lq + q) * (uint32_t)lkp + (uint32_t)(kt * KT + g * 4);
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
           if (nt >= nsub) continue;
           float dm[4];
-          drop_mul4(a.drop, e0 + nt * 16, dm);
+          drop_mul4(drop_, e0 + nt * 16, dm);
           st[nt][0] *= dm[0]; st[nt][1] *= dm[1]; st[nt][2] *= dm[2]; st[nt][3] *= dm[3];
         }
       }
@@ -525,6 +529,7 @@ __global__ __launch_bounds__(64 * QW) void attn_fwd_grouped_kernel(AttnArgs a) {
 
 template <int QW>
 __global__ __launch_bounds__(64 * QW, 32 / QW) void attn_bwd_dq_grouped_kernel(AttnArgs a) {
+  const DropSpec drop_ = drop_at_epoch(a.drop, a.drop_epoch);
   constexpr int NT = 64 * QW;
   __shared__ __attribute__((aligned(16))) char smem[4][2 * KT * 128];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -587,9 +592,9 @@ __global__ __launch_bounds__(64 * QW, 32 / QW) void attn_bwd_dq_grouped_kernel(A
         }
         const int key0 = kt * KT + nt * 16 + g * 4;
         s = apply_bias_mask(s, float4{0.f, 0.f, 0.f, 0.f}, mm[nt], key0, a.Lk, sc2);
-        if (a.drop.thr16) {
+        if (drop_.thr16) {
           float dm[4];
-          drop_mul4(a.drop, (uint32_t)(((long)b * a.H + h) * a.Lq + q) * (uint32_t)lkp + (uint32_t)key0, dm);
+          drop_mul4(drop_, (uint32_t)(((long)b * a.H + h) * a.Lq + q) * (uint32_t)lkp + (uint32_t)key0, dm);
           dp[0] *= dm[0]; dp[1] *= dm[1]; dp[2] *= dm[2]; dp[3] *= dm[3];
         }
 #pragma unroll
@@ -621,6 +626,7 @@ template <int KW, int KG, bool RES, int NS = (RES ? 4 : 2)>
 // chains only behind other waves, and left alone hipcc spends 170-230 VGPRs on the short-sequence forms (2 waves per SIMD);
 // capped at 128 they run 1.3-1.5x faster.  The streamed 4-wave form needs more than 128: 35 spills under the cap.)
 __global__ __launch_bounds__(64 * KW, (KW == 4 && !RES) ? 3 : 4) void attn_bwd_dkv_kernel(AttnArgs a) {
+  const DropSpec drop_ = drop_at_epoch(a.drop, a.drop_epoch);
   constexpr int NT = 64 * KW;
   __shared__ __attribute__((aligned(16))) char smem[NS][2 * KT * 128 + 2 * KT * 4];   // {Q tile, dO tile, LSE[64], Delta[64]} per slot
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -746,8 +752,8 @@ __global__ __launch_bounds__(64 * KW, (KW == 4 && !RES) ? 3 : 4) void attn_bwd_d
             const bool ok = kok[gk] && (qq0 + r < a.Lq);
             const float pv = ok ? exp2f(s[gk][r] * sc2 + bbv[r] * LOG2E + mk[gk] - lsv[r]) : 0.f;
             float dm = 1.f;
-            if (a.drop.thr16)
-              dm = drop_mul(a.drop, (uint32_t)(((long)b * a.H + h) * a.Lq + min(qq0 + r, a.Lq - 1)) * (uint32_t)lkp + (uint32_t)key[gk]);
+            if (drop_.thr16)
+              dm = drop_mul(drop_, (uint32_t)(((long)b * a.H + h) * a.Lq + min(qq0 + r, a.Lq - 1)) * (uint32_t)lkp + (uint32_t)key[gk]);
             p[gk][t][r] = pv * dm;
             ds[gk][t][r] = pv * (dp[gk][r] * dm - dlv[r]);
           }

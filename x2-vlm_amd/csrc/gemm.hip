@@ -31,6 +31,7 @@ struct GemmNT {
   int out_f32;  // C is float (1) or bf16 (0)
   int group_m;  // tile raster: GROUP_M row-panels are walked column by column (L2 working set = GROUP_M A panels + a few B tiles)
   DropSpec drop;            // hidden dropout on (acc + bias) before the residual add (xbert.py:429, 513)
+  const uint32_t* drop_epoch;  // device step counter mixed into drop.seed, or NULL (x2_common.h drop_at_epoch)
   const float* rowscale;    // [M] per-row factor before the residual add: DropPath keep/(1-p) per sample (beit2.py:206-207)
   float* colsum;            // [N] += column sums of the stored C (bias gradient of the layer below, fused)
   int dbg;                  // ablation switches for probes/bench_gemm.py: 4 = no epilogue, 16 = sc1 output stores
@@ -78,6 +79,7 @@ __device__ __forceinline__ void nt_epilogue(const GemmNT& p, f32x4 (&acc)[TM][4]
     gg[0] = g0.x; gg[1] = g0.y; gg[2] = g0.z; gg[3] = g0.w; gg[4] = g1.x; gg[5] = g1.y; gg[6] = g1.z; gg[7] = g1.w; }
   float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   const bool wt = (p.dbg & 16) != 0;
+  const DropSpec drop_ = drop_at_epoch(p.drop, p.drop_epoch);
 #pragma unroll
   for (int half = 0; half < TM / 2; ++half) {
 #pragma unroll
@@ -104,11 +106,11 @@ __device__ __forceinline__ void nt_epilogue(const GemmNT& p, f32x4 (&acc)[TM][4]
       } else if (p.aux) {
         st16(p.aux + (size_t)m * p.ldaux + n, u32x4{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7])}, wt);
       }
-      if (p.drop.thr16) {
+      if (drop_.thr16) {
         float dm[4];
-        drop_mul4(p.drop, (uint32_t)m * (uint32_t)p.N + (uint32_t)n, dm);
+        drop_mul4(drop_, (uint32_t)m * (uint32_t)p.N + (uint32_t)n, dm);
         v[0] *= dm[0]; v[1] *= dm[1]; v[2] *= dm[2]; v[3] *= dm[3];
-        drop_mul4(p.drop, (uint32_t)m * (uint32_t)p.N + (uint32_t)n + 4u, dm);
+        drop_mul4(drop_, (uint32_t)m * (uint32_t)p.N + (uint32_t)n + 4u, dm);
         v[4] *= dm[0]; v[5] *= dm[1]; v[6] *= dm[2]; v[7] *= dm[3];
       }
       const float rs_ = p.rowscale ? p.rowscale[m] : 1.f;
@@ -351,8 +353,8 @@ extern "C" int x2_tune(int key, int value) {
 
 extern "C" int x2_gemm_nt(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
                           const float* bias, const float* gamma, const float* resid, int ldr, void* aux, int ldaux,
-                          int act, int out_f32, unsigned drop_thr16, unsigned drop_seed, float drop_scale, const float* rowscale,
-                          float* colsum, void* stream) {
+                          int act, int out_f32, unsigned drop_thr16, unsigned drop_seed, float drop_scale, const unsigned* drop_epoch,
+                          const float* rowscale, float* colsum, void* stream) {
   X2_REQUIRE(M > 0 && N > 0 && K > 0, "x2_gemm_nt: empty problem M=%d N=%d K=%d", M, N, K);
   X2_REQUIRE(drop_thr16 < 65536u, "x2_gemm_nt: drop_thr16=%u", drop_thr16);
   X2_REQUIRE(K % BK == 0, "x2_gemm_nt: K=%d must be a multiple of %d", K, BK);
@@ -361,7 +363,7 @@ extern "C" int x2_gemm_nt(const void* A, const void* B, void* C, int M, int N, i
   X2_REQUIRE(act == 0 || aux, "x2_gemm_nt: act=%d needs aux", act);
   X2_REQUIRE((!resid || ldr % 4 == 0) && (!aux || ldaux % 8 == 0), "x2_gemm_nt: ldr/ldaux alignment");
   GemmNT p{(const bf16_t*)A, (const bf16_t*)B, C, bias, gamma, resid, (bf16_t*)aux, M, N, K, lda, ldb, ldc, ldr, ldaux, act, out_f32,
-           g_tune[0] > 0 ? g_tune[0] : 8, DropSpec{drop_thr16, drop_seed, drop_scale}, rowscale, colsum, g_tune[2], g_tune[4]};
+           g_tune[0] > 0 ? g_tune[0] : 8, DropSpec{drop_thr16, drop_seed, drop_scale}, drop_epoch, rowscale, colsum, g_tune[2], g_tune[4]};
   // tile choice: [1] = 0 auto, 1 force 128x128 (4 waves), 2 force 256x128 (8 waves, 3-deep ring)
   const int tiles8 = ((M + 255) / 256) * ((N + 127) / 128);
   // measured (probes/bench_gemm.py): two independent 4-wave workgroups per CU beat one 8-wave workgroup with a

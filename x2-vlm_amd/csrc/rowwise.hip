@@ -22,9 +22,10 @@ template <int NV>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                             const float* __restrict__ bsh, bf16_t* yb, float* yf,
                                                             float* mean, float* rstd, int rows, int D, float eps, int period,
-                                                            DropSpec drop) {
+                                                            DropSpec drop_in_, const uint32_t* __restrict__ epoch) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= rows) return;
+  const DropSpec drop = drop_at_epoch(drop_in_, epoch);
   const long gr = remap_row(row, period);
   const float* xr = x + gr * D;
   float4 v[NV];
@@ -63,10 +64,10 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
 
 extern "C" int x2_layernorm_fwd(const float* x, const float* w, const float* b, void* y_bf16, float* y_f32, float* mean,
                                 float* rstd, int rows, int D, float eps, int period, unsigned drop_thr16, unsigned drop_seed,
-                                float drop_scale, void* stream) {
+                                float drop_scale, const unsigned* drop_epoch, void* stream) {
   X2_REQUIRE(rows > 0 && D > 0 && D % 4 == 0 && D <= 256 * LN_MAXV, "x2_layernorm_fwd: rows=%d D=%d (D%%4==0, D<=2048)", rows, D);
 #define X2_LNF(NV) hipLaunchKernelGGL(layernorm_fwd_kernel<NV>, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, w, b, \
-                     (bf16_t*)y_bf16, y_f32, mean, rstd, rows, D, eps, period, DropSpec{drop_thr16, drop_seed, drop_scale})
+                     (bf16_t*)y_bf16, y_f32, mean, rstd, rows, D, eps, period, DropSpec{drop_thr16, drop_seed, drop_scale}, drop_epoch)
   LN_DISPATCH(D, X2_LNF);
   return x2_check_launch("x2_layernorm_fwd");
 }
@@ -161,8 +162,9 @@ __global__ __launch_bounds__(256, NV <= 3 ? 4 : 1) void layernorm_bwd_kernel(con
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
                                                             const float* __restrict__ w, const float* dres, float* dx, bf16_t* dxb,
                                                             float* ws, int rows, int D, int period,
-                                                            DropSpec din, DropSpec dout) {
+                                                            DropSpec din_, DropSpec dout_, const uint32_t* __restrict__ epoch) {
   extern __shared__ __attribute__((aligned(16))) float red[];      // [3][3 waves][D]
+  const DropSpec din = drop_at_epoch(din_, epoch), dout = drop_at_epoch(dout_, epoch);
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int nv = D >> 2;
   float4 ww[NV], aw[NV], ab[NV], ac[NV];
@@ -256,14 +258,14 @@ __global__ __launch_bounds__(256, NV <= 3 ? 4 : 1) void layernorm_bwd_kernel(con
 extern "C" int x2_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* w,
                                 const float* dres, float* dx, void* dx_bf16, float* dw, float* db, float* dcol, int rows, int D,
                                 int period, unsigned in_thr16, unsigned in_seed, float in_scale, unsigned out_thr16,
-                                unsigned out_seed, float out_scale, float* ws, int defer, void* stream) {
+                                unsigned out_seed, float out_scale, const unsigned* drop_epoch, float* ws, int defer, void* stream) {
   X2_REQUIRE(rows > 0 && D > 0 && D % 4 == 0 && D <= 256 * LN_MAXV, "x2_layernorm_bwd: rows=%d D=%d", rows, D);
   X2_REQUIRE(dw && db && ws, "x2_layernorm_bwd: dw/db and the workspace ws[ceil(rows/%d)*3*D] are required", LNB_ROWS);
   X2_REQUIRE(!(dcol && dres), "x2_layernorm_bwd: dcol sums the LN-input gradient, which excludes dres");
   X2_REQUIRE(!(out_thr16 && dres), "x2_layernorm_bwd: an output mask applies to the bf16 copy, which excludes dres");
 #define X2_LNB(NV) hipLaunchKernelGGL(layernorm_bwd_kernel<NV>, dim3((rows + LNB_ROWS - 1) / LNB_ROWS), dim3(256), 9 * D * sizeof(float), \
                      (hipStream_t)stream, dy, x, mean, rstd, w, dres, dx, (bf16_t*)dx_bf16, ws, rows, D, period,                \
-                     DropSpec{in_thr16, in_seed, in_scale}, DropSpec{out_thr16, out_seed, out_scale})
+                     DropSpec{in_thr16, in_seed, in_scale}, DropSpec{out_thr16, out_seed, out_scale}, drop_epoch)
   LN_DISPATCH(D, X2_LNB);
   if (!defer) launch_reduce(ws, (rows + LNB_ROWS - 1) / LNB_ROWS, 3, D, dw, db, dcol, (hipStream_t)stream);
   return x2_check_launch("x2_layernorm_bwd");

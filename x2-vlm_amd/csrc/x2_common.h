@@ -62,6 +62,14 @@ __device__ __forceinline__ uint32_t x2_hash(uint32_t x) {
   x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
   return x;
 }
+// Epoch: a step counter in DEVICE memory mixed into the site seed.  Lets a hipGraph-captured step (whose kernel
+// arguments are frozen at capture) draw fresh masks on every replay: the graph increments the counter, every dropout
+// site of the step reads it.  epoch == NULL: the seed is used as given (eager launches with host-drawn seeds).
+// Mirrored by kernels.dropout_keep() on the host.
+__device__ __forceinline__ DropSpec drop_at_epoch(DropSpec d, const uint32_t* __restrict__ epoch) {
+  if (epoch) d.seed = x2_hash(d.seed + 0x9E3779B1u * epoch[0]);
+  return d;
+}
 __device__ __forceinline__ float drop_mul(const DropSpec& d, uint32_t e) {          // one element
   const uint32_t h = x2_hash((e >> 1) ^ d.seed);
   const uint32_t u = (e & 1u) ? (h >> 16) : (h & 0xffffu);

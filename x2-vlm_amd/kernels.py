@@ -33,16 +33,21 @@ class _timed:
             GEMM_TIMER.append((self.a, self.b, self.flops, self.name))
 
 
-NO_DROP = (0, 0, 1.0)
+NO_DROP = (0, 0, 1.0, None)
+
+# int32 [1] device tensor or None.  When set (graph.GraphedStep does, for a hipGraph-captured step whose kernel arguments are
+# frozen at capture time), every dropout site mixes this device-resident step counter into its seed, so each replay of
+# the graph draws new masks; None = eager launches, seeds drawn on the host per call (xbert.next_dropout_seed).
+DROP_EPOCH = None
 
 
 def dropout_spec(p, seed, site):
-    """(thr16, site seed, scale) for the kernels' counter-based dropout: element e is dropped iff the 16-bit
-    uniform hashed from (e, site seed) is < thr16 = round(p * 65536); survivors are scaled by 1/(1-p)."""
+    """(thr16, site seed, scale, epoch tensor or None) for the kernels' counter-based dropout: element e is dropped iff
+    the 16-bit uniform hashed from (e, site seed [, epoch]) is < thr16 = round(p * 65536); survivors are scaled by 1/(1-p)."""
     if p <= 0.0:
         return NO_DROP
     return (int(round(p * 65536.0)), _hash32_int((int(seed) * 0x9E3779B1 + int(site) * 0x85EBCA77 + 0x165667B1) & 0xFFFFFFFF),
-            1.0 / (1.0 - p))
+            1.0 / (1.0 - p), DROP_EPOCH)
 
 
 def _hash32_int(x):
@@ -55,7 +60,9 @@ def _hash32_int(x):
 
 def dropout_keep(spec, index):
     """Host mirror of csrc/x2_common.h drop_mul(): multiplier (0 or scale) for int64 element indices."""
-    thr, seed, scale = spec
+    thr, seed, scale = spec[:3]
+    if len(spec) > 3 and spec[3] is not None:            # csrc/x2_common.h drop_at_epoch()
+        seed = _hash32_int((seed + 0x9E3779B1 * (int(spec[3].item()) & 0xFFFFFFFF)) & 0xFFFFFFFF)
     e = index.to(torch.int64) & 0xFFFFFFFF
     x = ((e >> 1) ^ seed) & 0xFFFFFFFF
     x = x ^ (x >> 16); x = (x * 0x7feb352d) & 0xFFFFFFFF
@@ -147,7 +154,7 @@ def gemm_nt(A, B, *, bias=None, gamma=None, resid=None, aux=None, act=0, out=Non
     with _timed(2.0 * M * N * K):
         call("x2_gemm_nt", ptr(A), ptr(B), ptr(out), M, N, K, _rows(A), _rows(B), _rows(out), ptr(bias), ptr(gamma),
              ptr(resid), _rows(resid) if resid is not None else 0, ptr(aux), _rows(aux) if aux is not None else 0,
-             act, 1 if out.dtype == F32 else 0, drop[0], drop[1], drop[2], ptr(rowscale), ptr(colsum))
+             act, 1 if out.dtype == F32 else 0, drop[0], drop[1], drop[2], ptr(drop[3]), ptr(rowscale), ptr(colsum))
     return out
 
 
@@ -188,7 +195,8 @@ def _attn_args(q, k, v, B, Bkv, H, Lq, Lk, scale, bias=None, biasT=None, mask=No
     a.V, a.v_bs, a.v_rs = v
     a.B, a.Bkv, a.H, a.Lq, a.Lk, a.scale = B, Bkv, H, Lq, Lk, scale
     a.head_dim = head_dim
-    a.drop_thr16, a.drop_seed, a.drop_scale = drop
+    a.drop_thr16, a.drop_seed, a.drop_scale = drop[:3]
+    a.drop_epoch = ptr(drop[3])
     if bias is not None:
         assert bias.dtype == F32 and bias.dim() == 3 and bias.is_contiguous()
         a.bias, a.bias_ld = bias.data_ptr(), bias.shape[2]
@@ -251,7 +259,7 @@ def layernorm_fwd(x, w, b, eps, *, rows=None, period=0, want_bf16=True, want_f32
     mean = torch.empty(R, device=x.device, dtype=F32)
     rstd = torch.empty(R, device=x.device, dtype=F32)
     call("x2_layernorm_fwd", ptr(x2), ptr(w), ptr(b), ptr(y_bf16), ptr(y_f32), ptr(mean), ptr(rstd), R, D, eps, period,
-         drop[0], drop[1], drop[2])
+         drop[0], drop[1], drop[2], ptr(drop[3]))
     return y_bf16, y_f32, mean, rstd
 
 
@@ -267,7 +275,8 @@ def layernorm_bwd(dy, x, mean, rstd, w, dw, db, *, dres=None, dcol=None, period=
     nblk = (R + 15) // 16
     ws, defer = _ws_and_defer(x.device, nblk * 3 * D)
     call("x2_layernorm_bwd", ptr(dy), ptr(x), ptr(mean), ptr(rstd), ptr(w), ptr(dres), ptr(dx), ptr(dxb), ptr(dw), ptr(db),
-         ptr(dcol), R, D, period, drop_in[0], drop_in[1], drop_in[2], drop_out[0], drop_out[1], drop_out[2], ptr(ws), defer)
+         ptr(dcol), R, D, period, drop_in[0], drop_in[1], drop_in[2], drop_out[0], drop_out[1], drop_out[2],
+         ptr(drop_in[3] if drop_in[3] is not None else drop_out[3]), ptr(ws), defer)
     if defer:
         DEFERRED.append((ws, nblk, 3, D, (dw, db, dcol)))
     return dx, dxb
