@@ -118,6 +118,7 @@ def main():
     ap.add_argument("--tiny", action="store_true", help="debug: 2-layer towers (NOT the benchmark configuration)")
     ap.add_argument("--with-optimizer", action="store_true",
                     help="also run clip + fused AdamW inside every step (the headline metric is fwd+bwd only)")
+    ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying the captured hipGraph")
     ap.add_argument("--serialize", action="store_true",
                     help="profiling aid: one HIP stream only (no concurrent text tower / weight-gradient stream), so that "
                          "per-kernel durations are not inflated by co-running kernels")
@@ -162,22 +163,14 @@ def main():
 
     eng = importlib.import_module("x2-vlm_amd.engine")
 
-    # the critical path (vision tower, fusion stack, input-gradient chain) runs on a high-priority HIP stream; the text
-    # tower and the weight-gradient GEMMs are on default-priority streams and fill the CUs it leaves idle
-    # (measured: no gain on MI355X/ROCm 7.2, so off by default)
-    hi = torch.cuda.Stream(priority=-1) if os.environ.get("X2_BENCH_HIPRIO", "0") == "1" else torch.cuda.current_stream()
-
-    def step():
-        with torch.cuda.stream(hi):
-            return _step()
-
     opt = None
     if args.with_optimizer:
         opt = importlib.import_module("x2-vlm_amd.optim").create_optimizer(dict(lr=1e-4, weight_decay=0.01, lr_mult=2), model)
 
     params = list(model.parameters())
 
-    def _step():
+    def fwd_bwd():
+        """One pass of the hot path: what Pretrain.run_image_iter does between zero_grad and optimizer.step."""
         eng.BANK.invalidate()        # as after an optimizer step: fp32 master weights are re-cast to bf16 inside the step
         with torch.no_grad():
             model.temp.clamp_(0.001, 0.5)                # Pretrain.py:327-328
@@ -189,9 +182,16 @@ def main():
         total.backward()
         if ddp is not None:
             ddp.finish()
+        return loss
+
+    def optimizer_part():
         if opt is not None:
             opt.grad_norm(max_norm=1.0)                   # CLIP_GRAD_NORM 1.0, no host sync
             opt.step()
+
+    def eager_step():
+        loss = fwd_bwd()
+        optimizer_part()
         return loss
 
     def fence():
@@ -199,16 +199,60 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def timed_gemms(n_steps):
+        """HIP events around every GEMM launch of n eager steps (rank 0 times; every rank runs them: the step contains
+        collectives), on the stream each launch goes to.  -> {kernel: (ms, flops, launches)}"""
+        if rank == 0:
+            K.GEMM_TIMER = []
+        for _ in range(n_steps):
+            eager_step()
+        torch.cuda.synchronize()
+        stat = {}
+        if rank == 0:
+            recs, K.GEMM_TIMER = K.GEMM_TIMER, None
+            for a, b, f, name in recs:
+                ms, fl, n = stat.get(name, (0.0, 0.0, 0))
+                stat[name] = (ms + a.elapsed_time(b), fl + f, n + 1)
+        return stat
+
+    # ---- untimed: eager warm-up, then the dominant kernel's launch durations from eager steps.  Dominant kernel = the bf16
+    # MFMA NT GEMM (7.56 of the 11.74 TFLOP of a base step).  `isolated`: one HIP stream only, so a launch's events see that
+    # kernel alone - the number a rocprofv3 kernel trace of `bench.py --serialize` reproduces, and the headline roofline
+    # figure; `concurrent`: the shipping three-stream schedule, where a launch also waits for CUs held by other streams.
+    for _ in range(max(args.warmup, 1)):
+        eager_step()
+    fence()
+    stat_conc = timed_gemms(2) if not args.serialize else {}
+    model.overlap_towers = False
+    eng.SIDE.enabled = False
+    eager_step()
+    stat_iso = timed_gemms(2)
+    if not args.serialize:
+        model.overlap_towers = True
+        eng.SIDE.enabled = True
+    fence()
+
+    # ---- the step as ONE hipGraph (x2-vlm_amd/graph.py): the launch sequence is static, replaying it removes the
+    # ~25 ms (base) / ~100 ms (large) of Python + ctypes launch time per step that bounded round 1.  The optimizer stays
+    # outside the graph.  X2_GRAPH=0 / --no-graph: eager launches.
+    graph = importlib.import_module("x2-vlm_amd.graph")
+    # gloo collectives (the 2-ranks-on-one-GPU debug mode) synchronise the host and cannot be captured
+    runner = graph.GraphedStep(fwd_bwd, warmup=1, enabled=not args.no_graph and (world == 1 or backend == "nccl"), verbose=(rank == 0))
+
+    def step():
+        loss = runner()
+        optimizer_part()
+        return loss
+
     for _ in range(args.warmup):
         step()
     fence()
-    # dominant kernel = the bf16 MFMA NT GEMM (7.56 of the 11.74 PFLOP of a step): HIP events around every one of its
-    # launches during the timed steps, recorded on the stream each launch goes to (rank 0 only; ~1 us of host time each)
-    if rank == 0:
-        K.GEMM_TIMER = []
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks[0].record()
+    for i in range(args.steps):
         loss = step()
+        marks[i + 1].record()
     host_dt = time.perf_counter() - t0          # host time to ENQUEUE the steps (no sync): close to dt => launch-bound
     fence()
     dt = time.perf_counter() - t0
@@ -217,59 +261,40 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t)
     pairs_s = world * args.batch * args.steps / dt
+    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
 
     roof = None
     if rank == 0:
-        recs, K.GEMM_TIMER = K.GEMM_TIMER, None
-        stat = {}
-        for a, b, f, name in recs:
+        def summary(stat, name):
             ms, fl, n = stat.get(name, (0.0, 0.0, 0))
-            stat[name] = (ms + a.elapsed_time(b), fl + f, n + 1)
-        ms, fl, n = stat["gemm_nt"]
-        ach = fl / (ms * 1e-3) / 1e12
-        tn_ms, tn_fl, tn_n = stat.get("gemm_tn", (0.0, 0.0, 0))
-        roof = {"bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(ach / PEAK_TFLOPS, 4), "traffic": PMC_TRAFFIC.get("hbm_bytes_per_launch"),
-                "traffic_note": ("HBM bytes per launch (fetch + write) of this kernel from separate rocprofv3 --pmc passes, "
-                                 "corrected per MI355X_MICROARCH.md; summaries: " + ", ".join(PMC_TRAFFIC.get("files", [])))
-                                if PMC_TRAFFIC else "no PMC pass committed",
-                "kernel": "gemm_nt_kernel (forward linears + input gradients)", "launches_per_step": n // args.steps,
-                "avg_launch_us": round(1e3 * ms / n, 1), "gflop_per_launch": round(fl / n / 1e9, 2),
-                "nt_gemm_ms_per_step": round(ms / args.steps, 2),
-                "also": {"gemm_tn256_kernel (weight gradients, side stream; two layers per grouped launch)": {
-                             "launches_per_step": tn_n // args.steps, "avg_launch_us": round(1e3 * tn_ms / max(tn_n, 1), 1),
-                             "achieved": round(tn_fl / max(tn_ms, 1e-9) / 1e9, 1)},
+            return None if n == 0 else {"avg_launch_us": round(1e3 * ms / n, 1), "achieved": round(fl / ms / 1e9, 1),
+                                        "frac": round(fl / ms / 1e9 / PEAK_TFLOPS, 4), "launches_per_step": n // 2,
+                                        "ms_per_step": round(ms / 2, 2), "gflop_per_launch": round(fl / n / 1e9, 2)}
+        iso = summary(stat_iso, "gemm_nt")
+        roof = {"bound": "mfma", "achieved": iso["achieved"], "peak": PEAK_TFLOPS, "unit": "TFLOP/s", "frac": iso["frac"],
+                "traffic": PMC_TRAFFIC.get("hbm_bytes_per_launch"),
+                "traffic_note": ("HBM bytes per launch (fetch + write) of this kernel from separate rocprofv3 --pmc passes of "
+                                 "`bench.py --serialize` (base config), corrected per MI355X_MICROARCH.md; summaries: "
+                                 + ", ".join(PMC_TRAFFIC.get("files", []))) if PMC_TRAFFIC else "no PMC pass committed",
+                "kernel": "gemm_nt_kernel (forward linears + input gradients)", "launches_per_step": iso["launches_per_step"],
+                "avg_launch_us": iso["avg_launch_us"], "gflop_per_launch": iso["gflop_per_launch"],
+                "how": "algorithmic FLOPs of the launches / HIP-event durations, one HIP stream (kernels not overlapped): what "
+                       "`rocprofv3 --kernel-trace --stats -- python bench.py --serialize` shows for this kernel",
+                "also": {"gemm_nt concurrent (three-stream eager schedule; a launch also waits for CUs other streams hold)":
+                             summary(stat_conc, "gemm_nt"),
+                         "gemm_tn256_kernel isolated (weight gradients; two layers per grouped launch)": summary(stat_iso, "gemm_tn"),
                          "whole_step_tflops": round(pairs_s / world * conf["f_min"] / 1e3, 1),
-                         "whole_step_frac": round(pairs_s / world * conf["f_min"] / 1e3 / PEAK_TFLOPS, 4),
-                         "note": "launch durations are taken while the text tower and the weight-gradient GEMMs run "
-                                 "concurrently on other HIP streams (a launch also waits for CUs they hold); "
-                                 "'isolated' below = same kernel timed in one extra single-stream step, the figure a "
-                                 "rocprofv3 kernel trace of `bench.py --serialize` reproduces"}}
-    # two extra steps on a single stream: per-kernel durations without co-running kernels.  EVERY rank runs them (the
-    # step contains collectives: ITC all-gather, gradient all-reduce); only rank 0 times its GEMM launches.
-    if not args.serialize:
-        model.overlap_towers = False
-        eng.SIDE.enabled = False
-        step(); torch.cuda.synchronize()
-        if rank == 0:
-            K.GEMM_TIMER = []
-        step(); torch.cuda.synchronize()
-        if rank == 0:
-            recs, K.GEMM_TIMER = K.GEMM_TIMER, None
-            ims = sum(a.elapsed_time(b) for a, b, f, nm in recs if nm == "gemm_nt")
-            ifl = sum(f for a, b, f, nm in recs if nm == "gemm_nt")
-            inn = sum(1 for r in recs if r[3] == "gemm_nt")
-            roof["also"]["isolated"] = {"avg_launch_us": round(1e3 * ims / inn, 1), "achieved": round(ifl / ims / 1e9, 1),
-                                        "frac": round(ifl / ims / 1e9 / PEAK_TFLOPS, 4)}
-        model.overlap_towers = True
-        eng.SIDE.enabled = True
+                         "whole_step_frac": round(pairs_s / world * conf["f_min"] / 1e3 / PEAK_TFLOPS, 4)}}
     if world > 1:
         dist.barrier()
     if rank == 0:
         out = {"metric": conf["metric"], "value": round(pairs_s, 1),
                "unit": conf["unit"], "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(1e3 * dt / args.steps, 2),
-               "host_enqueue_ms_per_step": round(1e3 * host_dt / args.steps, 2), "higher_is_better": True, "scaling": "weak",
+               "ms_per_step_spread": {"min": round(per_step[0], 2), "median": round(per_step[len(per_step) // 2], 2),
+                                      "max": round(per_step[-1], 2), "how": "HIP events between consecutive timed steps"},
+               "host_enqueue_ms_per_step": round(1e3 * host_dt / args.steps, 2), "launch_mode": runner.mode,
+               "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
                "config": {"workload": conf["workload"] + ", %d-token captions, 12 masks" % args.seq_len, "name": args.config,
                           "per_gpu_batch": args.batch, "global_batch": args.batch * world,

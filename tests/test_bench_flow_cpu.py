@@ -5,7 +5,7 @@ import ast
 import os
 
 SRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py")
-FORBIDDEN = {"step", "_step", "model", "fence"}
+FORBIDDEN = {"step", "_step", "eager_step", "fwd_bwd", "runner", "timed_gemms", "model", "fence"}
 
 
 def _is_rank0_test(node):

@@ -124,7 +124,10 @@ class VisionTransformer(nn.Module):
     def drop_path_scales(self, B, T, device, keep=None):
         """Per-row keep/(1-p) factors of every block's two residual branches (timm drop_path: one Bernoulli per
         sample and branch).  keep: optional (depth, 2, B) 0/1 tensor (tests); default draws it with torch.rand."""
-        rates = torch.tensor([b.drop_path_rate for b in self.blocks], device=device, dtype=torch.float32)
+        cache = self.__dict__.setdefault("_dp_rates", {})     # built once per device: a host->device copy cannot be hipGraph-captured
+        rates = cache.get(device)
+        if rates is None:
+            rates = cache[device] = torch.tensor([b.drop_path_rate for b in self.blocks], device=device, dtype=torch.float32)
         if keep is None:
             keep = (torch.rand(self.depth, 2, B, device=device) >= rates.view(-1, 1, 1)).float()
         scale = keep.to(device).float() / (1.0 - rates).view(-1, 1, 1)

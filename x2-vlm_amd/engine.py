@@ -230,6 +230,12 @@ class SideStream:
         self.streams = {}          # one side stream per launching stream (vision and text stages run concurrently)
         self.held = {}             # launching stream -> tensors the side stream still reads (released by join())
         self.enabled = True
+        # hipGraph capture (graph.GraphedStep): raw handle of the ONE stream allowed to fork a side stream - the capture's
+        # origin stream.  ROCm 7's stream capture crashes in hipStreamEndCapture when a stream that is already part of the
+        # capture waits on an event of another non-origin stream (probes/graph_capture_probe.py: nested_fork,
+        # sibling_cross), so under capture every side stream may only fork from and join into the origin: launches
+        # coming from any other stream (the text tower's) run inline on that stream.
+        self.only_from = None
 
     @property
     def stream(self):
@@ -241,7 +247,7 @@ class SideStream:
     def launch(self, fn, tensors):
         """Run fn() on the side stream after everything enqueued so far on the current stream; returns an event
         recorded behind it (None when running inline)."""
-        if not self.enabled or not torch.cuda.is_available():
+        if not self.enabled or not torch.cuda.is_available() or (self.only_from is not None and raw_stream() != self.only_from):
             fn()
             return None
         side = self.stream
@@ -262,7 +268,7 @@ class SideStream:
         """Make the current stream wait for the side stream (call before gradients leave the stage)."""
         if self.enabled and torch.cuda.is_available():
             key = raw_stream()
-            if key in self.streams:
+            if key in self.streams and (self.only_from is None or key == self.only_from):
                 torch.cuda.current_stream().wait_stream(self.streams[key])
             self.held.pop(key, None)
 

@@ -69,10 +69,13 @@ class XVLM(XVLMBase):
         loss_mlm, logits = self.text_encoder.mlm_loss_from_hidden(fused[-B:], masked_pos, masked_ids)
         self.last_mlm_logits = logits
         loss = {"loss_itc": loss_itc, "loss_itm": loss_itm, "loss_mlm": loss_mlm}
-        self.last = dict(image_embeds=image_embeds, text_embeds=text_embeds, image_feat=image_feat, text_feat=text_feat)
+        # detached: holding graph tensors here would keep the step's autograd graph (and its AccumulateGrad nodes) alive
+        # across iterations
+        self.last = dict(image_embeds=image_embeds.detach(), text_embeds=text_embeds.detach(), image_feat=image_feat.detach(),
+                         text_feat=text_feat.detach())
         if ret_bbox_loss:
             output_coord = self.predict_bbox(image_embeds_fullatts, text_embeds, text_atts)
-            self.last["bbox_coord"] = output_coord
+            self.last["bbox_coord"] = output_coord.detach()
             loss["loss_bbox"], loss["loss_giou"] = self.get_bbox_loss(output_coord, target_bbox, is_image=is_image)
         return loss
 

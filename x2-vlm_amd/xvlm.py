@@ -271,7 +271,8 @@ class XVLMBase(nn.Module):
 
     def _itm_loss(self, cls, B):
         logits = ops.mlp_head(self.itm_head, cls)
-        labels = torch.cat([torch.ones(B, dtype=torch.long), torch.zeros(2 * B, dtype=torch.long)]).to(cls.device)
+        labels = torch.zeros(3 * B, dtype=torch.long, device=cls.device)      # built on the device (graph-capturable)
+        labels[:B] = 1
         self.last_itm_logits = logits.detach()
         return ops.cross_entropy(logits, labels)
 
