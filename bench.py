@@ -228,8 +228,9 @@ def main():
     eager_step()
     stat_iso = timed_gemms(2)
     if not args.serialize:
-        model.overlap_towers = True
-        eng.SIDE.enabled = True
+        # A/B switches for the stream schedule of the timed steps (default: both on)
+        model.overlap_towers = os.environ.get("X2_OVERLAP_TOWERS", "1") == "1"
+        eng.SIDE.enabled = os.environ.get("X2_SIDE_STREAM", "1") == "1"
     fence()
 
     # ---- the step as ONE hipGraph (x2-vlm_amd/graph.py): the launch sequence is static, replaying it removes the

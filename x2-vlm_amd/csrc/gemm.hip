@@ -558,6 +558,10 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmTNGroup g) {
 // ---------------------------------------------------------------------------------------------
 #define T2_HALF 16384
 #define T2_LDS_BYTES (8 * T2_HALF)
+// source of the rows past a ragged contraction length (Mc % 64 != 0: X2VLM-large has 32 x 577 rows): the LDS-DMA lanes of
+// those rows read these 16 zero bytes instead, so the last contraction step multiplies zeros - no padded copies of the
+// operands, no out-of-bounds reads
+__device__ __attribute__((aligned(16))) const uint32_t x2_zero_chunk[4] = {0u, 0u, 0u, 0u};
 __global__ __launch_bounds__(512) void gemm_tn256_kernel(GemmTNGroup g, float* ws, int total_tiles) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -571,9 +575,12 @@ __global__ __launch_bounds__(512) void gemm_tn256_kernel(GemmTNGroup g, float* w
   int tnn, tkk;
   tile_coords(tile - p.tile_begin, (p.N + 255) / 256, p.tiles_k, 4, tnn, tkk);
   const int n0 = tnn * 256, k0 = tkk * 256;
-  const int steps = p.Mc / BK;                                     // host guarantees Mc % 64 == 0, steps >= gridDim.y
+  const int steps = (p.Mc + BK - 1) / BK, rag = p.Mc % BK;        // host guarantees steps >= gridDim.y; rag = rows of a partial last step
   const int s_begin = (int)((long)steps * blockIdx.y / gridDim.y), s_end = (int)((long)steps * (blockIdx.y + 1) / gridDim.y);
   const int nk = s_end - s_begin;
+  const int last_rel = (rag != 0 && s_end == steps) ? nk - 1 : -1;  // slice-relative index of the partial step, if this slice has it
+  const bf16_t* const zsrc = reinterpret_cast<const bf16_t*>(x2_zero_chunk);
+  const bool oob0 = (tid >> 4) >= rag, oob1 = ((512 + tid) >> 4) >= rag;   // this thread's two rows of a half-tile
 
   // per-thread global sources: half-tile h of A / B, chunk i (2 x 512 chunks of 16 B per half-tile)
   const bf16_t* srcA[2][2]; const bf16_t* srcB[2][2];
@@ -591,12 +598,13 @@ __global__ __launch_bounds__(512) void gemm_tn256_kernel(GemmTNGroup g, float* w
   auto issue = [&](int kt, auto slot) {                            // slot 0, 1: A halves; 2, 3: B halves
     constexpr int S = decltype(slot)::value;
     char* base = smem + ((kt & 1) * 4 + S) * T2_HALF + wave * 1024;
+    const bool z = kt == last_rel;
     if constexpr (S < 2) {
-      glds16(srcA[S][0] + kt * stepA, base);
-      glds16(srcA[S][1] + kt * stepA, base + 8192);
+      glds16(z && oob0 ? zsrc : srcA[S][0] + kt * stepA, base);
+      glds16(z && oob1 ? zsrc : srcA[S][1] + kt * stepA, base + 8192);
     } else {
-      glds16(srcB[S - 2][0] + kt * stepB, base);
-      glds16(srcB[S - 2][1] + kt * stepB, base + 8192);
+      glds16(z && oob0 ? zsrc : srcB[S - 2][0] + kt * stepB, base);
+      glds16(z && oob1 ? zsrc : srcB[S - 2][1] + kt * stepB, base + 8192);
     }
   };
   using S0 = std::integral_constant<int, 0>; using S1 = std::integral_constant<int, 1>;
@@ -731,8 +739,8 @@ __global__ __launch_bounds__(256) void gemm_tn256_reduce_kernel(GemmTNGroup g, c
 
 // problems: `count` rows of 11 int64: {A, B, C, Mc, N, K, lda, ldb, ldc, n_ld, k_ld}.
 // split = 0: automatic.  ws / ws_floats: scratch for the split partial tiles of the 256x256 kernel (may be null: then
-// it never splits).  The 256x256 kernel is used when every contraction length is a multiple of 64; otherwise (ragged
-// Mc) the 128x128 kernel, where split > 1 adds atomically and needs accumulate = 1.
+// it never splits).  The 256x256 kernel (any contraction length: a partial last step reads zeros) is used from 24 tiles
+// of 256x256 up, the 128x128 kernel for small launches; there split > 1 adds atomically and needs accumulate = 1.
 extern "C" int x2_gemm_tn_grouped(const int64_t* problems, int count, int accumulate, int split, float* ws, long ws_floats,
                                   void* stream) {
   X2_REQUIRE(count >= 1 && count <= 8, "x2_gemm_tn_grouped: count=%d not in [1,8]", count);
@@ -753,8 +761,8 @@ extern "C" int x2_gemm_tn_grouped(const int64_t* problems, int count, int accumu
     X2_REQUIRE(p.n_ld <= p.lda && p.k_ld <= p.ldb, "x2_gemm_tn_grouped[%d]: n_ld/k_ld exceed leading dims", i);
     tiles += ((p.N + 127) / 128) * ((p.K + 127) / 128);
     tiles256 += ((p.N + 255) / 256) * ((p.K + 255) / 256);
-    if (p.Mc % BK != 0) big = false;
-    min_steps = p.Mc / BK < min_steps ? p.Mc / BK : min_steps;
+    const int steps_i = (p.Mc + BK - 1) / BK;
+    min_steps = steps_i < min_steps ? steps_i : min_steps;
   }
   // small launches (a head's single weight) stay on the 128x128 kernel: more, smaller workgroups
   if (g_tune[5] != 2 && tiles256 < 24) big = false;

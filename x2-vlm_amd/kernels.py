@@ -162,8 +162,8 @@ def gemm_tn_grouped(problems, accumulate=False, split=0):
     """Weight gradients of one layer in one launch.  problems: list of (dY[Mc,N] bf16, X[Mc,K] bf16,
     dW[N,K] fp32) or 5-tuples with (n_ld, k_ld) = readable row widths when they exceed N / K.
     split: slices of the contraction (0 = the library picks what fills the CUs; partial tiles go through the stream
-    workspace and are added deterministically; ragged contraction lengths use the 128x128 kernel, where split > 1 adds
-    atomically and needs accumulate=True)."""
+    workspace and are added deterministically; small launches use the 128x128 kernel, where split > 1 adds atomically and
+    needs accumulate=True)."""
     rows = []
     for pr in problems:
         dY, X, dW = pr[:3]
@@ -179,7 +179,7 @@ def gemm_tn_grouped(problems, accumulate=False, split=0):
         arr = (C.c_int64 * (11 * len(chunk)))(*[v for r in chunk for v in r])
         tiles256 = sum(((r[4] + 255) // 256) * ((r[5] + 255) // 256) for r in chunk)
         want = (split if split else 4) * tiles256 * 65536
-        ws = workspace(dev, want) if (split != 1 and all(r[3] % 64 == 0 for r in chunk)) else None
+        ws = workspace(dev, want) if split != 1 else None
         with _timed(sum(2.0 * r[3] * r[4] * r[5] for r in chunk), "gemm_tn"):
             call("x2_gemm_tn_grouped", arr, len(chunk), 1 if accumulate else 0, split, ptr(ws), 0 if ws is None else ws.numel())
 
