@@ -1,267 +1,286 @@
-"""Checkpoint compatibility: released X2-VLM / BEiT-2 / BERT checkpoints load into
-the MI355X modules, including a change of image resolution.
+"""Checkpoint compatibility: released X2-VLM / BEiT-2 / BERT checkpoints load into the
+MI355X modules, including a change of image resolution.  Load-time host code only; nothing here touches the GPU.
 
-Pure load-time host code, as in the reference (nothing here touches the GPU):
+Organisation (what the reference spreads over if-ladders in models/xvlm.py:66-118, 318-460 and models/beit2.py:473-754):
 
-  interpolate_pos_embed    models/beit2.py:653-754   relative-position-bias tables (and abs. pos_embed) -> new grid
-  load_pretrained_beit2    models/beit2.py:473-601   stand-alone BEiT-2 checkpoint -> vision encoder
-  load_state_dict_lenient  models/beit2.py:604-650   non-strict load that ignores relative_position_index
-  rename_tf_layernorm      models/xvlm.py:66-73
-  load_params_choose_layers models/xvlm.py:76-118    BERT layer remapping (12 -> 18 layers: 6..11 copied to 12..17)
-  load_text_params         models/xvlm.py:318-385    pytorch_model.bin -> text encoder
-  load_pretrained          models/xvlm.py:390-456    X2-VLM checkpoint -> state dict for XVLMBase.load_state_dict
+  * ONE resampler, `resample_rel_pos_table`, for relative-position-bias tables (BEiT's geometric source grid, bicubic
+    spline), and `resample_abs_pos_embed` for encoders with an absolute table;
+  * ONE key-rewrite engine, `rewrite_keys`, driven by small rule tables:
+        TEXT_RECIPES      text-encoder family -> (TF LayerNorm names?, {model depth: layer map, keep sources?})
+        X2VLM_INFIXES     infixes dropped from text / cross encoder keys of an X2-VLM checkpoint
+        TIMESFORMER_COPIES spatial -> temporal block names (init_timesformer)
+  * thin entry points with the reference's names and call signatures (used by xvlm.XVLMBase and the fine-tune scripts):
+    interpolate_pos_embed, load_pretrained_beit2, rename_tf_layernorm, load_params_choose_layers, load_text_params,
+    load_pretrained, init_timesformer_keys.
 
-The relative-position interpolation follows BEiT: source offsets sit on a geometric progression (ratio q found by
-bisection so that the progression spans the target half-width), and every head's (2w-1)x(2w-1) table is resampled with a
-bicubic spline at integer target offsets.  The reference calls scipy.interpolate.interp2d(kind='cubic'), which was
-removed in SciPy 1.14; on a rectilinear grid that was FITPACK's regrid_smth, i.e. RectBivariateSpline(kx=ky=3, s=0),
-SciPy's documented replacement - used directly here (tests/golden/ckpt_interp.npz pins it against the reference's own
-function driven through that replacement).
+The spline: the reference calls scipy.interpolate.interp2d(kind='cubic') (removed in SciPy 1.14).  On a rectilinear grid
+that is the interpolating bicubic tensor-product spline with not-a-knot ends; it is evaluated here as two passes of 1-D
+not-a-knot cubic splines (scipy.interpolate.CubicSpline along one axis, then the other), a formulation independent of the
+FITPACK routine the golden vectors were produced with (tests/golden/make_golden_ckpt.py drove the reference's own
+function through SciPy's documented interp2d replacement); tests/test_checkpoint_cpu.py holds the two to 1e-6.
 """
-import copy
 import os
+import re
 
 import numpy as np
 import torch
 
+# --------------------------------------------------------------------------------------------- resampling
 
-def _geometric_positions(src_size, dst_size):
-    """Source coordinates (geometric progression, symmetric around 0) and integer target coordinates.
-    models/beit2.py:688-713."""
-    def geometric_progression(a, r, n):
-        return a * (1.0 - r ** n) / (1.0 - r)
+def _geometric_axis(src_size, dst_size):
+    """Source coordinates of a (2w-1)-point relative-offset axis laid out on a geometric progression that spans the
+    target half-width, and the integer target coordinates (BEiT; models/beit2.py:688-713).  The ratio is found by the
+    same bisection (bracket [1.01, 1.5], tolerance 1e-6) so that the coordinates agree to the last bit."""
+    half_src, half_dst = src_size // 2, dst_size // 2
+    lo, hi = 1.01, 1.5
+    ratio = (lo + hi) / 2.0
+    while hi - lo > 1e-6:
+        ratio = (lo + hi) / 2.0
+        span = (1.0 - ratio ** half_src) / (1.0 - ratio)          # 1 + r + ... + r^(half_src - 1)
+        lo, hi = (lo, ratio) if span > half_dst else (ratio, hi)
+    steps = np.cumsum([1.0] + [ratio ** (i + 1) for i in range(half_src - 1)]) if half_src else np.zeros(0)
+    src = np.concatenate([-steps[::-1], [0.0], steps])
+    dst = np.arange(-(dst_size // 2.0), dst_size // 2.0 + 0.1, 1.0)
+    return src, dst
 
-    left, right = 1.01, 1.5
-    q = (left + right) / 2.0
-    while right - left > 1e-6:
-        q = (left + right) / 2.0
-        gp = geometric_progression(1, q, src_size // 2)
-        if gp > dst_size // 2:
-            right = q
-        else:
-            left = q
-    dis, cur = [], 1
-    for i in range(src_size // 2):
-        dis.append(cur)
-        cur += q ** (i + 1)
-    r_ids = [-d for d in reversed(dis)]
-    x = np.asarray(r_ids + [0] + dis, dtype=np.float64)
-    t = dst_size // 2.0
-    dx = np.arange(-t, t + 0.1, 1.0)
-    return x, dx
+
+def _bicubic_resample(grid, src, dst):
+    """grid[iy][ix] sampled at src x src -> values at dst x dst: tensor-product not-a-knot cubic spline."""
+    from scipy.interpolate import CubicSpline
+    # the bisection leaves the outermost source offset within 1e-6 of the outermost target, on either side: a target a hair
+    # outside the source range is evaluated AT the boundary (what FITPACK's gridded evaluation does), not extrapolated
+    dst = np.clip(dst, src[0], src[-1])
+    along_x = CubicSpline(src, grid, axis=1, bc_type="not-a-knot")(dst)          # [src_y][dst_x]
+    return CubicSpline(src, along_x, axis=0, bc_type="not-a-knot")(dst)          # [dst_y][dst_x]
+
+
+def resample_rel_pos_table(table, dst_rows, dst_grid):
+    """[(2s-1)^2 + extra, heads] -> [dst_rows, heads]; the trailing cls/extra rows are carried over unchanged.
+    Returns the input object itself when the grids already agree."""
+    gh, gw = dst_grid
+    if gh != gw:
+        raise NotImplementedError("square patch grids only")
+    extra = dst_rows - (2 * gh - 1) * (2 * gw - 1)
+    src_size, dst_size = int((table.shape[0] - extra) ** 0.5), int((dst_rows - extra) ** 0.5)
+    if src_size == dst_size:
+        return table
+    src, dst = _geometric_axis(src_size, dst_size)
+    body = table[:table.shape[0] - extra].detach().float().cpu().numpy().astype(np.float64)
+    heads = body.reshape(src_size, src_size, -1)                                  # [iy][ix][head]
+    out = np.stack([_bicubic_resample(heads[:, :, h], src, dst) for h in range(heads.shape[2])], axis=-1)
+    new_body = torch.from_numpy(out.reshape(dst_size * dst_size, -1).astype(np.float32)).to(table.device)
+    return torch.cat([new_body, table[table.shape[0] - extra:]], dim=0)
+
+
+def resample_abs_pos_embed(pos, num_patches, num_extra):
+    """[1, extra + s*s, D] absolute table -> the model's grid (torch bicubic; encoders with pos_embed only)."""
+    dim = pos.shape[-1]
+    src, dst = int((pos.shape[-2] - num_extra) ** 0.5), int(num_patches ** 0.5)
+    if src == dst:
+        return pos
+    grid = pos[:, num_extra:].reshape(-1, src, src, dim).permute(0, 3, 1, 2)
+    grid = torch.nn.functional.interpolate(grid, size=(dst, dst), mode="bicubic", align_corners=False)
+    return torch.cat([pos[:, :num_extra], grid.permute(0, 2, 3, 1).flatten(1, 2)], dim=1)
 
 
 def interpolate_rel_pos_bias(rel_pos_bias, dst_num_pos, dst_patch_shape):
-    """[src_num_pos, heads] -> [dst_num_pos, heads]; the trailing cls/extra rows are carried over unchanged.
-    Returns the input object itself when no resampling is needed (models/beit2.py:676-731)."""
-    from scipy.interpolate import RectBivariateSpline
-
-    if dst_patch_shape[0] != dst_patch_shape[1]:
-        raise NotImplementedError()
-    src_num_pos, num_heads = rel_pos_bias.size()
-    num_extra_tokens = dst_num_pos - (dst_patch_shape[0] * 2 - 1) * (dst_patch_shape[1] * 2 - 1)
-    src_size = int((src_num_pos - num_extra_tokens) ** 0.5)
-    dst_size = int((dst_num_pos - num_extra_tokens) ** 0.5)
-    if src_size == dst_size:
-        return rel_pos_bias
-    extra_tokens = rel_pos_bias[-num_extra_tokens:, :]
-    body = rel_pos_bias[:-num_extra_tokens, :]
-    x, dx = _geometric_positions(src_size, dst_size)
-    heads = []
-    for h in range(num_heads):
-        z = body[:, h].view(src_size, src_size).float().numpy().astype(np.float64)       # z[iy][ix]
-        spline = RectBivariateSpline(x, x, z.T, kx=3, ky=3, s=0)                          # interp2d(x, y, z, 'cubic')
-        heads.append(torch.Tensor(spline(dx, dx).T.copy()).contiguous().view(-1, 1).to(rel_pos_bias.device))
-    return torch.cat((torch.cat(heads, dim=-1), extra_tokens), dim=0)
+    return resample_rel_pos_table(rel_pos_bias, dst_num_pos, dst_patch_shape)
 
 
 def interpolate_pos_embed(model, checkpoint_model):
-    """models/beit2.py:653-754.  model: the vision encoder; checkpoint_model: its state dict (no prefix), edited in
-    place and returned: relative_position_index buffers dropped, every relative_position_bias_table (and pos_embed, for
-    encoders that have one) resampled to the model's patch grid."""
+    """Vision-encoder state dict (no prefix) fitted to `model`'s patch grid, in place: index buffers dropped (they are
+    rebuilt by the module), every bias table / pos_embed resampled.  models/beit2.py:653-754."""
     own = model.state_dict()
-    for key in list(checkpoint_model.keys()):
-        if "relative_position_index" in key:
-            checkpoint_model.pop(key)
-        if "relative_position_bias_table" in key:
-            if key not in own:
-                print("Note that vision encoder does not have: ", key)
-                continue
-            new = interpolate_rel_pos_bias(checkpoint_model[key], own[key].size(0), model.patch_embed.patch_shape)
-            if new is not checkpoint_model[key]:
-                print("Position interpolate for %s to %dx%d" % (key, *model.patch_embed.patch_shape))
-                checkpoint_model[key] = new
+    grid = model.patch_embed.patch_shape
+    for key in [k for k in checkpoint_model if "relative_position_index" in k]:
+        del checkpoint_model[key]
+    for key in [k for k in checkpoint_model if "relative_position_bias_table" in k]:
+        if key not in own:
+            print("vision encoder has no parameter %s (left in the state dict)" % key)
+            continue
+        fitted = resample_rel_pos_table(checkpoint_model[key], own[key].shape[0], grid)
+        if fitted is not checkpoint_model[key]:
+            print("resampled %s to a %dx%d patch grid" % (key, grid[0], grid[1]))
+            checkpoint_model[key] = fitted
     if "pos_embed" in checkpoint_model and getattr(model, "pos_embed", None) is not None:
-        pos = checkpoint_model["pos_embed"]
-        dim = pos.shape[-1]
-        num_patches = model.patch_embed.num_patches
-        num_extra = model.pos_embed.shape[-2] - num_patches
-        orig, new = int((pos.shape[-2] - num_extra) ** 0.5), int(num_patches ** 0.5)
-        if orig != new:
-            extra = pos[:, :num_extra]
-            tok = pos[:, num_extra:].reshape(-1, orig, orig, dim).permute(0, 3, 1, 2)
-            tok = torch.nn.functional.interpolate(tok, size=(new, new), mode="bicubic", align_corners=False)
-            checkpoint_model["pos_embed"] = torch.cat((extra, tok.permute(0, 2, 3, 1).flatten(1, 2)), dim=1)
+        n = model.patch_embed.num_patches
+        checkpoint_model["pos_embed"] = resample_abs_pos_embed(checkpoint_model["pos_embed"], n, model.pos_embed.shape[-2] - n)
     return checkpoint_model
 
 
-def load_state_dict_lenient(model, state_dict, prefix="", ignore_missing="relative_position_index"):
-    """models/beit2.py:604-650: non-strict load; returns (missing keys that matter, unexpected keys)."""
-    msg = model.load_state_dict({k[len(prefix):] if prefix and k.startswith(prefix) else k: v for k, v in state_dict.items()},
-                                strict=False)
-    ignore = ignore_missing.split("|")
-    missing = [k for k in msg.missing_keys if not any(i in k for i in ignore)]
-    if missing:
-        print("Weights of {} not initialized from pretrained model: {}".format(model.__class__.__name__, missing))
-    if msg.unexpected_keys:
-        print("Weights from pretrained model not used in {}: {}".format(model.__class__.__name__, list(msg.unexpected_keys)))
-    return missing, list(msg.unexpected_keys)
+# --------------------------------------------------------------------------------------------- key rewriting
+
+def rewrite_keys(state_dict, rename=None, drop=None):
+    """In place: keys for which drop(key) holds are removed, every other key k becomes rename(k) (None / k = unchanged;
+    a later key wins when two map to the same name)."""
+    for key in list(state_dict.keys()):
+        if drop is not None and drop(key):
+            del state_dict[key]
+            continue
+        new = rename(key) if rename is not None else key
+        if new is not None and new != key:
+            state_dict[new] = state_dict.pop(key)
+    return state_dict
 
 
-def load_pretrained_beit2(model, ckpt_rpath):
-    """models/beit2.py:473-601: a stand-alone BEiT-2 checkpoint ('model' | 'module' | bare state dict) into the vision
-    encoder: classifier head dropped, a shared rel_pos_bias table expanded to every block, tables resampled."""
-    print("Load BEIT-V2 ckpt from %s" % ckpt_rpath)
-    checkpoint = torch.load(ckpt_rpath, map_location="cpu")
-    checkpoint_model = None
-    for model_key in ("model", "module"):
-        if model_key in checkpoint:
-            checkpoint_model = checkpoint[model_key]
-            print("Load state_dict by model_key = %s" % model_key)
-            break
-    if checkpoint_model is None:
-        checkpoint_model = checkpoint
-    for k in ("head.weight", "head.bias"):
-        del checkpoint_model[k]                         # KeyError if absent, as in the reference
-    if getattr(model, "use_rel_pos_bias", False) and "rel_pos_bias.relative_position_bias_table" in checkpoint_model:
-        print("Expand the shared relative position embedding to each transformer block. ")
-        shared = checkpoint_model.pop("rel_pos_bias.relative_position_bias_table")
-        for i in range(model.get_num_layers()):
-            checkpoint_model["blocks.%d.attn.relative_position_bias_table" % i] = shared.clone()
-    interpolate_pos_embed(model, checkpoint_model)
-    return load_state_dict_lenient(model, checkpoint_model)
+_TF_LAYERNORM = (("LayerNorm.beta", "LayerNorm.bias"), ("LayerNorm.gamma", "LayerNorm.weight"))
 
 
 def rename_tf_layernorm(state_dict):
-    """models/xvlm.py:66-73: TF-era LayerNorm.gamma / .beta -> .weight / .bias, in place."""
-    for k in list(state_dict.keys()):
-        if "LayerNorm." in k:
-            new_k = k.strip().replace("LayerNorm.beta", "LayerNorm.bias").strip().replace("LayerNorm.gamma", "LayerNorm.weight")
-            state_dict[new_k] = state_dict[k]
-            if new_k != k:
-                del state_dict[k]
+    """TF-era LayerNorm.gamma / .beta -> .weight / .bias (models/xvlm.py:66-73)."""
+    def fix(key):
+        for old, new in _TF_LAYERNORM:
+            key = key.replace(old, new)
+        return key
+    return rewrite_keys(state_dict, rename=lambda k: fix(k) if "LayerNorm." in k else k)
 
 
 def load_params_choose_layers(prefix, state_dict, mapper, do_expand=False):
-    """models/xvlm.py:76-118.  mapper: {old_layer: new_layer}; keys `<prefix>.<old>.…` are copied to `<prefix>.<new>.…`
-    walking from the lowest layer up; the source keys are kept only when do_expand."""
-    assert len(set(mapper.values())) == len(mapper), f"{set(mapper.values())} != {len(mapper)}"
-    mapper = {k: mapper[k] for k in sorted(int(k) for k in mapper.keys())}
-    if not len(mapper):
+    """Re-number encoder layers: keys `<prefix>.<src>.*` become `<prefix>.<mapper[src]>.*`.  With do_expand the source
+    layers are kept as well (12 -> 18 layers: 6..11 are ALSO used as 12..17); without it every layer outside the map is
+    dropped (pick 12 of 24).  models/xvlm.py:76-118."""
+    targets = list(mapper.values())
+    assert len(set(targets)) == len(targets), "layer map is not one-to-one: %s" % (mapper,)
+    mapper = {int(s): int(d) for s, d in mapper.items()}
+    if not mapper:
         return state_dict
-    keyed = []
-    for k in list(state_dict.keys()):
-        keyed.append((k, int(k[len(prefix) + 1:].strip().split(".")[0]) if k.startswith(prefix) else -1))
-    for k in [p[0] for p in sorted(keyed, key=lambda p: p[1])]:
-        if not k.startswith(prefix):
-            continue
-        new_k = None
-        for i in mapper.keys():
-            if k.startswith(f"{prefix}.{i}."):
-                new_k = k.replace(f"{prefix}.{i}.", f"{prefix}.{mapper[i]}.")
-                break
-        if new_k:
-            state_dict[new_k] = state_dict[k]
-        if (new_k != k) and (not do_expand):
-            del state_dict[k]
+    # values are taken from the checkpoint as loaded: a map whose target is itself a LATER source would need the
+    # reference's in-place chaining semantics, which no recipe uses
+    if any(d in mapper and d > s for s, d in mapper.items()):
+        raise NotImplementedError("chained layer map %s" % (mapper,))
+    layer_of = re.compile(re.escape(prefix) + r"\.(\d+)\.")
+    original = dict(state_dict)
+    family = [(key, layer_of.match(key)) for key in original]
+    if not do_expand:                      # picking layers: everything of the family goes, the chosen ones come back below
+        for key, m in family:
+            if m is not None:
+                del state_dict[key]
+    for key, m in family:
+        if m is not None and int(m.group(1)) in mapper:
+            state_dict["%s.%d.%s" % (prefix, mapper[int(m.group(1))], key[m.end():])] = original[key]
     return state_dict
+
+
+_UPPER_HALF_TWICE = {6: 12, 7: 13, 8: 14, 9: 15, 10: 16, 11: 17}     # fusion layers start as copies of text layers 6..11
+# text-encoder family (substring of config['text_encoder'], first match wins) ->
+#   tf_names: checkpoint uses LayerNorm.gamma/beta;  depths: {model depth: (layer map, keep sources)}, None = load as is;
+#   other depths: other_depths_ok or NotImplementedError (as the reference's ladder, models/xvlm.py:333-365)
+TEXT_RECIPES = (
+    ("bert-base-uncased", dict(tf_names=True, depths={18: (_UPPER_HALF_TWICE, True)}, other_depths_ok=True)),
+    ("bert-large-uncased-12l", dict(tf_names=False, depths={18: (_UPPER_HALF_TWICE, True)}, other_depths_ok=False)),
+    ("bert-large-uncased", dict(tf_names=True, depths={12: ({src: i for i, src in enumerate(range(1, 25, 2))}, False)},
+                                other_depths_ok=False)),
+)
 
 
 def load_text_params(text_encoder, config, config_text, use_mlm_loss):
-    """models/xvlm.py:318-385 (BERT branches): <text_encoder dir>/pytorch_model.bin into the text encoder.
-    Returns the missing keys (they join XVLMBase.init_params: trained with lr * lr_mult)."""
-    path = os.path.join(config["text_encoder"], "pytorch_model.bin")
-    print("### Initializing text encoder from ", path)
+    """<text_encoder dir>/pytorch_model.bin into the text encoder (models/xvlm.py:318-385, BERT families).
+    Returns the keys the checkpoint lacks: they join XVLMBase.init_params (trained with lr * lr_mult)."""
+    name = config["text_encoder"]
+    path = os.path.join(name, "pytorch_model.bin")
+    print("text encoder weights <- %s" % path)
     state_dict = torch.load(path, map_location="cpu")
-    if "model" in state_dict.keys():
-        state_dict = state_dict["model"]
-    if "roberta" in config["text_encoder"]:
+    state_dict = state_dict.get("model", state_dict)
+    if "roberta" in name:                  # the reference loads those into models/xroberta.py modules: not built on this path
         raise NotImplementedError("RoBERTa text encoders are outside the X2VLM-base/large hot path")
     prefix = "bert.encoder.layer"
-    if not use_mlm_loss:
+    if not use_mlm_loss:                   # bare BertModel: no `bert.` level in its own keys
         state_dict = {k.replace("roberta.", "").replace("bert.", ""): v for k, v in state_dict.items()}
         prefix = "encoder.layer"
-    expand = {6: 12, 7: 13, 8: 14, 9: 15, 10: 16, 11: 17}
-    if "bert-base-uncased" in config["text_encoder"]:
+    recipe = next((r for tag, r in TEXT_RECIPES if tag in name), None)
+    if recipe is None:
+        raise NotImplementedError("no loading recipe for text encoder %s" % name)
+    if recipe["tf_names"]:
         rename_tf_layernorm(state_dict)
-        if config_text.num_hidden_layers == 18:
+    depth = config_text.num_hidden_layers
+    if depth in recipe["depths"]:
+        layer_map, keep = recipe["depths"][depth]
+        if layer_map is _UPPER_HALF_TWICE:
             assert config["text_fusion_start_at"] == 12
-            load_params_choose_layers(prefix, state_dict, expand, do_expand=True)
-    elif "bert-large-uncased-12l" in config["text_encoder"]:
-        if config["text_num_hidden_layers"] == 18:
-            assert config["text_fusion_start_at"] == 12
-            load_params_choose_layers(prefix, state_dict, expand, do_expand=True)
-        else:
-            raise NotImplementedError
-    elif "bert-large-uncased" in config["text_encoder"]:
-        rename_tf_layernorm(state_dict)
-        if config_text.num_hidden_layers == 12:
-            load_params_choose_layers(prefix, state_dict, {layer: i for i, layer in enumerate(range(1, 24 + 1, 2))})
-        else:
-            raise NotImplementedError
-    elif "chinese-roberta-wwm-ext" in config["text_encoder"]:
-        if config_text.num_hidden_layers == 6:
-            load_params_choose_layers(prefix, state_dict, {1: 0, 3: 1, 5: 2, 7: 3, 9: 4, 11: 5})
-    else:
-        raise NotImplementedError
+        load_params_choose_layers(prefix, state_dict, layer_map, do_expand=keep)
+    elif not recipe["other_depths_ok"]:
+        raise NotImplementedError("%s with %d layers" % (name, depth))
     if config.get("init_word_embeddings", False):
-        print("### Train word_embeddings from scratch...", flush=True)
-        for k in list(state_dict.keys()):
-            if "word_embeddings" in k or k in ("cls.predictions.decoder.weight", "cls.predictions.bias"):
-                del state_dict[k]
-    msg = text_encoder.load_state_dict(state_dict, strict=False)
-    print("missing_keys: ", msg.missing_keys, flush=True)
-    print("unexpected_keys: ", msg.unexpected_keys, flush=True)
-    return list(msg.missing_keys)
+        print("word embeddings (and the tied MLM decoder) are left at their initialisation")
+        rewrite_keys(state_dict, drop=lambda k: "word_embeddings" in k or k in ("cls.predictions.decoder.weight", "cls.predictions.bias"))
+    result = text_encoder.load_state_dict(state_dict, strict=False)
+    print("text encoder: %d keys missing, %d unexpected" % (len(result.missing_keys), len(result.unexpected_keys)), flush=True)
+    return list(result.missing_keys)
 
 
-_TIMESFORMER_MAP = {"temporal_norm1": "norm1", "time_attn": "attn", "temporal_norm2": "norm2", "temporal_mlp": "mlp",
-                    "time_gamma_1": "gamma_1", "time_gamma_2": "gamma_2"}
+# --------------------------------------------------------------------------------------------- whole-model checkpoints
+
+X2VLM_INFIXES = ("roberta.", "bert.")          # dropped from text_encoder.* / cross_encoder.* keys when load_text
+TIMESFORMER_COPIES = (("norm1", "temporal_norm1"), ("attn", "time_attn"), ("norm2", "temporal_norm2"), ("mlp", "temporal_mlp"),
+                      ("gamma_1", "time_gamma_1"), ("gamma_2", "time_gamma_2"))
 
 
 def init_timesformer_keys(state_dict):
-    """models/xvlm.py:442-454 / 585-597: temporal blocks start as copies of the spatial ones."""
-    for from_key, to_key in _TIMESFORMER_MAP.items():
-        for key in list(state_dict.keys()):
-            if to_key in key:
-                state_dict[key.replace(to_key, from_key)] = copy.deepcopy(state_dict[key])
+    """Temporal blocks start as copies of the spatial ones (models/xvlm.py:442-454, 585-597)."""
+    for spatial, temporal in TIMESFORMER_COPIES:
+        for key in [k for k in state_dict if spatial in k]:
+            state_dict[key.replace(spatial, temporal)] = state_dict[key].clone()
+    return state_dict
+
+
+def _model_state(ckpt_rpath):
+    blob = torch.load(ckpt_rpath, map_location="cpu")
+    return blob["model"] if "model" in blob else blob
 
 
 def load_pretrained(model, ckpt_rpath, config, is_eval=False, load_text=False):
-    """models/xvlm.py:390-456 (use_beit_v2 branch): an X2-VLM checkpoint as a state dict for `model`; unless is_eval,
-    the vision tables are resampled to the model's resolution and (load_text) text keys lose their bert. infix."""
-    checkpoint = torch.load(ckpt_rpath, map_location="cpu")
-    state_dict = checkpoint["model"] if "model" in checkpoint.keys() else checkpoint
+    """An X2-VLM checkpoint as a state dict for `model` (models/xvlm.py:390-456, use_beit_v2 branch).  Unless is_eval the
+    vision tables are resampled to the model's resolution and, with load_text, text / cross encoder keys lose their
+    `bert.` / `roberta.` infix."""
+    state_dict = _model_state(ckpt_rpath)
     if is_eval:
         return state_dict
-    print("### Loading pretrained vision encoder", flush=True)
     if not config.get("use_beit_v2", False):
         raise ValueError("only use_beit_v2 vision encoders are built by the MI355X path")
-    vision_state_dict = {}
-    for k in list(state_dict.keys()):
-        if k.startswith("vision_encoder."):
-            vision_state_dict[k[15:]] = state_dict.pop(k)
-    vision_state_dict = interpolate_pos_embed(model.vision_encoder, vision_state_dict)
-    for k in vision_state_dict.keys():
-        state_dict["vision_encoder." + k] = vision_state_dict[k]
+    tag = "vision_encoder."
+    vision = {k[len(tag):]: state_dict.pop(k) for k in [k for k in state_dict if k.startswith(tag)]}
+    for k, v in interpolate_pos_embed(model.vision_encoder, vision).items():
+        state_dict[tag + k] = v
     if load_text:
-        print("### Loading pretrained text encoder", flush=True)
-        for key in list(state_dict.keys()):
-            if key.startswith("text_encoder.") or key.startswith("cross_encoder."):
-                encoder_key = key.replace("roberta.", "").replace("bert.", "").strip()
-                state_dict[encoder_key] = state_dict[key]
-                if encoder_key != key:
-                    del state_dict[key]
+        def strip(key):
+            if not key.startswith(("text_encoder.", "cross_encoder.")):
+                return key
+            for infix in X2VLM_INFIXES:
+                key = key.replace(infix, "")
+            return key.strip()
+        rewrite_keys(state_dict, rename=strip)
     if config.get("init_timesformer", False):
         init_timesformer_keys(state_dict)
     return state_dict
+
+
+def load_state_dict_lenient(model, state_dict, prefix="", ignore_missing="relative_position_index"):
+    """Non-strict load that does not report the index buffers (models/beit2.py:604-650).
+    Returns (missing keys that matter, unexpected keys)."""
+    if prefix:
+        state_dict = {k[len(prefix):] if k.startswith(prefix) else k: v for k, v in state_dict.items()}
+    result = model.load_state_dict(state_dict, strict=False)
+    quiet = ignore_missing.split("|")
+    missing = [k for k in result.missing_keys if not any(q in k for q in quiet)]
+    if missing:
+        print("%s: not in the checkpoint: %s" % (type(model).__name__, missing))
+    if result.unexpected_keys:
+        print("%s: unused checkpoint entries: %s" % (type(model).__name__, list(result.unexpected_keys)))
+    return missing, list(result.unexpected_keys)
+
+
+def load_pretrained_beit2(model, ckpt_rpath):
+    """A stand-alone BEiT-2 checkpoint ('model' | 'module' | bare state dict) into the vision encoder: classifier head
+    dropped, a shared rel_pos_bias table copied to every block, tables resampled.  models/beit2.py:473-601."""
+    print("vision encoder weights <- %s" % ckpt_rpath)
+    blob = torch.load(ckpt_rpath, map_location="cpu")
+    state = next((blob[k] for k in ("model", "module") if k in blob), blob)
+    for k in ("head.weight", "head.bias"):
+        del state[k]                                    # a BEiT-2 file always carries its classifier (KeyError otherwise)
+    shared = "rel_pos_bias.relative_position_bias_table"
+    if getattr(model, "use_rel_pos_bias", False) and shared in state:
+        table = state.pop(shared)
+        for i in range(model.get_num_layers()):
+            state["blocks.%d.attn.relative_position_bias_table" % i] = table.clone()
+    interpolate_pos_embed(model, state)
+    return load_state_dict_lenient(model, state)

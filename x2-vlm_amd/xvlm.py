@@ -129,28 +129,31 @@ class XVLMBase(nn.Module):
         self.init_params = [n for n in self.init_params if n in named]
 
     def load_pretrained(self, ckpt_rpath, config, is_eval=False, is_domain_pretrain=False):
-        """xvlm.py:579-613: load an X2-VLM checkpoint (vision tables resampled to this model's resolution unless
-        is_eval / is_domain_pretrain); parameters the checkpoint lacks join init_params (lr * lr_mult group)."""
-        print("load checkpoint from %s" % ckpt_rpath)
+        """Load an X2-VLM checkpoint (models/xvlm.py:579-613).  Plain pre-training / fine-tuning start: vision tables are
+        resampled to this model's resolution (unless is_eval) and text keys are normalised by checkpoint.load_pretrained;
+        is_domain_pretrain continues from a checkpoint of this very architecture and takes the keys as they are.
+        Parameters the checkpoint does not provide join init_params (the lr * lr_mult group).  Returns the
+        load_state_dict result."""
         if is_domain_pretrain:
-            ck = torch.load(ckpt_rpath, map_location="cpu")
-            state_dict = ck["model"] if "model" in ck.keys() else ck
+            state = checkpoint._model_state(ckpt_rpath)
             if config.get("init_timesformer", False):
-                checkpoint.init_timesformer_keys(state_dict)
+                checkpoint.init_timesformer_keys(state)
         else:
-            state_dict = checkpoint.load_pretrained(self, ckpt_rpath, config, is_eval=is_eval, load_text=True)
-        if hasattr(self, "absolute_frame_pos_embed") and ("absolute_frame_pos_embed" in state_dict.keys()):
-            pretrained = state_dict["absolute_frame_pos_embed"]
-            if pretrained.shape != self.absolute_frame_pos_embed.shape:
-                frame_len = min(pretrained.shape[1], self.absolute_frame_pos_embed.shape[1])
-                self.absolute_frame_pos_embed.data[:, :frame_len, :, :] = pretrained.data[:, :frame_len, :, :]
-                print(f"load absolute_frame_pos_embed[:{frame_len}] ({pretrained.shape[1]}/{self.absolute_frame_pos_embed.shape[1]})", flush=True)
-                del state_dict["absolute_frame_pos_embed"]
-        msg = self.load_state_dict(state_dict, strict=False)
-        print("unexpected_keys: ", msg.unexpected_keys)
-        self.update_init_params([p for p in msg.missing_keys])
-        print("train from scratch: ", sorted(self.init_params))
-        return msg
+            state = checkpoint.load_pretrained(self, ckpt_rpath, config, is_eval=is_eval, load_text=True)
+        own = getattr(self, "absolute_frame_pos_embed", None)
+        given = state.get("absolute_frame_pos_embed")
+        if own is not None and given is not None and given.shape != own.shape:
+            # a checkpoint trained with another clip length: keep the frame positions both have
+            n = min(given.shape[1], own.shape[1])
+            with torch.no_grad():
+                own[:, :n] = given[:, :n]
+            del state["absolute_frame_pos_embed"]
+            print("frame position embedding: %d of %d checkpoint frames used" % (n, given.shape[1]), flush=True)
+        result = self.load_state_dict(state, strict=False)
+        self.update_init_params(list(result.missing_keys))
+        print("checkpoint %s: %d unexpected keys; trained from scratch: %s"
+              % (ckpt_rpath, len(result.unexpected_keys), sorted(self.init_params)), flush=True)
+        return result
 
     # ------------------------------------------------------------------ encoders
     @property
