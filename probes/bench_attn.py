@@ -38,11 +38,13 @@ def case(B, H, Lq, Lk, bias, mask):
                    K.view3(dqkv, B, Lq, 0), K.view3(dkv, B, Lk, HD), K.view3(dkv, B, Lk, 2 * HD), dS=dS, **kw)
     return fwd, bwd
 
-for name, B, H, Lq, Lk, bias, mask in [("vision", 64, 12, 197, 197, True, False), ("text self", 128, 12, 30, 30, False, True),
+for name, B, H, Lq, Lk, bias, mask in [("vision large", 32, 16, 577, 577, True, False), ("vision", 64, 12, 197, 197, True, False), ("text self", 128, 12, 30, 30, False, True),
                                        ("fusion self", 256, 12, 30, 30, False, True)]:
     fwd, bwd = case(B, H, Lq, Lk, bias, mask)
     fl = 4.0 * B * H * Lq * Lk * 64
     t = timeit(fwd); tb = timeit(bwd)
+    if name == "vision large":
+        a_ = K._attn_args  # per-kernel split of the backward
     print("%-12s fwd %6.1fus %5.0fTF   bwd(dq+dkv) %6.1fus %5.0fTF" % (name, t, fl / t / 1e6, tb, 2.5 * fl / tb / 1e6))
     if name == "vision":
         print("   fwd ablation: " + "  ".join("d%d %.1fus" % (g, timeit(lambda g=g: fwd(g))) for g in (0, 1, 2, 3, 4, 8, 12, 15)))

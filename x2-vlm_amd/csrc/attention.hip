@@ -138,7 +138,7 @@ __device__ __forceinline__ void load_bias_mask(const AttnArgs& a, int h, int b, 
 // per workgroup instead of 32-64 KB lets 10 of the 2-wave workgroups share a CU instead of 5, and these launches are a
 // serial load -> multiply -> store chain per workgroup whose only latency hiding is other workgroups).
 template <int QW, int QG, bool RES, int NS = (RES ? 4 : 2)>
-__global__ __launch_bounds__(64 * QW, 4) void attn_fwd_kernel(AttnArgs a) {
+__global__ __launch_bounds__(64 * QW, QG > 1 ? 2 : 4) void attn_fwd_kernel(AttnArgs a) {
   const DropSpec drop_ = drop_at_epoch(a.drop, a.drop_epoch);
   constexpr int NT = 64 * QW;
   __shared__ __attribute__((aligned(16))) char smem[NS][2 * KT * 128];   // {K tile, V tile} per slot
@@ -281,7 +281,7 @@ __global__ __launch_bounds__(64 * QW, 4) void attn_fwd_kernel(AttnArgs a) {
 
 // ------------------------------------------------------------------------------------------ backward: dQ (+ dS)
 template <int QW, int QG, bool RES, int NS = (RES ? 4 : 2)>
-__global__ __launch_bounds__(64 * QW, 4) void attn_bwd_dq_kernel(AttnArgs a) {
+__global__ __launch_bounds__(64 * QW, QG > 1 ? 2 : 4) void attn_bwd_dq_kernel(AttnArgs a) {
   const DropSpec drop_ = drop_at_epoch(a.drop, a.drop_epoch);
   constexpr int NT = 64 * QW;
   __shared__ __attribute__((aligned(16))) char smem[NS][2 * KT * 128];
@@ -831,6 +831,12 @@ extern "C" int x2_attn_fwd(const AttnArgs* pa, void* stream) {
     hipLaunchKernelGGL((attn_fwd_grouped_kernel<8>), dim3(1, a.H, a.Bkv), dim3(512), 0, st, a);
   else if (a.Lq <= 32 && a.Lk <= 64) hipLaunchKernelGGL((attn_fwd_kernel<2, 1, true, 1>), dim3(1, a.H, a.B), dim3(128), 0, st, a);
   else if (a.Lq <= 32) hipLaunchKernelGGL((attn_fwd_kernel<2, 1, false>), dim3(1, a.H, a.B), dim3(128), 0, st, a);
+  else if (a.Lk > 256 && a.Lq > 64 && (attn_variant() & 256))
+    hipLaunchKernelGGL((attn_fwd_kernel<8, 2, false>), dim3((a.Lq + 255) / 256, a.H, a.B), dim3(512), 0, st, a);
+  else if (a.Lk > 256 && a.Lq > 64 && (attn_variant() & 1024))
+    hipLaunchKernelGGL((attn_fwd_kernel<4, 2, false>), dim3((a.Lq + 127) / 128, a.H, a.B), dim3(256), 0, st, a);
+  else if (a.Lk > 256 && a.Lq > 64 && !(attn_variant() & 32))      // long sequences (X2VLM-large, N = 577): 8 waves share each streamed K/V tile (285 -> 254 us)
+    hipLaunchKernelGGL((attn_fwd_kernel<8, 1, false>), dim3((a.Lq + 127) / 128, a.H, a.B), dim3(512), 0, st, a);
   else if (a.Lq <= 64 || a.Lk > 256) hipLaunchKernelGGL((attn_fwd_kernel<4, 1, false>), dim3((a.Lq + 63) / 64, a.H, a.B), dim3(256), 0, st, a);
   else if (attn_variant() & 4) hipLaunchKernelGGL((attn_fwd_kernel<4, 2, true>), dim3((a.Lq + 127) / 128, a.H, a.B), dim3(256), 0, st, a);
   else hipLaunchKernelGGL((attn_fwd_kernel<8, 1, true>), dim3((a.Lq + 127) / 128, a.H, a.B), dim3(512), 0, st, a);
@@ -850,6 +856,12 @@ extern "C" int x2_attn_bwd(const AttnArgs* pa, void* stream) {
     hipLaunchKernelGGL((attn_bwd_dq_grouped_kernel<8>), dim3(1, a.H, a.Bkv), dim3(512), 0, st, a);
   else if (a.Lq <= 32 && a.Lk <= 64) hipLaunchKernelGGL((attn_bwd_dq_kernel<2, 1, true, 1>), dim3(1, a.H, a.B), dim3(128), 0, st, a);
   else if (a.Lq <= 32) hipLaunchKernelGGL((attn_bwd_dq_kernel<2, 1, false>), dim3(1, a.H, a.B), dim3(128), 0, st, a);
+  else if (a.Lk > 256 && a.Lq > 64 && (attn_variant() & 512))
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<8, 2, false>), dim3((a.Lq + 255) / 256, a.H, a.B), dim3(512), 0, st, a);
+  else if (a.Lk > 256 && a.Lq > 64 && (attn_variant() & 2048))
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<4, 2, false>), dim3((a.Lq + 127) / 128, a.H, a.B), dim3(256), 0, st, a);
+  else if (a.Lk > 256 && a.Lq > 64 && !(attn_variant() & 64))      // N = 577: dQ + dK/dV 810 -> 652 us with 8-wave workgroups
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<8, 1, false>), dim3((a.Lq + 127) / 128, a.H, a.B), dim3(512), 0, st, a);
   else if (a.Lq <= 64 || a.Lk > 256) hipLaunchKernelGGL((attn_bwd_dq_kernel<4, 1, false>), dim3((a.Lq + 63) / 64, a.H, a.B), dim3(256), 0, st, a);
   else if (attn_variant() & 2) hipLaunchKernelGGL((attn_bwd_dq_kernel<4, 2, true>), dim3((a.Lq + 127) / 128, a.H, a.B), dim3(256), 0, st, a);
   else hipLaunchKernelGGL((attn_bwd_dq_kernel<8, 1, true>), dim3((a.Lq + 127) / 128, a.H, a.B), dim3(512), 0, st, a);
@@ -865,6 +877,8 @@ extern "C" int x2_attn_bwd(const AttnArgs* pa, void* stream) {
     hipLaunchKernelGGL((attn_bwd_dkv_kernel<8, 1, true>), dim3((a.Lk + 127) / 128, a.H, a.Bkv), dim3(512), 0, st, a);
   } else if (res) {
     hipLaunchKernelGGL((attn_bwd_dkv_kernel<4, 1, true>), dim3((a.Lk + 63) / 64, a.H, a.Bkv), dim3(256), 0, st, a);
+  } else if (a.Lk > 256 && !a.seq_off && !(attn_variant() & 128)) {
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<8, 1, false>), dim3((a.Lk + 127) / 128, a.H, a.Bkv), dim3(512), 0, st, a);
   } else {
     hipLaunchKernelGGL((attn_bwd_dkv_kernel<4, 1, false>), dim3((a.Lk + 63) / 64, a.H, a.Bkv), dim3(256), 0, st, a);
   }
