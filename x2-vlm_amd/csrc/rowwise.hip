@@ -619,23 +619,36 @@ extern "C" int x2_pool_tokens(float* x, const float* w, int B, int P, int D, int
 
 // ---------------------------------------------------------------------------------- rel-pos bias
 // bias[h][i][j] = table[index[i][j]][h] for i,j < N (padded [H][N][ld]); biasT[h][j][i] likewise [H][N][ldT].
+// indexT (optional) = the transposed index [j][i], built once by the host from the static buffer: with it the transposed
+// copy is written row-contiguously as well (a thread-per-(i,j) scatter into biasT is one 4-byte write per cache line:
+// 57 us per X2VLM-large block).
 __global__ __launch_bounds__(256) void relpos_bias_kernel(const float* __restrict__ table, const long* __restrict__ index,
-                                                          float* bias, float* biasT, int N, int H, int ld, int ldT) {
+                                                          const long* __restrict__ indexT, float* bias, float* biasT, int N, int H,
+                                                          int ld, int ldT) {
   const long total = (long)N * N;
   long e = blockIdx.x * 256L + threadIdx.x;
   if (e >= total) return;
   const int i = (int)(e / N), j = (int)(e % N);
   const long idx = index[e];
+  if (indexT && biasT) {
+    const long idt = indexT[e];
+    for (int h = 0; h < H; ++h) {
+      bias[((long)h * N + i) * ld + j] = table[idx * H + h];
+      biasT[((long)h * N + i) * ldT + j] = table[idt * H + h];
+    }
+    return;
+  }
   for (int h = 0; h < H; ++h) {
     const float v = table[idx * H + h];
     bias[((long)h * N + i) * ld + j] = v;
     if (biasT) biasT[((long)h * N + j) * ldT + i] = v;
   }
 }
-extern "C" int x2_relpos_bias(const float* table, const long* index, float* bias, float* biasT, int N, int H, int ld, int ldT, void* stream) {
+extern "C" int x2_relpos_bias(const float* table, const long* index, const long* indexT, float* bias, float* biasT, int N, int H, int ld,
+                              int ldT, void* stream) {
   X2_REQUIRE(N > 0 && H > 0 && ld >= N && (!biasT || ldT >= N), "x2_relpos_bias: N=%d H=%d ld=%d ldT=%d", N, H, ld, ldT);
-  hipLaunchKernelGGL(relpos_bias_kernel, dim3((int)(((long)N * N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, table, index, bias,
-                     biasT, N, H, ld, ldT);
+  hipLaunchKernelGGL(relpos_bias_kernel, dim3((int)(((long)N * N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, table, index, indexT,
+                     bias, biasT, N, H, ld, ldT);
   return x2_check_launch("x2_relpos_bias");
 }
 // dtable[index[i][j]][h] += sum_b dS[b][h][i][j]   (dS bf16 [B][H][N][ld], ld % 8 == 0), without atomics:

@@ -359,11 +359,23 @@ def relpos_bias(table, index, want_T=True):
     # pad columns stay undefined: the attention kernels select on key < Lk / query < Lq before using a bias value
     bias = torch.empty(H, N, ld, device=table.device, dtype=F32)
     biasT = torch.empty(H, N, ld, device=table.device, dtype=F32) if want_T else None
-    call("x2_relpos_bias", ptr(table), ptr(index), ptr(bias), ptr(biasT), N, H, ld, ld)
+    call("x2_relpos_bias", ptr(table), ptr(index), ptr(_relpos_index_t(index)) if want_T else None, ptr(bias), ptr(biasT), N, H, ld, ld)
     return bias, biasT
 
 
 _RELPOS_CSR = {}
+_RELPOS_T = {}
+
+
+def _relpos_index_t(index):
+    """Transposed copy of the (static) relative_position_index, built once per buffer: lets x2_relpos_bias write the
+    transposed bias row-contiguously."""
+    key = (index.data_ptr(), index._version)
+    ent = _RELPOS_T.get(key)
+    if ent is None:
+        ent = _RELPOS_T[key] = (index.t().contiguous(), index)      # keeps `index` alive: the key holds its address
+    return ent[0]
+
 
 
 def _relpos_csr(index, ld, T):
@@ -388,7 +400,7 @@ def relpos_bias_bwd(dS, index, dtable):
     T = dtable.shape[0]
     assert dS.dtype == BF16 and dS.is_contiguous() and dtable.dtype == F32 and dtable.is_contiguous() and dtable.shape[1] == H
     off, pos = _relpos_csr(index, ld, T)
-    slices = max(1, min(8, B // 8))
+    slices = 1      # probes/bench_relpos.py: 21 / 109 us (base / large) with one slice vs 51 / 217 us with 8 / 4: the gather reads S x
     ws = workspace(dS.device, slices * H * N * ld)
     call("x2_relpos_bias_bwd", ptr(dS), ptr(off), ptr(pos), ptr(dtable), B, N, H, ld, T, ptr(ws), slices)
 
