@@ -237,8 +237,11 @@ def main():
     # ~25 ms (base) / ~100 ms (large) of Python + ctypes launch time per step that bounded round 1.  The optimizer stays
     # outside the graph.  X2_GRAPH=0 / --no-graph: eager launches.
     graph = importlib.import_module("x2-vlm_amd.graph")
-    # gloo collectives (the 2-ranks-on-one-GPU debug mode) synchronise the host and cannot be captured
-    runner = graph.GraphedStep(fwd_bwd, warmup=1, enabled=not args.no_graph and (world == 1 or backend == "nccl"), verbose=(rank == 0))
+    # N > 1: eager launches.  The bucketed all-reduce waits on events of the weight-gradient and text-tower streams, i.e.
+    # side stream -> side stream edges, which ROCm 7's stream capture does not survive (probes/graph_capture_probe.py);
+    # issuing every collective on the capture's origin stream instead would serialise ~1 GB of all-reduce with the
+    # critical path.  Eager multi-GPU steps keep the overlap (and are host-bound at ~30 ms, as in round 1).
+    runner = graph.GraphedStep(fwd_bwd, warmup=1, enabled=not args.no_graph and world == 1, verbose=(rank == 0))
 
     def step():
         loss = runner()

@@ -6,7 +6,9 @@ Tolerances (bf16 GEMM/attention operands, fp32 everything else, vs the reference
   losses              1e-3 relative at the headline batch (case base_full_b64, BASELINE.json configs[1]:
                       the north-star tolerance); 5e-3 for the 3..6-sample toy batches, whose losses
                       average the same per-sample bf16 operand-rounding noise over 16x fewer samples
-  activations/logits  2.5e-2 of the tensor's max-abs (one bf16 rounding is 2^-9 of an element; ~36 GEMMs deep)
+  activations/logits  2.5e-2 of the tensor's max-abs pointwise (one bf16 rounding is 2^-9 of an element; ~36 GEMMs deep;
+                      measured 0.2-1.9e-2); 2e-3 for whole-tensor moments, 1e-3 for the MLM log-partition, 5e-3 for bbox
+                      coordinates (measured 6e-4, 7e-5, 1.7e-3)
   parameter grads     per-tensor norm error <= 3e-2 of max(its norm, 1e-2 x total gradient norm): tensors whose
                       true gradient is ~0 by cancellation (q/k projections of saturated attention, key biases)
                       are held to 3e-4 of the total norm instead of to their own norm;
@@ -79,7 +81,9 @@ def test_step_matches_reference(case, tmp_path, synthetic):
         got = reduce_out(acts[name], full)[kind]
         ref = gold[k].astype(np.float64)
         scale = max(np.abs(ref).max(), 1e-6)
-        tol = 2.5e-2
+        # whole-tensor moments and the MLM log-partition are averages over thousands of elements: held to ~1e-3;
+        # bbox coordinates are sigmoid outputs of an fp32 head fed by one bf16 fusion pass
+        tol = 2e-3 if kind == "moments" else 1e-3 if name == "mlm_lse" else 5e-3 if name == "bbox_coord" else 2.5e-2
         report.append(("act " + name + "/" + kind, float(np.abs(got - ref).max() / scale), tol))
     sd = dict(model.named_parameters())
     total = float(gold["total_grad_norm"])

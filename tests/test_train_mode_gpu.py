@@ -175,3 +175,93 @@ def test_whole_model_train_mode_sanity(synthetic):
         for k in d:
             assert math.isfinite(d[k]) and abs(d[k] - ev[k]) < 2.0 * max(1.0, abs(ev[k])), (k, d[k], ev[k])
     assert math.isfinite(gn1) and math.isfinite(gn2)
+
+
+def test_whole_model_train_mode_matches_oracle_with_same_masks(synthetic):
+    """The WHOLE training step in train mode (what bench.py times): every dropout site of the text tower, the fusion stack
+    and the embeddings plus per-sample DropPath, against the oracle's stage functions run with exactly the masks the HIP
+    path drew (host mirror of the counter-based generator).  The oracle stages are composed in the order the product
+    batches them (clean + masked ids as one 2B-row text batch; positives, two negative sets and the MLM rows as one 4B-row
+    fusion batch), because a mask element is addressed by its position in that batch; in eval mode this composition is
+    the pinned oracle.xvlm_forward (tests/test_oracle_golden.py, test_model_gpu.py)."""
+    K = importlib.import_module("x2-vlm_amd.kernels")
+    xbert = importlib.import_module("x2-vlm_amd.xbert")
+    mp = importlib.import_module("x2-vlm_amd.model_pretrain")
+    c = CASES["tiny"]
+    cfg = O.config_from_case(c)
+    model = mp.XVLM(config=model_config("tiny", tempfile.mkdtemp()), load_vision_params=False, load_text_params=False)
+    synthetic.synth_state_dict(model, c["wseed"])
+    model = model.to(dev).train()
+    sd = O.make_params(cfg, c["wseed"], synthetic.synth_tensor)
+    batch = synthetic.synth_batch(c["bseed"], c["batch"], c["seq_len"], c["image_res"], c["vocab"], c["max_masks"], ragged=True)
+    ineg, tneg = synthetic.synth_negatives(c["bseed"], c["batch"])
+    model.injected_negatives = (ineg, tneg)
+    B, L, Hd, H, V = c["batch"], c["seq_len"], c["hidden"], c["heads"], c["vocab"]
+    depth = c["vision_layers"]
+    keep = (torch.rand(depth, 2, B, generator=torch.Generator().manual_seed(9)) > 0.3).float()
+    model.vision_encoder.fixed_drop_path_keep = keep
+    s_emb, s_text, s_fus = 1001, 2002, 3003
+    xbert._FIXED_SEEDS[:] = [s_emb, s_text, s_fus]
+    gb = {k: v.to(dev) for k, v in batch.items()}
+    loss = model(gb["image"], gb["text_ids"], gb["text_atts"], text_ids_masked=gb["text_ids_masked"], masked_pos=gb["masked_pos"],
+                 masked_ids=gb["masked_ids"])
+    sum(loss.values()).backward()
+    torch.cuda.synchronize()
+    assert not xbert._FIXED_SEEDS                      # exactly three draws: embeddings, text layers, fusion layers
+
+    # ---- the same step on the oracle, same masks ----
+    bc = model.text_encoder.config
+    p_h, p_a = bc.hidden_dropout_prob, bc.attention_probs_dropout_prob
+    T = cfg.n_tokens
+
+    def masks(seed, S, Lk_cross):
+        def drop(name):
+            if name == "emb":
+                return K.dropout_keep(K.dropout_spec(p_h, s_emb, 1000), torch.arange(S * L * Hd)).view(S, L, Hd)
+            layer = int(name[1:name.index(".")])
+            kind = {"self.probs": 0, "self.out": 1, "cross.probs": 2, "cross.out": 3, "ffn.out": 4}[name[name.index(".") + 1:]]
+            spec = K.dropout_spec(p_a if kind in (0, 2) else p_h, seed, 8 * layer + kind)
+            if kind in (1, 3, 4):
+                return K.dropout_keep(spec, torch.arange(S * L * Hd)).view(S, L, Hd)
+            Lk = L if kind == 0 else Lk_cross
+            b, h, q, k = torch.meshgrid(torch.arange(S), torch.arange(H), torch.arange(L), torch.arange(Lk), indexing="ij")
+            return K.dropout_keep(spec, ((b * H + h) * L + q) * K.round_up(Lk, 64) + k)
+        return drop
+
+    rates = [blk.drop_path_rate for blk in model.vision_encoder.blocks]
+    dp = [tuple(((keep[i, j] if rates[i] > 0 else torch.ones(B)) / (1 - rates[i])).view(B, 1, 1) for j in range(2)) for i in range(depth)]
+    ids2 = torch.cat([batch["text_ids"], batch["text_ids_masked"]]); atts2 = torch.cat([batch["text_atts"], batch["text_atts"]])
+    d_text = masks(s_text, 2 * B, 0)
+    both = O.bert_encoder(sd, cfg, O.text_embeddings(sd, cfg, ids2, d_text), atts2, mode="text", drop=d_text)
+    image_embeds = O.vision_encoder(sd, cfg, batch["image"], drop_path=dp)
+    fi, ft = O.features(sd, image_embeds, both[:B])
+    ref = {"loss_itc": O.contrastive_loss(sd, fi, ft)[0]}
+    ar = torch.arange(B)
+    t_idx = torch.cat([ar, ar, torch.tensor(tneg), ar + B]); kv = torch.cat([ar, torch.tensor(ineg), ar, ar])
+    ones = torch.ones(4 * B, T, dtype=torch.int64)
+    fused = O.bert_encoder(sd, cfg, both[t_idx], atts2[t_idx], image_embeds[kv], ones, "fusion", masks(s_fus, 4 * B, T))
+    labels = torch.cat([torch.ones(B, dtype=torch.int64), torch.zeros(2 * B, dtype=torch.int64)])
+    ref["loss_itm"] = O.cross_entropy(O.head_mlp(sd, "itm_head", fused[:3 * B, 0]), labels)
+    h = fused[-B:].gather(1, batch["masked_pos"].unsqueeze(-1).expand(-1, -1, Hd))
+    pr = "text_encoder.cls.predictions."
+    h = O.gelu(O.linear(h, sd[pr + "transform.dense.weight"], sd[pr + "transform.dense.bias"]))
+    h = O.layer_norm(h, sd[pr + "transform.LayerNorm.weight"], sd[pr + "transform.LayerNorm.bias"], 1e-12)
+    logits = O.linear(h, sd["text_encoder.bert.embeddings.word_embeddings.weight"], sd[pr + "bias"])
+    ref["loss_mlm"] = O.cross_entropy(logits.reshape(-1, V), batch["masked_ids"].reshape(-1))
+    sum(ref.values()).backward()
+
+    for k in ref:
+        assert abs(float(loss[k]) - float(ref[k])) <= 5e-3 * max(1.0, abs(float(ref[k]))), (k, float(loss[k]), float(ref[k]))
+    got = {n: p.grad for n, p in model.named_parameters() if p.grad is not None}
+    tot = math.sqrt(sum(float(t.grad.double().pow(2).sum()) for t in sd.values() if t.grad is not None))
+    gn = math.sqrt(sum(float(g.double().pow(2).sum()) for g in got.values()))
+    assert abs(gn - tot) <= 1e-2 * tot, (gn, tot)
+    worst = ("", 0.0)
+    for n, g in got.items():
+        r = sd[n].grad
+        if n == "text_encoder.cls.predictions.decoder.weight" or r is None:
+            continue
+        err = float((g.cpu().double() - r.double()).norm()) / max(float(r.double().norm()), 1e-2 * tot)
+        worst = max(worst, (n, err), key=lambda t: t[1])
+        assert err < 5e-2, (n, err)
+    print("whole-model train mode: losses", {k: (round(float(loss[k]), 5), round(float(ref[k]), 5)) for k in ref}, "worst grad", worst)
