@@ -345,6 +345,13 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_w8_kernel(GemmNT p) {
 //   [3] NT tile: 1 = 128x128, 2 = 192x128, 3 = 64x128        [4] NT start stagger (x 4 us)
 //   [5] TN: 1 = always 128x128 tiles, 2 = 256x256 tiles whenever the contraction lengths allow
 static int g_tune[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+extern "C" int x2_device_cus(void);
+// compute units of the current device (256 on MI355X), asked once: grid-fill decisions below are made in units of it
+static int x2_cus() {
+  static int n = 0;
+  if (n <= 0) { n = x2_device_cus(); if (n <= 0) n = 256; }
+  return n;
+}
 extern "C" int x2_tune(int key, int value) {
   if (key < 0 || key >= 8) return X2_ERR_ARG;
   g_tune[key] = value;
@@ -386,8 +393,11 @@ extern "C" int x2_gemm_nt(const void* A, const void* B, void* C, int M, int N, i
     const int t64 = ((M + 63) / 64) * ((N + BN - 1) / BN);
     // measured (probes/bench_gemm.py): 64x128 wins up to ~1.2 workgroups of 128x128 per CU slot pair, except on long
     // contractions with exactly one 192x128 round (fc2, dqkv: 757 / 817 TFLOP/s on 192x128)
-    const bool use64 = g_tune[3] == 3 || (g_tune[3] == 0 && (t128 <= 512 || (t128 <= 600 && K <= 1024)));
-    const bool use192 = !use64 && (g_tune[3] == 2 || (g_tune[3] == 0 && t128 > 512 && t192 <= 512));
+    const int slots = 2 * x2_cus();                      // two 128x128 workgroups per CU
+    const bool use64 = g_tune[3] == 3 || (g_tune[3] == 0 && (t128 <= slots || (t128 <= slots + slots / 6 && K <= 1024)));
+    // (192x128 on the long-row shapes of X2VLM-large - qkv / fc1 at K = 1024, fc2 at K = 4096 - is 4-9 % faster in
+    // probes/bench_gemm_large.py but neutral inside the step: not selected)
+    const bool use192 = !use64 && (g_tune[3] == 2 || (g_tune[3] == 0 && t128 > slots && t192 <= slots));
     if (use64) {
       hipLaunchKernelGGL(gemm_nt_kernel<2>, dim3(t64), dim3(256), 2 * (64 * 128 + TILE_BYTES), (hipStream_t)stream, p);
     } else if (use192) {
@@ -769,7 +779,7 @@ extern "C" int x2_gemm_tn_grouped(const int64_t* problems, int count, int accumu
   if (big) {
     int t = 0;
     for (int i = 0; i < count; ++i) { g.p[i].tile_begin = t; g.p[i].tiles_k = (g.p[i].K + 255) / 256; t += ((g.p[i].N + 255) / 256) * g.p[i].tiles_k; }
-    int cus = 256;
+    const int cus = x2_cus();
     int sp = split;
     if (sp == 0) {              // fullest last round of one-workgroup-per-CU slots, fewest partial tiles on a tie
       double best = -1.0; sp = 1;
