@@ -237,11 +237,26 @@ def main():
     # ~25 ms (base) / ~100 ms (large) of Python + ctypes launch time per step that bounded round 1.  The optimizer stays
     # outside the graph.  X2_GRAPH=0 / --no-graph: eager launches.
     graph = importlib.import_module("x2-vlm_amd.graph")
+    use_graph = not args.no_graph and world == 1
+    if use_graph and os.environ.get("X2_GRAPH_CANARY", "1") == "1" and not args.tiny:
+        # Multi-stream capture leans on ROCm behaviour found by probing (graph.py): a runtime that breaks it tends to crash
+        # inside hipStreamEndCapture, which cannot be caught in-process.  A 2-layer copy of this step is captured in a child
+        # process first (~10 s); if that does not come back with launch_mode == "hipgraph" the benchmark launches eagerly.
+        import subprocess
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--tiny", "--config", args.config, "--batch", "4", "--steps", "1",
+                                "--warmup", "1", "--no-cpu-baseline"], capture_output=True, text=True, timeout=240,
+                               env=dict(os.environ, X2_GRAPH_CANARY="0"))
+            use_graph = r.returncode == 0 and '"launch_mode": "hipgraph"' in r.stdout
+        except Exception:      # noqa: BLE001
+            use_graph = False
+        if not use_graph and rank == 0:
+            print("bench: hipGraph canary failed, launching eagerly", file=sys.stderr, flush=True)
     # N > 1: eager launches.  The bucketed all-reduce waits on events of the weight-gradient and text-tower streams, i.e.
     # side stream -> side stream edges, which ROCm 7's stream capture does not survive (probes/graph_capture_probe.py);
     # issuing every collective on the capture's origin stream instead would serialise ~1 GB of all-reduce with the
     # critical path.  Eager multi-GPU steps keep the overlap (and are host-bound at ~30 ms, as in round 1).
-    runner = graph.GraphedStep(fwd_bwd, warmup=1, enabled=not args.no_graph and world == 1, verbose=(rank == 0))
+    runner = graph.GraphedStep(fwd_bwd, warmup=1, enabled=use_graph, verbose=(rank == 0))
 
     def step():
         loss = runner()
