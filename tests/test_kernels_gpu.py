@@ -427,7 +427,14 @@ def test_cross_entropy_and_sampling(K):
     w = torch.softmax(sim, 1) + 1e-5; w.fill_diagonal_(0)
     cdf = torch.cumsum(w.double(), 1)
     refpick = (cdf > (u.double() * cdf[:, -1]).unsqueeze(1)).float().argmax(1)
-    assert (pick != torch.arange(n)).all() and (pick == refpick).float().mean() > 0.95
+    assert (pick != torch.arange(n)).all()
+    # inverse-CDF draw in fp32 on the device vs float64 here: a different pick is only acceptable where the target u * total
+    # sits within fp32 rounding of the CDF step that separates the two candidates
+    target = u.double() * cdf[:, -1]
+    for r in (pick != refpick).nonzero().flatten().tolist():
+        lo = min(int(pick[r]), int(refpick[r]))
+        assert abs(int(pick[r]) - int(refpick[r])) == 1 or w[r, lo + 1:max(int(pick[r]), int(refpick[r]))].sum() == 0, (r, pick[r], refpick[r])
+        assert abs(float(cdf[r, lo] - target[r])) <= 1e-5 * float(cdf[r, -1]), (r, float(cdf[r, lo]), float(target[r]))
     x = rnd(1000, seed=5); dy = rnd(1000, seed=6)
     xl = x.clone().requires_grad_(True); O.gelu(xl).backward(dy)
     assert relerr(K.gelu_f32(x.to(dev)), O.gelu(x)) < 1e-6 and relerr(K.gelu_f32(x.to(dev), dy.to(dev)), xl.grad) < 1e-5
