@@ -237,6 +237,8 @@ def main():
     # ~25 ms (base) / ~100 ms (large) of Python + ctypes launch time per step that bounded round 1.  The optimizer stays
     # outside the graph.  X2_GRAPH=0 / --no-graph: eager launches.
     graph = importlib.import_module("x2-vlm_amd.graph")
+    if os.environ.get("X2_HACK_NT_ABLATE"):           # timing experiment only (garbage outputs): NT GEMM ablation bits, gemm.hip
+        importlib.import_module("x2-vlm_amd._lib").lib().x2_tune(2, int(os.environ["X2_HACK_NT_ABLATE"]))
     use_graph = not args.no_graph and world == 1
     if use_graph and os.environ.get("X2_GRAPH_CANARY", "1") == "1" and not args.tiny:
         # Multi-stream capture leans on ROCm behaviour found by probing (graph.py): a runtime that breaks it tends to crash
