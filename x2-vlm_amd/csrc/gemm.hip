@@ -61,8 +61,35 @@ __device__ __forceinline__ void st16(void* p, u32x4 v, bool wt) {
   else *reinterpret_cast<u32x4*>(p) = v;
 }
 
-template <int TM>
+// VAR: the epilogue's feature set as a compile-time constant for the shapes that carry the step (a runtime flag tested inside
+// the row-group loop costs ~1 % of the NT GEMM time each: two extra ablation flags measured +2.3 % on the whole step):
+//   0 bias -> bf16            (qkv / q / kv projections, bf16 input gradients)
+//   1 bias -> fp32            (fp32 input gradients, logits, head linears)
+//   2 bias, GELU, pre-activation saved -> bf16                  (fc1 / intermediate forward)
+//   3 x GELU'(saved pre-activation), column sums -> bf16        (input gradient through the GELU)
+//   5 bias, (dropout), + residual -> fp32                       (BERT output projections, BERT input gradients)
+//   6 bias, layer scale (x DropPath row factor), value before the scale saved, + residual -> fp32   (BEiT proj / fc2)
+//   4 everything decided at run time (any other combination)
+template <int V> struct EpiTraits {
+  static constexpr bool generic = V == 4;
+  static constexpr int act = V == 2 ? 1 : V == 3 ? 2 : 0;
+  static constexpr bool out_f32 = V == 1 || V == 5 || V == 6;
+  static constexpr bool resid = V == 5 || V == 6;
+  static constexpr bool scale = V == 6;           // gamma and optional rowscale
+  static constexpr bool aux0 = V == 6;            // act == 0 with aux: save the value before the layer scale
+  static constexpr bool drop = V == 5;            // dropout possible (still a runtime test on thr16, outside the hot variants)
+  static constexpr bool colsum = V == 3;
+};
+template <int TM, int VAR>
 __device__ __forceinline__ void nt_epilogue(const GemmNT& p, f32x4 (&acc)[TM][4], char* smem, int wave, int lane, int mw0, int nw0) {
+  using E = EpiTraits<VAR>;
+  const int act = E::generic ? p.act : E::act;
+  const bool out_f32 = E::generic ? p.out_f32 != 0 : E::out_f32;
+  const bool has_resid = E::generic ? p.resid != nullptr : E::resid;
+  const bool has_scale = E::generic ? (p.gamma != nullptr || p.rowscale != nullptr) : E::scale;
+  const bool has_aux0 = E::generic ? (p.act == 0 && p.aux != nullptr) : E::aux0;
+  const bool has_drop = (E::generic || E::drop) ? p.drop.thr16 != 0 : false;
+  const bool has_colsum = E::generic ? p.colsum != nullptr : (E::colsum && p.colsum != nullptr);
   const int frow = lane & 15, fg = lane >> 4;
   float* stg = reinterpret_cast<float*>(smem) + wave * (32 * 68);
   // read-back: 8 lanes x 8 columns cover one 64-column row (32-byte fp32 reads, 16-byte bf16 / 2 x 16-byte fp32 stores),
@@ -75,7 +102,7 @@ __device__ __forceinline__ void nt_epilogue(const GemmNT& p, f32x4 (&acc)[TM][4]
   for (int e = 0; e < 8; ++e) { bb[e] = 0.f; gg[e] = 1.f; }
   if (nok && p.bias) { const float4 b0 = *reinterpret_cast<const float4*>(p.bias + n), b1 = *reinterpret_cast<const float4*>(p.bias + n + 4);
     bb[0] = b0.x; bb[1] = b0.y; bb[2] = b0.z; bb[3] = b0.w; bb[4] = b1.x; bb[5] = b1.y; bb[6] = b1.z; bb[7] = b1.w; }
-  if (nok && p.gamma) { const float4 g0 = *reinterpret_cast<const float4*>(p.gamma + n), g1 = *reinterpret_cast<const float4*>(p.gamma + n + 4);
+  if (nok && has_scale && p.gamma) { const float4 g0 = *reinterpret_cast<const float4*>(p.gamma + n), g1 = *reinterpret_cast<const float4*>(p.gamma + n + 4);
     gg[0] = g0.x; gg[1] = g0.y; gg[2] = g0.z; gg[3] = g0.w; gg[4] = g1.x; gg[5] = g1.y; gg[6] = g1.z; gg[7] = g1.w; }
   float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   const bool wt = (p.dbg & 16) != 0;
@@ -89,7 +116,7 @@ __device__ __forceinline__ void nt_epilogue(const GemmNT& p, f32x4 (&acc)[TM][4]
     float4 r0[4], r1[4];
     u32x4 pre[4];
     const int nc = nok ? n : 0;
-    if (p.resid) {
+    if (has_resid) {
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) {
         const int mc = min(mw0 + half * 32 + rr * 8 + er, p.M - 1);
@@ -97,7 +124,7 @@ __device__ __forceinline__ void nt_epilogue(const GemmNT& p, f32x4 (&acc)[TM][4]
         r1[rr] = *reinterpret_cast<const float4*>(p.resid + (size_t)mc * p.ldr + nc + 4);
       }
     }
-    if (p.act == 2) {
+    if (act == 2) {
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) {
         const int mc = min(mw0 + half * 32 + rr * 8 + er, p.M - 1);
@@ -117,33 +144,37 @@ __device__ __forceinline__ void nt_epilogue(const GemmNT& p, f32x4 (&acc)[TM][4]
       const float4 a0 = *reinterpret_cast<const float4*>(stg + row * 68 + ec), a1 = *reinterpret_cast<const float4*>(stg + row * 68 + ec + 4);
       if (m >= p.M || !nok) continue;
       float v[8] = {a0.x + bb[0], a0.y + bb[1], a0.z + bb[2], a0.w + bb[3], a1.x + bb[4], a1.y + bb[5], a1.z + bb[6], a1.w + bb[7]};
-      if (p.act == 1) {
+      if (act == 1) {
         st16(p.aux + (size_t)m * p.ldaux + n, u32x4{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7])}, wt);
 #pragma unroll
         for (int r = 0; r < 8; ++r) v[r] = gelu_f(v[r]);
-      } else if (p.act == 2) {
+      } else if (act == 2) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) { v[2 * r] *= dgelu_f(bf_lo(pre[rr][r])); v[2 * r + 1] *= dgelu_f(bf_hi(pre[rr][r])); }
-      } else if (p.aux) {
+      } else if (has_aux0) {
         st16(p.aux + (size_t)m * p.ldaux + n, u32x4{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7])}, wt);
       }
-      if (drop_.thr16) {
+      if (has_drop) {
         float dm[4];
         drop_mul4(drop_, (uint32_t)m * (uint32_t)p.N + (uint32_t)n, dm);
         v[0] *= dm[0]; v[1] *= dm[1]; v[2] *= dm[2]; v[3] *= dm[3];
         drop_mul4(drop_, (uint32_t)m * (uint32_t)p.N + (uint32_t)n + 4u, dm);
         v[4] *= dm[0]; v[5] *= dm[1]; v[6] *= dm[2]; v[7] *= dm[3];
       }
-      const float rs_ = p.rowscale ? p.rowscale[m] : 1.f;
+      if (has_scale) {
+        const float rs_ = p.rowscale ? p.rowscale[m] : 1.f;
 #pragma unroll
-      for (int r = 0; r < 8; ++r) v[r] *= gg[r] * rs_;
-      if (p.resid) {
+        for (int r = 0; r < 8; ++r) v[r] *= gg[r] * rs_;
+      }
+      if (has_resid) {
         v[0] += r0[rr].x; v[1] += r0[rr].y; v[2] += r0[rr].z; v[3] += r0[rr].w;
         v[4] += r1[rr].x; v[5] += r1[rr].y; v[6] += r1[rr].z; v[7] += r1[rr].w;
       }
+      if (has_colsum) {
 #pragma unroll
-      for (int r = 0; r < 8; ++r) cs[r] += v[r];
-      if (p.out_f32) {
+        for (int r = 0; r < 8; ++r) cs[r] += v[r];
+      }
+      if (out_f32) {
         float* c = reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n;
         st16(c, u32x4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])}, wt);
         st16(c + 4, u32x4{__float_as_uint(v[4]), __float_as_uint(v[5]), __float_as_uint(v[6]), __float_as_uint(v[7])}, wt);
@@ -153,7 +184,7 @@ __device__ __forceinline__ void nt_epilogue(const GemmNT& p, f32x4 (&acc)[TM][4]
       }
     }
   }
-  if (p.colsum) {     // lanes sharing (lane & 7) hold the same 8 columns for different rows: fold 8 -> 1, one atomic per column
+  if (has_colsum) {     // lanes sharing (lane & 7) hold the same 8 columns for different rows: fold 8 -> 1, one atomic per column
 #pragma unroll
     for (int e = 0; e < 8; ++e) { cs[e] += __shfl_xor(cs[e], 8, 64); cs[e] += __shfl_xor(cs[e], 16, 64); cs[e] += __shfl_xor(cs[e], 32, 64); }
     if (er == 0 && nok) {
@@ -167,7 +198,7 @@ __device__ __forceinline__ void nt_epilogue(const GemmNT& p, f32x4 (&acc)[TM][4]
 // NT: both operands K-contiguous.  LDS image per operand: [128 rows][8 chunks of 16 B], chunk c of
 // row r stored at chunk position c ^ (r & 7)  -> conflict-free ds_read_b128 fragment reads.
 // ---------------------------------------------------------------------------------------------
-template <int TM>   // 16-row MFMA tiles per wave along M: 4 -> 128x128 block tile, 6 -> 192x128 (2 x 80 KB LDS = exactly 2 blocks / CU)
+template <int TM, int VAR>   // TM: 16-row MFMA tiles per wave along M: 4 -> 128x128 block tile, 6 -> 192x128 (2 x 80 KB LDS = exactly 2 blocks / CU)
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNT p) {
   constexpr int BMT = 32 * TM;                       // block rows (2 waves along M)
   constexpr int A_BYTES = BMT * 128, STG = A_BYTES + TILE_BYTES;
@@ -276,7 +307,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNT p) {
 
   __syncthreads();                                   // every wave is done reading the last operand tiles
   if (p.dbg & 4) { if (acc[0][0][0] == 12345.678f) reinterpret_cast<float*>(p.C)[0] = acc[1][1][1] + acc[2][2][2] + acc[3][3][3]; return; }
-  nt_epilogue<TM>(p, acc, smem, wave, lane, m0 + wm * 16 * TM, n0 + wn * 64);
+  nt_epilogue<TM, VAR>(p, acc, smem, wave, lane, m0 + wm * 16 * TM, n0 + wn * 64);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -357,12 +388,12 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_w8_kernel(GemmNT p) {
     buf = buf == 2 ? 0 : buf + 1;
   }
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // every wave is done reading operand tiles
-  nt_epilogue<4>(p, acc, smem, wave, lane, m0 + wm * 64, n0 + wn * 64);
+  nt_epilogue<4, 4>(p, acc, smem, wave, lane, m0 + wm * 64, n0 + wn * 64);
 }
 
 // knobs for A/B measurements and for the tests that pin a kernel variant (0 = automatic everywhere):
 //   [0] GROUP_M of the NT tile raster            [1] 2: NT on the 8-wave 256x128 kernel
-//   [2] NT ablation bits (4 no epilogue, 16 sc1 stores)
+//   [2] NT ablation bits (4 no epilogue, 16 sc1 stores)          [6] 1: always the generic (run-time flags) NT epilogue
 //   [3] NT tile: 1 = 128x128, 2 = 192x128, 3 = 64x128        [4] NT start stagger (x 4 us)
 //   [5] TN: 1 = always 128x128 tiles, 2 = 256x256 tiles whenever the contraction lengths allow
 static int g_tune[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -419,15 +450,38 @@ extern "C" int x2_gemm_nt(const void* A, const void* B, void* C, int M, int N, i
     // (192x128 on the long-row shapes of X2VLM-large - qkv / fc1 at K = 1024, fc2 at K = 4096 - is 4-9 % faster in
     // probes/bench_gemm_large.py but neutral inside the step: not selected)
     const bool use192 = !use64 && (g_tune[3] == 2 || (g_tune[3] == 0 && t128 > slots && t192 <= slots));
-    if (use64) {
-      hipLaunchKernelGGL(gemm_nt_kernel<2>, dim3(t64), dim3(256), 2 * (64 * 128 + TILE_BYTES), (hipStream_t)stream, p);
-    } else if (use192) {
-      static bool attr192 = false;
-      if (!attr192) { hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<6>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (192 * 128 + TILE_BYTES)); attr192 = true; }
-      hipLaunchKernelGGL(gemm_nt_kernel<6>, dim3(t192), dim3(256), 2 * (192 * 128 + TILE_BYTES), (hipStream_t)stream, p);
-    } else {
-      hipLaunchKernelGGL(gemm_nt_kernel<4>, dim3(t128), dim3(256), GEMM_LDS_BYTES, (hipStream_t)stream, p);
+    // epilogue variant (EpiTraits): the feature sets the step uses are compiled separately, anything else runs the generic one
+    int var = 4;
+    const bool plain = !gamma && !rowscale && !drop_thr16 && !colsum;
+    if (g_tune[6] == 1) var = 4;                                                     // probes / tests: force the generic epilogue
+    else if (act == 1 && !out_f32 && !resid && plain) var = 2;
+    else if (act == 2 && !out_f32 && !resid && !gamma && !rowscale && !drop_thr16) var = 3;
+    else if (act == 0 && !aux && !resid && plain) var = out_f32 ? 1 : 0;
+    else if (act == 0 && !aux && resid && out_f32 && !gamma && !rowscale && !colsum) var = 5;
+    else if (act == 0 && aux && resid && out_f32 && gamma && !drop_thr16 && !colsum) var = 6;
+    static bool attr192 = false;
+    if (use192 && !attr192) {
+#define X2_ATTR192(V) hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<6, V>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (192 * 128 + TILE_BYTES))
+      X2_ATTR192(0); X2_ATTR192(1); X2_ATTR192(2); X2_ATTR192(3); X2_ATTR192(4); X2_ATTR192(5); X2_ATTR192(6);
+#undef X2_ATTR192
+      attr192 = true;
     }
+#define X2_NT_LAUNCH(V)                                                                                                              \
+    do {                                                                                                                             \
+      if (use64) hipLaunchKernelGGL((gemm_nt_kernel<2, V>), dim3(t64), dim3(256), 2 * (64 * 128 + TILE_BYTES), (hipStream_t)stream, p);   \
+      else if (use192) hipLaunchKernelGGL((gemm_nt_kernel<6, V>), dim3(t192), dim3(256), 2 * (192 * 128 + TILE_BYTES), (hipStream_t)stream, p); \
+      else hipLaunchKernelGGL((gemm_nt_kernel<4, V>), dim3(t128), dim3(256), GEMM_LDS_BYTES, (hipStream_t)stream, p);               \
+    } while (0)
+    switch (var) {
+      case 0: X2_NT_LAUNCH(0); break;
+      case 1: X2_NT_LAUNCH(1); break;
+      case 2: X2_NT_LAUNCH(2); break;
+      case 3: X2_NT_LAUNCH(3); break;
+      case 5: X2_NT_LAUNCH(5); break;
+      case 6: X2_NT_LAUNCH(6); break;
+      default: X2_NT_LAUNCH(4); break;
+    }
+#undef X2_NT_LAUNCH
   }
   return x2_check_launch("x2_gemm_nt");
 }
