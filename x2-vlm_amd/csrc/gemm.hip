@@ -647,6 +647,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmTNGroup g) {
 // those rows read these 16 zero bytes instead, so the last contraction step multiplies zeros - no padded copies of the
 // operands, no out-of-bounds reads
 __device__ __attribute__((aligned(16))) const uint32_t x2_zero_chunk[4] = {0u, 0u, 0u, 0u};
+template <bool RAG>      // RAG: some problem of the launch has a contraction length that is not a multiple of 64
 __global__ __launch_bounds__(512) void gemm_tn256_kernel(GemmTNGroup g, float* ws, int total_tiles) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -663,7 +664,7 @@ __global__ __launch_bounds__(512) void gemm_tn256_kernel(GemmTNGroup g, float* w
   const int steps = (p.Mc + BK - 1) / BK, rag = p.Mc % BK;        // host guarantees steps >= gridDim.y; rag = rows of a partial last step
   const int s_begin = (int)((long)steps * blockIdx.y / gridDim.y), s_end = (int)((long)steps * (blockIdx.y + 1) / gridDim.y);
   const int nk = s_end - s_begin;
-  const int last_rel = (rag != 0 && s_end == steps) ? nk - 1 : -1;  // slice-relative index of the partial step, if this slice has it
+  const int last_rel = (RAG && rag != 0 && s_end == steps) ? nk - 1 : -1;  // slice-relative index of the partial step, if this slice has it
   const bf16_t* const zsrc = reinterpret_cast<const bf16_t*>(x2_zero_chunk);
   const bool oob0 = (tid >> 4) >= rag, oob1 = ((512 + tid) >> 4) >= rag;   // this thread's two rows of a half-tile
 
@@ -683,7 +684,7 @@ __global__ __launch_bounds__(512) void gemm_tn256_kernel(GemmTNGroup g, float* w
   auto issue = [&](int kt, auto slot) {                            // slot 0, 1: A halves; 2, 3: B halves
     constexpr int S = decltype(slot)::value;
     char* base = smem + ((kt & 1) * 4 + S) * T2_HALF + wave * 1024;
-    const bool z = kt == last_rel;
+    const bool z = RAG && kt == last_rel;
     if constexpr (S < 2) {
       glds16(z && oob0 ? zsrc : srcA[S][0] + kt * stepA, base);
       glds16(z && oob1 ? zsrc : srcA[S][1] + kt * stepA, base + 8192);
@@ -866,8 +867,15 @@ extern "C" int x2_gemm_tn_grouped(const int64_t* problems, int count, int accumu
     }
     while (sp > 1 && (sp > min_steps || !ws || (long)sp * t * 65536 > ws_floats)) --sp;
     static bool attr = false;
-    if (!attr) { hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn256_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, T2_LDS_BYTES); attr = true; }
-    hipLaunchKernelGGL(gemm_tn256_kernel, dim3(t, sp), dim3(512), T2_LDS_BYTES, (hipStream_t)stream, g, ws, t);
+    if (!attr) {
+      hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn256_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, T2_LDS_BYTES);
+      hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn256_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, T2_LDS_BYTES);
+      attr = true;
+    }
+    bool ragged = false;
+    for (int i = 0; i < count; ++i) ragged = ragged || (g.p[i].Mc % BK != 0);
+    if (ragged) hipLaunchKernelGGL(gemm_tn256_kernel<true>, dim3(t, sp), dim3(512), T2_LDS_BYTES, (hipStream_t)stream, g, ws, t);
+    else hipLaunchKernelGGL(gemm_tn256_kernel<false>, dim3(t, sp), dim3(512), T2_LDS_BYTES, (hipStream_t)stream, g, ws, t);
     if (sp > 1) hipLaunchKernelGGL(gemm_tn256_reduce_kernel, dim3(t * 64), dim3(256), 0, (hipStream_t)stream, g, ws, t, sp);
     return x2_check_launch("x2_gemm_tn_grouped");
   }
