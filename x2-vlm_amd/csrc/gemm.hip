@@ -66,7 +66,8 @@ __device__ __forceinline__ void st16(void* p, u32x4 v, bool wt) {
 //   0 bias -> bf16            (qkv / q / kv projections, bf16 input gradients)
 //   1 bias -> fp32            (fp32 input gradients, logits, head linears)
 //   2 bias, GELU, pre-activation saved -> bf16                  (fc1 / intermediate forward)
-//   3 x GELU'(saved pre-activation), column sums -> bf16        (input gradient through the GELU)
+//   3 x GELU'(saved pre-activation) -> bf16                     (input gradient through the GELU; its bias-gradient column
+//     sums are a separate two-stage kernel: fused as one atomic per column and wave they cost 30-50 us per launch)
 //   5 bias, (dropout), + residual -> fp32                       (BERT output projections, BERT input gradients)
 //   6 bias, layer scale (x DropPath row factor), value before the scale saved, + residual -> fp32   (BEiT proj / fc2)
 //   4 everything decided at run time (any other combination)
@@ -78,7 +79,7 @@ template <int V> struct EpiTraits {
   static constexpr bool scale = V == 6;           // gamma and optional rowscale
   static constexpr bool aux0 = V == 6;            // act == 0 with aux: save the value before the layer scale
   static constexpr bool drop = V == 5;            // dropout possible (still a runtime test on thr16, outside the hot variants)
-  static constexpr bool colsum = V == 3;
+  static constexpr bool colsum = false;
 };
 template <int TM, int VAR>
 __device__ __forceinline__ void nt_epilogue(const GemmNT& p, f32x4 (&acc)[TM][4], char* smem, int wave, int lane, int mw0, int nw0) {
@@ -455,7 +456,7 @@ extern "C" int x2_gemm_nt(const void* A, const void* B, void* C, int M, int N, i
     const bool plain = !gamma && !rowscale && !drop_thr16 && !colsum;
     if (g_tune[6] == 1) var = 4;                                                     // probes / tests: force the generic epilogue
     else if (act == 1 && !out_f32 && !resid && plain) var = 2;
-    else if (act == 2 && !out_f32 && !resid && !gamma && !rowscale && !drop_thr16) var = 3;
+    else if (act == 2 && !out_f32 && !resid && plain) var = 3;
     else if (act == 0 && !aux && !resid && plain) var = out_f32 ? 1 : 0;
     else if (act == 0 && !aux && resid && out_f32 && !gamma && !rowscale && !colsum) var = 5;
     else if (act == 0 && aux && resid && out_f32 && gamma && !drop_thr16 && !colsum) var = 6;

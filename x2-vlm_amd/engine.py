@@ -462,7 +462,8 @@ class VisionEncoderFn(torch.autograd.Function):
             _, wprojT = BANK.linear(p[b + "attn.proj.weight"])
             _, wqkvT = BANK.linear(p[b + "attn.qkv.weight"])
             dy2 = K.layerscale_bwd(dx, aux2, p[b + "gamma_2"], G["gamma_2"], G["mlp.fc2.bias"], rowscale=rs2)
-            dpre = K.gemm_nt(dy2, w2T, aux=pre, act=2, colsum=G["mlp.fc1.bias"])
+            dpre = K.gemm_nt(dy2, w2T, aux=pre, act=2)
+            K.colsum_bf16(dpre, G["mlp.fc1.bias"])        # two-stage sums: 20 us; fused into the GEMM epilogue (atomics) 30 us
             dh2 = K.gemm_nt(dpre, w1T, out_dtype=F32)
             dx1, _ = K.layernorm_bwd(dh2, x1, mean2, rstd2, p[b + "norm2.weight"], G["norm2.weight"], G["norm2.bias"], dres=dx)
             dy1 = K.layerscale_bwd(dx1, aux1, p[b + "gamma_1"], G["gamma_1"], G["attn.proj.bias"], rowscale=rs1)
@@ -655,7 +656,8 @@ class BertLayersFn(torch.autograd.Function):
                                         drop_out=BertLayersFn._drop(meta, i, 4))
             _, woutT = BANK.linear(p[b + "output.dense.weight"])
             _, wiT = BANK.linear(p[b + "intermediate.dense.weight"])
-            dpre = K.gemm_nt(ds3b, woutT, aux=pre, act=2, colsum=G["intermediate.dense.bias"])
+            dpre = K.gemm_nt(ds3b, woutT, aux=pre, act=2)
+            K.colsum_bf16(dpre, G["intermediate.dense.bias"])
             dh2 = K.gemm_nt(dpre, wiT, resid=ds3, out_dtype=F32)
             tn += [(ds3b, act, G["output.dense.weight"]), (dpre, h2b, G["intermediate.dense.weight"])]
             if cr is not None:
