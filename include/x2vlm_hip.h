@@ -23,7 +23,7 @@ extern "C" {
 #endif
 
 const char* x2_last_error(void);
-int x2_abi_version(void);          /* == 3 */
+int x2_abi_version(void);          /* == 4 */
 int x2_device_cus(void);           /* compute units of the current HIP device, 0 if none */
 int x2_tune(int key, int value);   /* kernel-variant knobs for probes/ and tests (0 = automatic); keys listed in csrc/gemm.hip */
 
@@ -99,7 +99,7 @@ int x2_layernorm_fwd(const float* x, const float* w, const float* b, void* y_bf1
                      float drop_scale, const unsigned* drop_epoch, void* stream);   /* drop: dropout on the LN output (xbert.py:215) */
 /* g = LN'(mask_in(dy)); dx = dres + g (fp32); dx_bf16 = mask_out(g); dw += , db += ; dcol += column sums of mask_out(g)
  * (= gradient and bias gradient of the linear whose dropped output was added to the residual before this LN) */
-int x2_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* w,
+int x2_layernorm_bwd(const void* dy /* fp32, or bf16 when dy_is_bf16 */, int dy_is_bf16, const float* x, const float* mean, const float* rstd, const float* w,
                      const float* dres, float* dx, void* dx_bf16, float* dw, float* db, float* dcol, int rows, int D,
                      int period, unsigned in_thr16, unsigned in_seed, float in_scale, unsigned out_thr16,
                      unsigned out_seed, float out_scale, const unsigned* drop_epoch, float* ws /* [ceil(rows/16)][3][D] */,

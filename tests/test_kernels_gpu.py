@@ -277,6 +277,13 @@ def test_layernorm(K, rows, D, period):
     assert relerr(dx[sel], xl.grad[sel] + dres[sel]) < 2e-5
     assert relerr(dxb[sel], xl.grad[sel]) < 6e-3          # bf16 copy = gradient of the LN input alone (feeds the producing linear)
     assert relerr(dw, wl.grad) < 2e-5 and relerr(db, bl.grad) < 2e-5
+    # bf16 incoming gradient (input-gradient GEMMs of the pre-LN blocks write bf16): same arithmetic on the rounded values
+    dyb = bf(dy)
+    xl2 = x.clone().requires_grad_(True)
+    O.layer_norm(xl2[sel], w, b, 1e-6).backward(dyb.float()[sel])
+    dwb, dbb = torch.zeros(D, device=dev), torch.zeros(D, device=dev)
+    dxh, _ = K.layernorm_bwd(dyb.to(dev), x.to(dev), mean, rstd, w.to(dev), dwb, dbb, dres=dres.to(dev), period=period)
+    assert relerr(dxh[sel], xl2.grad[sel] + dres[sel]) < 2e-5
     dw2, db2, dcol = torch.zeros(D, device=dev), torch.zeros(D, device=dev), torch.zeros(D, device=dev)
     dx2, _ = K.layernorm_bwd(dy.to(dev), x.to(dev), mean, rstd, w.to(dev), dw2, db2, dcol=dcol, period=period)
     assert relerr(dcol, xl.grad[sel].sum(0)) < 5e-5 and relerr(dx2[sel], xl.grad[sel]) < 2e-5

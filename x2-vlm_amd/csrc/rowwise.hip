@@ -157,8 +157,10 @@ extern "C" int x2_reduce_partials_multi(const int64_t* desc, int count, void* st
 // four waves are combined through LDS and written as one partial row per workgroup (ws[blk][3][D]);
 // reduce_partials_kernel then adds the partial rows into dw/db/dcol.
 #define LNB_ROWS 16
-template <int NV>
-__global__ __launch_bounds__(256, NV <= 3 ? 4 : 1) void layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+// DYB: the incoming gradient dy is bf16 (the input-gradient GEMM of a pre-LN block writes bf16, as the reference's apex-O1
+// linears hand fp16 gradients to their LayerNorm: 2 bytes instead of 4 written by the GEMM and read here)
+template <int NV, bool DYB>
+__global__ __launch_bounds__(256, NV <= 3 ? 4 : 1) void layernorm_bwd_kernel(const void* __restrict__ dy_, const float* __restrict__ x,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
                                                             const float* __restrict__ w, const float* dres, float* dx, bf16_t* dxb,
                                                             float* ws, int rows, int D, int period,
@@ -184,7 +186,13 @@ __global__ __launch_bounds__(256, NV <= 3 ? 4 : 1) void layernorm_bwd_kernel(con
     for (int i = 0; i < NV; ++i) {
       const int c = lane + i * 64;
       if (c < nv) {
-        float4 d = *reinterpret_cast<const float4*>(dy + gr * D + c * 4);
+        float4 d;
+        if constexpr (DYB) {
+          const u32x2 raw = *reinterpret_cast<const u32x2*>(reinterpret_cast<const bf16_t*>(dy_) + gr * D + c * 4);
+          d = float4{bf_lo(raw.x), bf_hi(raw.x), bf_lo(raw.y), bf_hi(raw.y)};
+        } else {
+          d = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(dy_) + gr * D + c * 4);
+        }
         const float4 xv = *reinterpret_cast<const float4*>(x + gr * D + c * 4);
         if (din.thr16) {      // the forward dropped the LN OUTPUT: mask the incoming gradient the same way
           float dm[4];
@@ -255,7 +263,7 @@ __global__ __launch_bounds__(256, NV <= 3 ? 4 : 1) void layernorm_bwd_kernel(con
   }
 }
 
-extern "C" int x2_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* w,
+extern "C" int x2_layernorm_bwd(const void* dy, int dy_is_bf16, const float* x, const float* mean, const float* rstd, const float* w,
                                 const float* dres, float* dx, void* dx_bf16, float* dw, float* db, float* dcol, int rows, int D,
                                 int period, unsigned in_thr16, unsigned in_seed, float in_scale, unsigned out_thr16,
                                 unsigned out_seed, float out_scale, const unsigned* drop_epoch, float* ws, int defer, void* stream) {
@@ -263,9 +271,10 @@ extern "C" int x2_layernorm_bwd(const float* dy, const float* x, const float* me
   X2_REQUIRE(dw && db && ws, "x2_layernorm_bwd: dw/db and the workspace ws[ceil(rows/%d)*3*D] are required", LNB_ROWS);
   X2_REQUIRE(!(dcol && dres), "x2_layernorm_bwd: dcol sums the LN-input gradient, which excludes dres");
   X2_REQUIRE(!(out_thr16 && dres), "x2_layernorm_bwd: an output mask applies to the bf16 copy, which excludes dres");
-#define X2_LNB(NV) hipLaunchKernelGGL(layernorm_bwd_kernel<NV>, dim3((rows + LNB_ROWS - 1) / LNB_ROWS), dim3(256), 9 * D * sizeof(float), \
+#define X2_LNB_T(NV, B) hipLaunchKernelGGL((layernorm_bwd_kernel<NV, B>), dim3((rows + LNB_ROWS - 1) / LNB_ROWS), dim3(256), 9 * D * sizeof(float), \
                      (hipStream_t)stream, dy, x, mean, rstd, w, dres, dx, (bf16_t*)dx_bf16, ws, rows, D, period,                \
                      DropSpec{in_thr16, in_seed, in_scale}, DropSpec{out_thr16, out_seed, out_scale}, drop_epoch)
+#define X2_LNB(NV) do { if (dy_is_bf16) X2_LNB_T(NV, true); else X2_LNB_T(NV, false); } while (0)
   LN_DISPATCH(D, X2_LNB);
   if (!defer) launch_reduce(ws, (rows + LNB_ROWS - 1) / LNB_ROWS, 3, D, dw, db, dcol, (hipStream_t)stream);
   return x2_check_launch("x2_layernorm_bwd");

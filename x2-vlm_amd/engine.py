@@ -464,7 +464,7 @@ class VisionEncoderFn(torch.autograd.Function):
             dy2 = K.layerscale_bwd(dx, aux2, p[b + "gamma_2"], G["gamma_2"], G["mlp.fc2.bias"], rowscale=rs2)
             dpre = K.gemm_nt(dy2, w2T, aux=pre, act=2)
             K.colsum_bf16(dpre, G["mlp.fc1.bias"])        # two-stage sums: 20 us; fused into the GEMM epilogue (atomics) 30 us
-            dh2 = K.gemm_nt(dpre, w1T, out_dtype=F32)
+            dh2 = K.gemm_nt(dpre, w1T)            # bf16, like the fp16 grad_input of the reference's O1 linears: half the bytes
             dx1, _ = K.layernorm_bwd(dh2, x1, mean2, rstd2, p[b + "norm2.weight"], G["norm2.weight"], G["norm2.bias"], dres=dx)
             dy1 = K.layerscale_bwd(dx1, aux1, p[b + "gamma_1"], G["gamma_1"], G["attn.proj.bias"], rowscale=rs1)
             datt = K.gemm_nt(dy1, wprojT)
@@ -477,7 +477,7 @@ class VisionEncoderFn(torch.autograd.Function):
             K.colsum_bf16(dqkv, G["qkv_bias"])
             G.alias("attn.q_bias", G["qkv_bias"][:D])
             G.alias("attn.v_bias", G["qkv_bias"][2 * D:])
-            dh1 = K.gemm_nt(dqkv, wqkvT, out_dtype=F32)
+            dh1 = K.gemm_nt(dqkv, wqkvT)
             dxn, _ = K.layernorm_bwd(dh1, x, mean1, rstd1, p[b + "norm1.weight"], G["norm1.weight"], G["norm1.bias"], dres=dx1)
             tn = [(dy2, act, G["mlp.fc2.weight"]), (dpre, h2, G["mlp.fc1.weight"]),
                   (dy1, att, G["attn.proj.weight"]), (dqkv, h1, G["attn.qkv.weight"])]

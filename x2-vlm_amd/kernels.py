@@ -266,7 +266,7 @@ def layernorm_fwd(x, w, b, eps, *, rows=None, period=0, want_bf16=True, want_f32
 def layernorm_bwd(dy, x, mean, rstd, w, dw, db, *, dres=None, dcol=None, period=0, want_f32=True, want_bf16=False, dx=None,
                   drop_in=NO_DROP, drop_out=NO_DROP):
     """dcol (fp32 [D], accumulated): column sums of the LN-input gradient = bias gradient of the producing linear."""
-    assert dy.dtype == F32 and x.dtype == F32 and dy.is_contiguous() and x.is_contiguous()
+    assert dy.dtype in (F32, BF16) and x.dtype == F32 and dy.is_contiguous() and x.is_contiguous()
     D = x.shape[-1]
     R = mean.numel()
     if want_f32 and dx is None:
@@ -274,7 +274,7 @@ def layernorm_bwd(dy, x, mean, rstd, w, dw, db, *, dres=None, dcol=None, period=
     dxb = torch.empty(x.shape, device=x.device, dtype=BF16) if want_bf16 else None
     nblk = (R + 15) // 16
     ws, defer = _ws_and_defer(x.device, nblk * 3 * D)
-    call("x2_layernorm_bwd", ptr(dy), ptr(x), ptr(mean), ptr(rstd), ptr(w), ptr(dres), ptr(dx), ptr(dxb), ptr(dw), ptr(db),
+    call("x2_layernorm_bwd", ptr(dy), 1 if dy.dtype == BF16 else 0, ptr(x), ptr(mean), ptr(rstd), ptr(w), ptr(dres), ptr(dx), ptr(dxb), ptr(dw), ptr(db),
          ptr(dcol), R, D, period, drop_in[0], drop_in[1], drop_in[2], drop_out[0], drop_out[1], drop_out[2],
          ptr(drop_in[3] if drop_in[3] is not None else drop_out[3]), ptr(ws), defer)
     if defer:
