@@ -23,7 +23,7 @@ extern "C" {
 #endif
 
 const char* x2_last_error(void);
-int x2_abi_version(void);          /* == 4 */
+int x2_abi_version(void);          /* == 5 */
 int x2_device_cus(void);           /* compute units of the current HIP device, 0 if none */
 int x2_tune(int key, int value);   /* kernel-variant knobs for probes/ and tests (0 = automatic); keys listed in csrc/gemm.hip */
 
@@ -51,6 +51,15 @@ int x2_gemm_nt(const void* A, const void* B, void* C, int M, int N, int K, int l
                const float* bias, const float* gamma, const float* resid, int ldr, void* aux, int ldaux,
                int act, int out_f32, unsigned drop_thr16, unsigned drop_seed, float drop_scale, const unsigned* drop_epoch,
                const float* rowscale, float* colsum, void* stream);      /* colsum[n] += sum_m C[m,n] (fused bias gradient), NULL = off */
+
+/* The same product with a split contraction, for few output tiles and a long K: C[M,N] (fp32, no epilogue) =
+ * A[M,K] . B[N,K]^T.  The input gradient of the tied MLM decoder (reference: autograd of the F.linear behind
+ * xbert.py:822, dt[R,768] = dlogits[R,30528] . E) is 36-72 output tiles of 477 contraction steps - a serial chain on a
+ * seventh of the chip.  Slice s of the contraction writes its partial product to ws[s*M*N ...]; a second kernel adds the
+ * slices in a fixed order (deterministic, no atomics).  slices: 0 = chosen to put two workgroups on every CU with at
+ * least 8 contraction steps each; clamped to ws_floats / (M*N); ws = NULL or one slice: a single launch straight into C. */
+int x2_gemm_nt_splitk(const void* A, const void* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
+                      int slices, float* ws, long ws_floats, void* stream);
 
 /* Weight gradients of one layer in one launch: for each problem  dW[N,K] (+)= dY[Mc,N]^T . X[Mc,K]  (fp32 out).
  * problems: count (<= 8) rows of 11 int64 {dY, X, dW, Mc, N, K, ld_dY, ld_X, ld_dW, n_ld, k_ld}; n_ld / k_ld are
@@ -161,6 +170,23 @@ int x2_ce_fwd(const float* logits, long ld, const long* labels, int R, int C, fl
               void* stream);
 int x2_ce_bwd(const float* logits, long ld, const long* labels, const float* lse, const float* g, const float* stat,
               float gscale, int R, int C, float* dl_f32, void* dl_bf16, long ldd, void* stream);
+/* The MLM head's cross-entropy over the tied decoder with the logits kept in the GEMM accumulators (reference:
+ * BertLMPredictionHead.decoder = nn.Linear(hidden, vocab) followed by CrossEntropyLoss, xbert.py:822, 1653-1661; there
+ * the [R, V] logits are materialised in fp16 and up-cast for the loss).  X [R, Hd] bf16 = transformed masked rows,
+ * E [Vp, Hd] bf16 = word embeddings padded to Vp % 64 == 0 rows, bias [Vp], labels [R] (< 0: ignored), V = vocabulary.
+ *   x2_mlm_ce_fwd : part[R][Vp/64][2] = (max, sum exp(z - max)) of every 64-column chunk of z = X.E^T + bias (columns
+ *                   < V only), zlab[r] = z[r][label[r]]
+ *   x2_ce_combine : lse[r] from the chunks of row r, loss_row[r] = lse - zlab (0 for ignored rows),
+ *                   out2 = {mean loss, counted rows}
+ *   x2_mlm_ce_bwd : dl[R][ldd] bf16 = (exp(z - lse[r]) - [c == label]) * gscale * g[0] / stat[1], z recomputed by the same
+ *                   GEMM; ignored rows and columns >= V are written as 0 */
+int x2_mlm_ce_fwd(const void* X, const void* E, const float* bias, const long* labels, int R, int Vp, int V, int Hd,
+                  int ldx, int lde, float* part, float* zlab, void* stream);
+int x2_ce_combine(const float* part, int chunks, const float* zlab, const long* labels, int R, float* lse, float* loss_row,
+                  float* out2, void* stream);
+int x2_mlm_ce_bwd(const void* X, const void* E, const float* bias, const long* labels, const float* lse, const float* g,
+                  const float* stat, float gscale, int R, int Vp, int V, int Hd, int ldx, int lde, void* dl_bf16, long ldd,
+                  void* stream);
 /* hard negatives, xvlm.py:828-857: softmax(sim)+1e-5 with the diagonal (or same-group entries) zeroed, one
  * inverse-CDF draw per row from u[b] in [0,1); replaces 2*B torch.multinomial(...).item() host syncs */
 int x2_sample_negatives(const float* sim, int n, const long* group, const float* u, int* out, void* stream);

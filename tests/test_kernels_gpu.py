@@ -38,7 +38,7 @@ def relerr(got, ref):
     return float((got - ref).abs().max() / ref.abs().max().clamp_min(1e-12))
 
 
-@pytest.fixture(params=[(1, 1), (1, 2), (2, 0), (1, 3)], ids=["tile128x128", "tile192x128", "tile256x128w8", "tile64x128"])
+@pytest.fixture(params=[(1, 1), (1, 2), (2, 0), (1, 3), (1, 4)], ids=["tile128x128", "tile192x128", "tile256x128w8", "tile64x128", "tile160x128"])
 def nt_tile(request):
     lib = importlib.import_module("x2-vlm_amd._lib").lib()
     lib.x2_tune(1, request.param[0])
@@ -78,6 +78,71 @@ def test_gemm_nt_plain_and_epilogues(K, M, N, K_, nt_tile):
                     out_dtype=torch.float32)
     assert relerr(out, resid + gamma * (ref + bias)) < 1e-5
     assert relerr(aux, ref + bias) < 6e-3
+    # the compiled feature sets of the step that the calls above do not reach (they run the generic epilogue):
+    # bias + GELU -> bf16, GELU' -> bf16, bias + residual -> fp32
+    aux = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+    out = K.gemm_nt(A.to(dev), B.to(dev), bias=bias.to(dev), aux=aux, act=1)
+    assert relerr(out, O.gelu(ref + bias)) < 6e-3 and relerr(aux, ref + bias) < 6e-3
+    out = K.gemm_nt(A.to(dev), B.to(dev), aux=pre.to(dev), act=2)
+    assert relerr(out, ref * x.grad) < 6e-3
+    out = K.gemm_nt(A.to(dev), B.to(dev), bias=bias.to(dev), resid=resid.to(dev), out_dtype=torch.float32)
+    assert relerr(out, resid + ref + bias) < 1e-5
+
+
+@pytest.mark.parametrize("M,N,K_,slices", [(768, 768, 30528, 0), (96, 768, 30528, 0), (40, 256, 4096, 0), (300, 200, 1024, 3),
+                                           (130, 136, 640, 10), (256, 256, 128, 0), (384, 1024, 30528, 7)])
+def test_gemm_nt_split_contraction(K, M, N, K_, slices):
+    """few output tiles, long contraction (input gradient of the tied MLM decoder): slices of K into partial products
+    added in a fixed order; equal to the one-launch product and bitwise reproducible."""
+    A, B = bf(rnd(M, K_, seed=11)), bf(rnd(N, K_, seed=12, scale=K_ ** -0.5))
+    ref = A.double() @ B.double().t()
+    out = K.gemm_nt_splitk(A.to(dev), B.to(dev), slices=slices)
+    assert relerr(out, ref) < 1e-5
+    again = K.gemm_nt_splitk(A.to(dev), B.to(dev), slices=slices)
+    assert torch.equal(out, again)
+    wide = torch.zeros(M, N + 64, device=dev)
+    K.gemm_nt_splitk(A.to(dev), B.to(dev), out=wide[:, 32:32 + N], slices=slices)          # strided output rows
+    assert torch.equal(wide[:, 32:32 + N], out) and float(wide[:, :32].abs().max()) == 0.0 and float(wide[:, 32 + N:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("R,Hd,V", [(200, 128, 1000), (37, 64, 30522), (768, 768, 30522), (96, 1024, 30522), (64, 128, 512)])
+def test_fused_mlm_cross_entropy(K, R, Hd, V):
+    """decoder GEMM + cross-entropy with the logits kept in the accumulators (x2_mlm_ce_fwd / x2_ce_combine / x2_mlm_ce_bwd)
+    against float64 log-softmax of the same bf16 operands, and against the unfused kernels (fp32 logits + x2_ce_*)."""
+    Vp = K.round_up(V, 64)
+    x = bf(rnd(R, Hd, seed=21))
+    E = torch.zeros(Vp, Hd)
+    E[:V] = rnd(V, Hd, seed=22, scale=3.0 * Hd ** -0.5)
+    E = bf(E)
+    bias = torch.zeros(Vp)
+    bias[:V] = rnd(V, seed=23)
+    g_ = torch.Generator().manual_seed(24)
+    labels = torch.randint(0, V, (R,), generator=g_)
+    labels[::5] = -100
+    labels[1] = V - 1                                   # last valid column (the chunk that also holds the padding)
+    xd, Ed, bd, ld = x.to(dev), E.to(dev), bias.to(dev), labels.to(dev)
+    stat, lse = K.mlm_ce_fwd(xd, Ed, bd, ld, V)
+    z = x.double() @ E.double().t()[:, :V] + bias[:V].double()
+    ref_lse = torch.logsumexp(z, -1)
+    valid = labels >= 0
+    ref_rows = ref_lse - z[torch.arange(R), labels.clamp_min(0)]
+    assert float((lse.cpu().double() - ref_lse).abs().max()) < 1e-4
+    assert abs(float(stat[0]) - float(ref_rows[valid].mean())) < 1e-5 * max(1.0, float(ref_rows[valid].mean()))
+    assert float(stat[1]) == float(valid.sum())
+    g = torch.tensor([0.7], device=dev)
+    dl = K.mlm_ce_bwd(xd, Ed, bd, ld, lse, g, stat, V)
+    ref_dl = torch.softmax(z, -1)
+    ref_dl[torch.arange(R), labels.clamp_min(0)] -= 1.0
+    ref_dl = ref_dl * (0.7 / float(valid.sum())) * valid.double().unsqueeze(1)
+    assert relerr(dl[:, :V], ref_dl) < 6e-3
+    assert float(dl[:, V:].float().abs().max()) == 0.0 if Vp > V else True
+    assert float(dl[~valid.to(dev)].float().abs().max()) == 0.0
+    # the unfused kernels on materialised fp32 logits: same statistics, same gradient up to the bf16 rounding of dl
+    logits = K.gemm_nt(xd, Ed, bias=bd, out_dtype=torch.float32)
+    stat2, lse2 = K.ce_fwd(logits, ld, C_valid=V)
+    assert float((lse - lse2).abs().max()) < 2e-5 and abs(float(stat[0] - stat2[0])) < 2e-6 * max(1.0, float(stat2[0]))
+    dl2 = K.ce_bwd(logits, ld, lse2, g, stat2, C_valid=V, out_dtype=torch.bfloat16)
+    assert relerr(dl, dl2.float().cpu()) < 6e-3
 
 
 def test_gemm_nt_strided_views(K):

@@ -47,7 +47,12 @@ def run_case(case, tmpdir, synthetic):
     if c["region"]:
         kw.update(image_atts=batch["image_atts"], idx_to_group_img=batch["idx_to_group_img"],
                   target_bbox=batch["target_bbox"], is_image=batch["is_image"], ret_bbox_loss=True)
-    loss = model(batch["image"], batch["text_ids"], batch["text_atts"], **kw)
+    eng = importlib.import_module("x2-vlm_amd.engine")
+    eng.KEEP_MLM_LOGITS = True          # inspection copy of the MLM logits; the loss and its gradient still take the fused path
+    try:
+        loss = model(batch["image"], batch["text_ids"], batch["text_atts"], **kw)
+    finally:
+        eng.KEEP_MLM_LOGITS = False
     sum(loss.values()).backward()
     torch.cuda.synchronize()
     return model, loss, c
@@ -69,7 +74,9 @@ def test_step_matches_reference(case, tmp_path, synthetic):
     V = c["vocab"]
     ml = model.last_mlm_logits[:, :V].reshape(c["batch"], c["max_masks"], V)
     acts["mlm_logits"] = ml
-    acts["mlm_lse"] = torch.logsumexp(ml.double(), dim=-1).float()
+    # the log-partition the loss was computed from (softmax statistics reduced in the decoder GEMM's epilogue when fused)
+    acts["mlm_lse"] = model.last_mlm_lse.reshape(c["batch"], c["max_masks"])
+    assert float((acts["mlm_lse"].double() - torch.logsumexp(ml.double(), dim=-1)).abs().max()) < 2e-4
     if c["frames"]:
         acts.pop("image_embeds")        # fixture holds the per-frame encoder output; pooled output is checked via the losses
     for k in gold.files:

@@ -30,6 +30,7 @@ class AttnArgs(C.Structure):
 # name -> argtypes (all return int: 0 ok, < 0 error; message via x2_last_error)
 _SIGS = {
     "x2_gemm_nt": [P, P, P, I, I, I, I, I, I, P, P, P, I, P, I, I, I, U, U, F, P, P, P, P],
+    "x2_gemm_nt_splitk": [P, P, P, I, I, I, I, I, I, I, P, L, P],
     "x2_gemm_tn_grouped": [P, I, I, I, P, L, P],
     "x2_attn_fwd": [C.POINTER(AttnArgs), P],
     "x2_attn_bwd": [C.POINTER(AttnArgs), P],
@@ -57,6 +58,9 @@ _SIGS = {
     "x2_l2norm": [P, P, P, I, I, I, P],
     "x2_ce_fwd": [P, L, P, I, I, P, P, P, P],
     "x2_ce_bwd": [P, L, P, P, P, P, F, I, I, P, P, L, P],
+    "x2_mlm_ce_fwd": [P, P, P, P, I, I, I, I, I, I, P, P, P],
+    "x2_ce_combine": [P, I, P, P, I, P, P, P, P],
+    "x2_mlm_ce_bwd": [P, P, P, P, P, P, P, F, I, I, I, I, I, I, P, L, P],
     "x2_sample_negatives": [P, I, P, P, P, P],
     "x2_gelu_f32": [P, P, P, L, P],
     "x2_grad_norm": [P, I, I, F, P, P, P],
@@ -100,6 +104,9 @@ def lib():
         h.x2_abi_version.restype = I
         h.x2_device_cus.restype = I
         h.x2_tune.argtypes, h.x2_tune.restype = [I, I], I
+        for kv in filter(None, os.environ.get("X2_TUNE", "").split(",")):      # probes: "key=value,..." kernel-variant knobs (csrc/gemm.hip)
+            k, v = kv.split("=")
+            h.x2_tune(int(k), int(v))
         _lib = h
     return _lib
 

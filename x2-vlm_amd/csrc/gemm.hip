@@ -36,6 +36,16 @@ struct GemmNT {
   float* colsum;            // [N] += column sums of the stored C (bias gradient of the layer below, fused)
   int dbg;                  // ablation switches for probes/bench_gemm.py: 4 = no epilogue, 16 = sc1 output stores
   int stagger;              // experiment: odd workgroups start `stagger` x 4 us late (de-phases the two workgroups of a CU)
+  int ksplit;               // split-contraction launches (epilogue variant 7): columns of A / B per blockIdx.y slice
+  // fused MLM cross-entropy (epilogue variants 8 / 9, x2_mlm_ce_fwd / _bwd): the logits never leave the accumulators
+  const long* ce_labels;    // [M] target column or < 0 (ignored row)
+  const float* ce_lse;      // [M] log-partition of every row (variant 9)
+  const float* ce_g;        // [1] incoming loss gradient; ce_stat[1] = number of counted rows (variant 9)
+  const float* ce_stat;
+  float* ce_part;           // [M][N / 64][2] (max, sum exp(z - max)) of every 64-column chunk (variant 8)
+  float* ce_zlab;           // [M] logit at the label (variant 8)
+  float ce_gscale;
+  int ce_C;                 // valid columns (vocabulary size; N is padded to a multiple of 64)
 };
 
 // logical tile id -> (row tile, col tile): XCD-contiguous chunks, inside a chunk groups of `gm` row panels
@@ -71,10 +81,13 @@ __device__ __forceinline__ void st16(void* p, u32x4 v, bool wt) {
 //   5 bias, (dropout), + residual -> fp32                       (BERT output projections, BERT input gradients)
 //   6 bias, layer scale (x DropPath row factor), value before the scale saved, + residual -> fp32   (BEiT proj / fc2)
 //   4 everything decided at run time (any other combination)
+//   7 partial products of one contraction slice -> fp32 workspace (x2_gemm_nt_splitk; slice = blockIdx.y)
+//   8 bias, then per row and 64-column chunk (max, sum exp) + the logit at the label: softmax statistics, nothing stored
+//   9 bias, then (softmax - onehot) * row scale -> bf16: gradient of the mean cross-entropy w.r.t. the logits
 template <int V> struct EpiTraits {
   static constexpr bool generic = V == 4;
   static constexpr int act = V == 2 ? 1 : V == 3 ? 2 : 0;
-  static constexpr bool out_f32 = V == 1 || V == 5 || V == 6;
+  static constexpr bool out_f32 = V == 1 || V == 5 || V == 6 || V == 7;
   static constexpr bool resid = V == 5 || V == 6;
   static constexpr bool scale = V == 6;           // gamma and optional rowscale
   static constexpr bool aux0 = V == 6;            // act == 0 with aux: save the value before the layer scale
@@ -109,7 +122,9 @@ __device__ __forceinline__ void nt_epilogue(const GemmNT& p, f32x4 (&acc)[TM][4]
   const bool wt = (p.dbg & 16) != 0;
   const DropSpec drop_ = drop_at_epoch(p.drop, p.drop_epoch);
 #pragma unroll
-  for (int half = 0; half < TM / 2; ++half) {
+  for (int half = 0; half < (TM + 1) / 2; ++half) {
+    // an odd TM ends with a 16-row half: `full` folds at compile time once the loop is unrolled
+    const bool full = half * 2 + 1 < TM;
     // operands the epilogue reads from HBM (residual rows, saved pre-activation) are requested for all four row groups
     // of this half BEFORE the accumulators go through LDS: their latency hides behind the staging round trip instead
     // of sitting in front of every row group's arithmetic (rows / columns past the edge are clamped, results discarded).
@@ -120,6 +135,7 @@ __device__ __forceinline__ void nt_epilogue(const GemmNT& p, f32x4 (&acc)[TM][4]
     if (has_resid) {
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) {
+        if (!full && rr >= 2) continue;
         const int mc = min(mw0 + half * 32 + rr * 8 + er, p.M - 1);
         r0[rr] = *reinterpret_cast<const float4*>(p.resid + (size_t)mc * p.ldr + nc);
         r1[rr] = *reinterpret_cast<const float4*>(p.resid + (size_t)mc * p.ldr + nc + 4);
@@ -128,6 +144,7 @@ __device__ __forceinline__ void nt_epilogue(const GemmNT& p, f32x4 (&acc)[TM][4]
     if (act == 2) {
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) {
+        if (!full && rr >= 2) continue;
         const int mc = min(mw0 + half * 32 + rr * 8 + er, p.M - 1);
         pre[rr] = *reinterpret_cast<const u32x4*>(p.aux + (size_t)mc * p.ldaux + nc);
       }
@@ -136,15 +153,42 @@ __device__ __forceinline__ void nt_epilogue(const GemmNT& p, f32x4 (&acc)[TM][4]
     for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
       for (int j = 0; j < 4; ++j)
-        *reinterpret_cast<f32x4*>(stg + (ii * 16 + frow) * 68 + j * 16 + fg * 4) = acc[half * 2 + ii][j];
+        if (full || ii == 0) *reinterpret_cast<f32x4*>(stg + (ii * 16 + frow) * 68 + j * 16 + fg * 4) = acc[full ? half * 2 + ii : half * 2][j];
     // same-wave LDS traffic only: no barrier, the compiler's lgkmcnt wait orders write -> read
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
+      if (!full && rr >= 2) continue;
       const int row = rr * 8 + er;
       const int m = mw0 + half * 32 + row;
       const float4 a0 = *reinterpret_cast<const float4*>(stg + row * 68 + ec), a1 = *reinterpret_cast<const float4*>(stg + row * 68 + ec + 4);
       if (m >= p.M || !nok) continue;
       float v[8] = {a0.x + bb[0], a0.y + bb[1], a0.z + bb[2], a0.w + bb[3], a1.x + bb[4], a1.y + bb[5], a1.z + bb[6], a1.w + bb[7]};
+      if constexpr (VAR == 8) {
+        // the 8 lanes sharing `er` hold the 64 columns of row m: chunk statistics by three xor-shuffles inside that group
+        const long lab = p.ce_labels[m];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) mx = n + e < p.ce_C ? fmaxf(mx, v[e]) : mx;
+        mx = fmaxf(mx, __shfl_xor(mx, 1, 64)); mx = fmaxf(mx, __shfl_xor(mx, 2, 64)); mx = fmaxf(mx, __shfl_xor(mx, 4, 64));
+        float se = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          se += n + e < p.ce_C ? __expf(v[e] - mx) : 0.f;
+          if ((long)(n + e) == lab) p.ce_zlab[m] = v[e];
+        }
+        se += __shfl_xor(se, 1, 64); se += __shfl_xor(se, 2, 64); se += __shfl_xor(se, 4, 64);
+        if ((lane & 7) == 0) *reinterpret_cast<float2*>(p.ce_part + ((size_t)m * (p.N >> 6) + (nw0 >> 6)) * 2) = float2{mx, se};
+        continue;
+      }
+      if constexpr (VAR == 9) {
+        const long lab = p.ce_labels[m];
+        const float sc = lab >= 0 ? p.ce_gscale * p.ce_g[0] / p.ce_stat[1] : 0.f, l = p.ce_lse[m];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = n + e < p.ce_C ? (__expf(v[e] - l) - ((long)(n + e) == lab ? 1.f : 0.f)) * sc : 0.f;
+        st16(reinterpret_cast<bf16_t*>(p.C) + (size_t)m * p.ldc + n,
+             u32x4{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7])}, false);
+        continue;
+      }
       if (act == 1) {
         st16(p.aux + (size_t)m * p.ldaux + n, u32x4{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7])}, wt);
 #pragma unroll
@@ -202,6 +246,12 @@ __device__ __forceinline__ void nt_epilogue(const GemmNT& p, f32x4 (&acc)[TM][4]
 template <int TM, int VAR>   // TM: 16-row MFMA tiles per wave along M: 4 -> 128x128 block tile, 6 -> 192x128 (2 x 80 KB LDS = exactly 2 blocks / CU)
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNT p) {
   constexpr int BMT = 32 * TM;                       // block rows (2 waves along M)
+  if constexpr (VAR == 7) {                          // slice blockIdx.y of the contraction -> its own M x N partial in the workspace
+    const int koff = blockIdx.y * p.ksplit;
+    p.A += koff; p.B += koff;
+    p.K = min(p.ksplit, p.K - koff);
+    p.C = reinterpret_cast<float*>(p.C) + (size_t)blockIdx.y * p.M * p.ldc;
+  }
   constexpr int A_BYTES = BMT * 128, STG = A_BYTES + TILE_BYTES;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -392,10 +442,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_w8_kernel(GemmNT p) {
   nt_epilogue<4, 4>(p, acc, smem, wave, lane, m0 + wm * 64, n0 + wn * 64);
 }
 
-// knobs for A/B measurements and for the tests that pin a kernel variant (0 = automatic everywhere):
+// knobs for A/B measurements and for the tests that pin a kernel variant (0 = automatic everywhere); [7] 1: no 160x128 NT tiles
 //   [0] GROUP_M of the NT tile raster            [1] 2: NT on the 8-wave 256x128 kernel
 //   [2] NT ablation bits (4 no epilogue, 16 sc1 stores)          [6] 1: always the generic (run-time flags) NT epilogue
-//   [3] NT tile: 1 = 128x128, 2 = 192x128, 3 = 64x128        [4] NT start stagger (x 4 us)
+//   [3] NT tile: 1 = 128x128, 2 = 192x128, 3 = 64x128, 4 = 160x128        [4] NT start stagger (x 4 us)
 //   [5] TN: 1 = always 128x128 tiles, 2 = 256x256 tiles whenever the contraction lengths allow
 static int g_tune[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 extern "C" int x2_device_cus(void);
@@ -423,7 +473,7 @@ extern "C" int x2_gemm_nt(const void* A, const void* B, void* C, int M, int N, i
   X2_REQUIRE(act == 0 || aux, "x2_gemm_nt: act=%d needs aux", act);
   X2_REQUIRE((!resid || ldr % 4 == 0) && (!aux || ldaux % 8 == 0), "x2_gemm_nt: ldr/ldaux alignment");
   GemmNT p{(const bf16_t*)A, (const bf16_t*)B, C, bias, gamma, resid, (bf16_t*)aux, M, N, K, lda, ldb, ldc, ldr, ldaux, act, out_f32,
-           g_tune[0] > 0 ? g_tune[0] : 8, DropSpec{drop_thr16, drop_seed, drop_scale}, drop_epoch, rowscale, colsum, g_tune[2], g_tune[4]};
+           g_tune[0] > 0 ? g_tune[0] : 8, DropSpec{drop_thr16, drop_seed, drop_scale}, drop_epoch, rowscale, colsum, g_tune[2], g_tune[4], 0};
   // tile choice: [1] = 0 auto, 1 force 128x128 (4 waves), 2 force 256x128 (8 waves, 3-deep ring)
   const int tiles8 = ((M + 255) / 256) * ((N + 127) / 128);
   // measured (probes/bench_gemm.py): two independent 4-wave workgroups per CU beat one 8-wave workgroup with a
@@ -451,6 +501,11 @@ extern "C" int x2_gemm_nt(const void* A, const void* B, void* C, int M, int N, i
     // (192x128 on the long-row shapes of X2VLM-large - qkv / fc1 at K = 1024, fc2 at K = 4096 - is 4-9 % faster in
     // probes/bench_gemm_large.py but neutral inside the step: not selected)
     const bool use192 = !use64 && (g_tune[3] == 2 || (g_tune[3] == 0 && t128 > slots && t192 <= slots));
+    // 160x128 where 192x128 was chosen to save a round and 160-row tiles still fit that one round: the vision N = 768
+    // outputs are 79 x 6 = 474 tiles instead of 66 x 6 = 396, i.e. the busiest CU holds 2 x 160 rows instead of 2 x 192
+    // (balanced would be 148): x2_tune(7, 1) switches the rule off
+    const int t160 = ((M + 159) / 160) * ((N + BN - 1) / BN);
+    const bool use160 = g_tune[3] == 4 || (use192 && g_tune[3] == 0 && g_tune[7] != 1 && t160 <= slots);
     // epilogue variant (EpiTraits): the feature sets the step uses are compiled separately, anything else runs the generic one
     int var = 4;
     const bool plain = !gamma && !rowscale && !drop_thr16 && !colsum;
@@ -467,9 +522,17 @@ extern "C" int x2_gemm_nt(const void* A, const void* B, void* C, int M, int N, i
 #undef X2_ATTR192
       attr192 = true;
     }
+    static bool attr160 = false;
+    if (use160 && !attr160) {
+#define X2_ATTR160(V) hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<5, V>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (160 * 128 + TILE_BYTES))
+      X2_ATTR160(0); X2_ATTR160(1); X2_ATTR160(2); X2_ATTR160(3); X2_ATTR160(4); X2_ATTR160(5); X2_ATTR160(6);
+#undef X2_ATTR160
+      attr160 = true;
+    }
 #define X2_NT_LAUNCH(V)                                                                                                              \
     do {                                                                                                                             \
       if (use64) hipLaunchKernelGGL((gemm_nt_kernel<2, V>), dim3(t64), dim3(256), 2 * (64 * 128 + TILE_BYTES), (hipStream_t)stream, p);   \
+      else if (use160) hipLaunchKernelGGL((gemm_nt_kernel<5, V>), dim3(t160), dim3(256), 2 * (160 * 128 + TILE_BYTES), (hipStream_t)stream, p); \
       else if (use192) hipLaunchKernelGGL((gemm_nt_kernel<6, V>), dim3(t192), dim3(256), 2 * (192 * 128 + TILE_BYTES), (hipStream_t)stream, p); \
       else hipLaunchKernelGGL((gemm_nt_kernel<4, V>), dim3(t128), dim3(256), GEMM_LDS_BYTES, (hipStream_t)stream, p);               \
     } while (0)
@@ -485,6 +548,96 @@ extern "C" int x2_gemm_nt(const void* A, const void* B, void* C, int M, int N, i
 #undef X2_NT_LAUNCH
   }
   return x2_check_launch("x2_gemm_nt");
+}
+
+// ---------------------------------------------------------------------------------------------
+// NT with a split contraction: C[M,N] (fp32, no epilogue) = A[M,K] . B[N,K]^T for few output tiles and a long K - the
+// input gradient of the tied MLM decoder, dt[R,768] = dlogits[R,30528] . E^T, is 36-72 tiles of 477 contraction steps,
+// i.e. a 354 us serial chain on a seventh of the chip.  Slice s of the contraction (gridDim.y) writes its M x N partial
+// product to ws[s] through the ordinary NT kernel (epilogue variant 7), gemm_nt_sum_slices_kernel adds the slices in a
+// fixed order (deterministic, no atomics).  slices = 0: as many as fill two workgroups per CU, at least 8 steps each.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gemm_nt_sum_slices_kernel(const float* __restrict__ ws, float* __restrict__ C, int M, int N, int ldc, int S) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x, per = (long)M * N / 4;      // one float4 of the M x N result
+  if (e >= per) return;
+  const int m = (int)(e * 4 / N), n = (int)(e * 4 % N);
+  float4 o = *reinterpret_cast<const float4*>(ws + e * 4);
+  for (int s_ = 1; s_ < S; ++s_) {
+    const float4 v = *reinterpret_cast<const float4*>(ws + (size_t)s_ * M * N + e * 4);
+    o.x += v.x; o.y += v.y; o.z += v.z; o.w += v.w;
+  }
+  *reinterpret_cast<float4*>(C + (size_t)m * ldc + n) = o;
+}
+extern "C" int x2_gemm_nt_splitk(const void* A, const void* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
+                                 int slices, float* ws, long ws_floats, void* stream) {
+  X2_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0, "x2_gemm_nt_splitk: empty problem M=%d N=%d K=%d", M, N, K);
+  X2_REQUIRE(K % BK == 0 && N % 8 == 0, "x2_gemm_nt_splitk: K=%d must be a multiple of %d, N=%d of 8", K, BK, N);
+  X2_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && ldc % 4 == 0 && ldc >= N, "x2_gemm_nt_splitk: leading dims must keep 16-byte rows");
+  X2_REQUIRE(slices >= 0, "x2_gemm_nt_splitk: slices=%d", slices);
+  const int nk = K / BK, tiles_n = (N + BN - 1) / BN;
+  const bool small = M <= 64;                                     // 64-row tiles when there is a single short row panel
+  const int tiles = (small ? (M + 63) / 64 : (M + 127) / 128) * tiles_n;
+  int S = slices;
+  if (S == 0) { S = (2 * x2_cus() + tiles - 1) / tiles; if (S > nk / 8) S = nk / 8; }
+  if (S > nk) S = nk;
+  const long per = (long)M * N;
+  if (ws == nullptr) S = 1;
+  else if ((long)S * per > ws_floats) S = (int)(ws_floats / per);
+  if (S < 1) S = 1;
+  const int steps = (nk + S - 1) / S;                             // contraction steps per slice; the last slice may be shorter
+  S = (nk + steps - 1) / steps;                                   // no empty slice
+  GemmNT p{(const bf16_t*)A, (const bf16_t*)B, S > 1 ? (void*)ws : (void*)C, nullptr, nullptr, nullptr, nullptr, M, N, K, lda, ldb,
+           S > 1 ? N : ldc, 0, 0, 0, 1, g_tune[0] > 0 ? g_tune[0] : 8, DropSpec{0u, 0u, 1.f}, nullptr, nullptr, nullptr, 0, 0, steps * BK};
+  if (small) hipLaunchKernelGGL((gemm_nt_kernel<2, 7>), dim3(tiles, S), dim3(256), 2 * (64 * 128 + TILE_BYTES), (hipStream_t)stream, p);
+  else hipLaunchKernelGGL((gemm_nt_kernel<4, 7>), dim3(tiles, S), dim3(256), GEMM_LDS_BYTES, (hipStream_t)stream, p);
+  if (S > 1)
+    hipLaunchKernelGGL(gemm_nt_sum_slices_kernel, dim3((unsigned)((per / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ws, C, M, N, ldc, S);
+  return x2_check_launch("x2_gemm_nt_splitk");
+}
+
+// ---------------------------------------------------------------------------------------------
+// MLM head: cross-entropy over the tied decoder WITHOUT materialising the [R, Vp] fp32 logits (94 MB written once and
+// read twice per step at R = 768).  Forward: the decoder GEMM's epilogue reduces every 64-column chunk of a row to
+// (max, sum exp) and picks the logit at the label; x2_ce_combine (heads.hip) folds the Vp / 64 chunks of a row into its
+// log-partition and the mean loss.  Backward: the same GEMM again (36 GFLOP, ~45 us) with an epilogue that turns the
+// accumulators straight into (softmax - onehot) * g / count in bf16 - the operand of the two gradient GEMMs that follow.
+// Reference: BertLMPredictionHead.decoder + CrossEntropyLoss, xbert.py:822, 1653-1661.
+// ---------------------------------------------------------------------------------------------
+static int launch_nt_ce(GemmNT& p, int var, hipStream_t stream) {
+  const int tiles_n = (p.N + BN - 1) / BN, t128 = ((p.M + 127) / 128) * tiles_n, t64 = ((p.M + 63) / 64) * tiles_n;
+  const bool use64 = t128 <= 2 * x2_cus();
+  if (var == 8) {
+    if (use64) hipLaunchKernelGGL((gemm_nt_kernel<2, 8>), dim3(t64), dim3(256), 2 * (64 * 128 + TILE_BYTES), stream, p);
+    else hipLaunchKernelGGL((gemm_nt_kernel<4, 8>), dim3(t128), dim3(256), GEMM_LDS_BYTES, stream, p);
+  } else {
+    if (use64) hipLaunchKernelGGL((gemm_nt_kernel<2, 9>), dim3(t64), dim3(256), 2 * (64 * 128 + TILE_BYTES), stream, p);
+    else hipLaunchKernelGGL((gemm_nt_kernel<4, 9>), dim3(t128), dim3(256), GEMM_LDS_BYTES, stream, p);
+  }
+  return 0;
+}
+static bool mlm_ce_shapes_ok(int R, int Vp, int V, int Hd, int ldx, int lde) {
+  return R > 0 && V > 0 && V <= Vp && Vp % 64 == 0 && Hd > 0 && Hd % BK == 0 && ldx % 8 == 0 && lde % 8 == 0 && ldx >= Hd && lde >= Hd;
+}
+extern "C" int x2_mlm_ce_fwd(const void* X, const void* E, const float* bias, const long* labels, int R, int Vp, int V, int Hd,
+                             int ldx, int lde, float* part, float* zlab, void* stream) {
+  X2_REQUIRE(X && E && labels && part && zlab, "x2_mlm_ce_fwd: null argument");
+  X2_REQUIRE(mlm_ce_shapes_ok(R, Vp, V, Hd, ldx, lde), "x2_mlm_ce_fwd: R=%d Vp=%d V=%d Hd=%d ldx=%d lde=%d", R, Vp, V, Hd, ldx, lde);
+  GemmNT p{(const bf16_t*)X, (const bf16_t*)E, nullptr, bias, nullptr, nullptr, nullptr, R, Vp, Hd, ldx, lde, Vp, 0, 0, 0, 0,
+           g_tune[0] > 0 ? g_tune[0] : 8, DropSpec{0u, 0u, 1.f}, nullptr, nullptr, nullptr, 0, 0, 0,
+           labels, nullptr, nullptr, nullptr, part, zlab, 1.f, V};
+  launch_nt_ce(p, 8, (hipStream_t)stream);
+  return x2_check_launch("x2_mlm_ce_fwd");
+}
+extern "C" int x2_mlm_ce_bwd(const void* X, const void* E, const float* bias, const long* labels, const float* lse, const float* g,
+                             const float* stat, float gscale, int R, int Vp, int V, int Hd, int ldx, int lde, void* dl_bf16, long ldd,
+                             void* stream) {
+  X2_REQUIRE(X && E && labels && lse && g && stat && dl_bf16, "x2_mlm_ce_bwd: null argument");
+  X2_REQUIRE(mlm_ce_shapes_ok(R, Vp, V, Hd, ldx, lde) && ldd >= Vp && ldd % 8 == 0, "x2_mlm_ce_bwd: R=%d Vp=%d V=%d Hd=%d ldd=%ld", R, Vp, V, Hd, ldd);
+  GemmNT p{(const bf16_t*)X, (const bf16_t*)E, dl_bf16, bias, nullptr, nullptr, nullptr, R, Vp, Hd, ldx, lde, (int)ldd, 0, 0, 0, 0,
+           g_tune[0] > 0 ? g_tune[0] : 8, DropSpec{0u, 0u, 1.f}, nullptr, nullptr, nullptr, 0, 0, 0,
+           labels, lse, g, stat, nullptr, nullptr, gscale, V};
+  launch_nt_ce(p, 9, (hipStream_t)stream);
+  return x2_check_launch("x2_mlm_ce_bwd");
 }
 
 // ---------------------------------------------------------------------------------------------

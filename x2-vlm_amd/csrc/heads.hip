@@ -244,6 +244,35 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ l
     if (dlb) dlb[(long)r * ldd + c] = f2bf(v);
   }
 }
+// Fused MLM cross-entropy, second stage (first stage: x2_mlm_ce_fwd, gemm.hip): fold the (max, sum exp) pairs of a row's
+// 64-column chunks into its log-partition; loss_row = lse - logit[label] (0 for ignored rows).  One wave per row.
+__global__ __launch_bounds__(256) void ce_combine_kernel(const float* __restrict__ part, int chunks, const float* __restrict__ zlab,
+                                                         const long* __restrict__ labels, int R, float* lse, float* loss_row) {
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (r >= R) return;
+  const float2* pr = reinterpret_cast<const float2*>(part) + (size_t)r * chunks;
+  float mx = -INFINITY;
+  for (int c = lane; c < chunks; c += 64) mx = fmaxf(mx, pr[c].x);
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  float s = 0.f;
+  for (int c = lane; c < chunks; c += 64) { const float2 q = pr[c]; s += q.y * __expf(q.x - mx); }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (lane == 0) {
+    const float l = mx + logf(s);
+    const long lab = labels[r];
+    lse[r] = l;
+    loss_row[r] = lab >= 0 ? l - zlab[r] : 0.f;
+  }
+}
+extern "C" int x2_ce_combine(const float* part, int chunks, const float* zlab, const long* labels, int R, float* lse, float* loss_row,
+                             float* out2, void* stream) {
+  X2_REQUIRE(part && zlab && labels && lse && loss_row && out2 && R > 0 && chunks > 0, "x2_ce_combine: R=%d chunks=%d", R, chunks);
+  hipLaunchKernelGGL(ce_combine_kernel, dim3((R + 3) / 4), dim3(256), 0, (hipStream_t)stream, part, chunks, zlab, labels, R, lse, loss_row);
+  hipLaunchKernelGGL(ce_reduce_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, loss_row, labels, R, out2);
+  return x2_check_launch("x2_ce_combine");
+}
 extern "C" int x2_ce_fwd(const float* logits, long ld, const long* labels, int R, int C, float* lse, float* loss_row, float* out2,
                          void* stream) {
   X2_REQUIRE(R > 0 && C > 0 && ld >= C, "x2_ce_fwd: R=%d C=%d ld=%ld", R, C, ld);

@@ -179,6 +179,9 @@ class WeightBank:
 
 
 BANK = WeightBank()
+SPLIT_DECODER_DGRAD = os.environ.get("X2_SPLIT_DECODER_DGRAD", "1") == "1"     # A/B switches (probes/run_ab3.sh)
+FUSED_MLM_CE = os.environ.get("X2_FUSED_MLM_CE", "1") == "1"
+KEEP_MLM_LOGITS = False     # tests: also materialise the MLM logits (inspection only; the loss still comes from the fused path)
 
 
 class Grads:
@@ -284,7 +287,9 @@ def _begin_layer_backward():
 class _LayerPairs:
     """Weight gradients of TWO consecutive layers per grouped launch when they fit its 8 problem slots (a vision block
     or a text layer has 4): 216 tiles of 256x256 fill the 256 CUs without splitting the contraction, so there are no
-    partial tiles to write and re-add, and half the launches.  Layers with more problems (fusion: 7) go alone."""
+    partial tiles to write and re-add, and half the launches.  Layers with more problems (fusion: 7) go alone.
+    (Measured and dropped: un-pairing the LAST two vision layers so that only two weight gradients remain after the critical
+    stream has finished block 0 - the split launches cost more than the shorter tail saves: 25.48 -> 25.90 ms per base step.)"""
 
     enabled = os.environ.get("X2_PAIR_WGRAD", "1") == "1"
 
@@ -749,10 +754,16 @@ class EmbeddingsFn(torch.autograd.Function):
 class MlmLossFn(torch.autograd.Function):
     """rows (R,Hd) fp32 at the masked positions -> mean CE over labels != -100.
     transform dense + GELU + LayerNorm, decoder tied to the word embeddings + bias
-    (xbert.py:785-824, 1653-1661).  Returns (loss, logits fp32 [R, Vp] detached view for inspection)."""
+    (xbert.py:785-824, 1653-1661).  Returns (loss, lse [R], logits): the per-row log-partition and - only when they were
+    materialised (unfused path, keep_logits, or KEEP_MLM_LOGITS for tests; else None) - the fp32 logits [R, Vp]; neither is
+    differentiable.
+
+    Fused path (default): the decoder GEMM's epilogue reduces the logits to softmax statistics, the backward recomputes the
+    GEMM and writes (softmax - onehot) * g / count straight to bf16 (csrc/gemm.hip, x2_mlm_ce_fwd / _bwd): no [R, Vp] fp32
+    tensor (94 MB at R = 768) is written, saved or read."""
 
     @staticmethod
-    def forward(ctx, rows, labels, eps, dw_, db_, lnw, lnb, dec_bias, word):
+    def forward(ctx, rows, labels, eps, keep_logits, dw_, db_, lnw, lnb, dec_bias, word):
         R, Hd = rows.shape
         V = word.shape[0]
         rb = K.cast_bf16(rows.contiguous())
@@ -764,27 +775,41 @@ class MlmLossFn(torch.autograd.Function):
         Vp = Eb.shape[0]
         bias_p = torch.zeros(Vp, device=rows.device, dtype=F32)
         bias_p[:V] = dec_bias.detach()
-        logits = K.gemm_nt(tb, Eb, bias=bias_p, out_dtype=F32)
         labels = labels.contiguous().view(-1)
-        stat, lse = K.ce_fwd(logits, labels, C_valid=V)
-        ctx.save_for_backward(rb, t_pre, t_act, mean, rstd, tb, logits, labels, lse, stat, dw_, lnw, word)
+        ctx.fused = FUSED_MLM_CE
+        logits = None
+        if not ctx.fused or keep_logits or KEEP_MLM_LOGITS:
+            logits = K.gemm_nt(tb, Eb, bias=bias_p, out_dtype=F32)
+        if ctx.fused:
+            stat, lse = K.mlm_ce_fwd(tb, Eb, bias_p, labels, V)
+            saved = bias_p
+        else:
+            stat, lse = K.ce_fwd(logits, labels, C_valid=V)
+            saved = logits
+        ctx.save_for_backward(rb, t_pre, t_act, mean, rstd, tb, saved, labels, lse, stat, dw_, lnw, word)
         ctx.V = V
-        ctx.mark_non_differentiable(logits)
-        return stat[0].clone(), logits
+        lse_out = lse.clone()
+        ctx.mark_non_differentiable(*([lse_out] + ([logits] if logits is not None else [])))
+        return stat[0].clone(), lse_out, logits
 
     @staticmethod
-    def backward(ctx, g, _gl):
-        rb, t_pre, t_act, mean, rstd, tb, logits, labels, lse, stat, dw_, lnw, word = ctx.saved_tensors
+    def backward(ctx, g, _glse, _gl):
+        rb, t_pre, t_act, mean, rstd, tb, saved, labels, lse, stat, dw_, lnw, word = ctx.saved_tensors
         BANK.note_backward()
         V = ctx.V
         R, Hd = rb.shape
         dev = rb.device
-        dl = K.ce_bwd(logits, labels, lse, g.reshape(1).to(F32).contiguous(), stat, C_valid=V, out_dtype=BF16)
+        Eb, EbT = BANK.vocab(word)
+        g1 = g.reshape(1).to(F32).contiguous()
+        if ctx.fused:
+            dl = K.mlm_ce_bwd(tb, Eb, saved, labels, lse, g1, stat, V)
+        else:
+            dl = K.ce_bwd(saved, labels, lse, g1, stat, C_valid=V, out_dtype=BF16)
         Vp = dl.shape[1]
         dbias = torch.zeros(Vp, device=dev, dtype=F32)
         K.colsum_bf16(dl, dbias)
-        Eb, EbT = BANK.vocab(word)
-        dt = K.gemm_nt(dl, EbT, out_dtype=F32)                       # [R, Hd]
+        # [R, Hd] from a 30528-long contraction: 36-72 output tiles, so the contraction is split (354 -> ~50 us)
+        dt = K.gemm_nt_splitk(dl, EbT) if SPLIT_DECODER_DGRAD else K.gemm_nt(dl, EbT, out_dtype=F32)
         dword = torch.empty_like(word)
         small = torch.zeros(3 * Hd, device=dev, dtype=F32)
         dlnw, dlnb, dbd = small[:Hd], small[Hd:2 * Hd], small[2 * Hd:]
@@ -796,7 +821,7 @@ class MlmLossFn(torch.autograd.Function):
         drows = K.gemm_nt(dpre_b, wdT, out_dtype=F32)
         ddw = torch.empty_like(dw_)
         K.gemm_tn_grouped([(dl, tb, dword, Vp, Hd), (dpre_b, rb, ddw)])
-        return drows, None, None, ddw, dbd, dlnw, dlnb, dbias[:V], dword
+        return drows, None, None, None, ddw, dbd, dlnw, dlnb, dbias[:V], dword
 
 
 # ----------------------------------------------------------------------------- small differentiable ops (heads)

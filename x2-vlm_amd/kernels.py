@@ -158,6 +158,22 @@ def gemm_nt(A, B, *, bias=None, gamma=None, resid=None, aux=None, act=0, out=Non
     return out
 
 
+def gemm_nt_splitk(A, B, out=None, slices=0):
+    """out[M,N] fp32 = A[M,K] @ B[N,K]^T with the contraction cut into slices (0 = the library fills the CUs): few output
+    tiles, long K (input gradient of the tied MLM decoder).  Partials pass through the stream workspace and are added in
+    a fixed order."""
+    assert A.dtype == BF16 and B.dtype == BF16 and A.shape[1] == B.shape[1]
+    M, K = A.shape
+    N = B.shape[0]
+    if out is None:
+        out = torch.empty(M, N, device=A.device, dtype=F32)
+    assert out.shape == (M, N) and out.dtype == F32
+    ws = workspace(A.device, min(32, max(1, K // 64)) * M * N)       # room for up to 32 slices
+    with _timed(2.0 * M * N * K):
+        call("x2_gemm_nt_splitk", ptr(A), ptr(B), ptr(out), M, N, K, _rows(A), _rows(B), _rows(out), slices, ptr(ws), ws.numel())
+    return out
+
+
 def gemm_tn_grouped(problems, accumulate=False, split=0):
     """Weight gradients of one layer in one launch.  problems: list of (dY[Mc,N] bf16, X[Mc,K] bf16,
     dW[N,K] fp32) or 5-tuples with (n_ld, k_ld) = readable row widths when they exceed N / K.
@@ -478,6 +494,34 @@ def ce_bwd(logits, labels, lse, g, stat, C_valid=None, gscale=1.0, out_dtype=F32
     dl = torch.empty(R, ld, device=logits.device, dtype=out_dtype)
     call("x2_ce_bwd", ptr(logits), ld, ptr(labels), ptr(lse), ptr(g), ptr(stat), gscale, R, Cv,
          ptr(dl) if out_dtype == F32 else None, ptr(dl) if out_dtype == BF16 else None, ld)
+    return dl
+
+
+def mlm_ce_fwd(x, E, bias, labels, V):
+    """Cross-entropy of z = x @ E^T + bias over the first V columns without storing z (x [R,Hd] bf16, E [Vp,Hd] bf16,
+    Vp % 64 == 0).  Returns (stat[2] = (mean loss, #counted rows), lse[R])."""
+    assert x.dtype == BF16 and E.dtype == BF16 and x.shape[1] == E.shape[1] and bias.dtype == F32 and bias.numel() == E.shape[0]
+    assert labels.dtype == torch.int64 and labels.numel() == x.shape[0]
+    R, Hd = x.shape
+    Vp = E.shape[0]
+    dev = x.device
+    part = torch.empty(R, Vp // 64, 2, device=dev, dtype=F32)
+    small = torch.empty(3 * R + 2, device=dev, dtype=F32)
+    zlab, lse, rows, stat = small[:R], small[R:2 * R], small[2 * R:3 * R], small[3 * R:]
+    with _timed(2.0 * R * Vp * Hd):
+        call("x2_mlm_ce_fwd", ptr(x), ptr(E), ptr(bias), ptr(labels), R, Vp, V, Hd, _rows(x), _rows(E), ptr(part), ptr(zlab))
+    call("x2_ce_combine", ptr(part), Vp // 64, ptr(zlab), ptr(labels), R, ptr(lse), ptr(rows), ptr(stat))
+    return stat, lse
+
+
+def mlm_ce_bwd(x, E, bias, labels, lse, g, stat, V, gscale=1.0):
+    """dlogits bf16 [R, Vp] of the loss above (logits recomputed in the GEMM, never stored)."""
+    R, Hd = x.shape
+    Vp = E.shape[0]
+    dl = torch.empty(R, Vp, device=x.device, dtype=BF16)
+    with _timed(2.0 * R * Vp * Hd, "gemm_nt_recompute"):        # not algorithmic work: kept out of bench.py's NT roofline sums
+        call("x2_mlm_ce_bwd", ptr(x), ptr(E), ptr(bias), ptr(labels), ptr(lse), ptr(g), ptr(stat), gscale, R, Vp, V, Hd,
+             _rows(x), _rows(E), ptr(dl), Vp)
     return dl
 
 

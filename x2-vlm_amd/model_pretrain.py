@@ -66,8 +66,7 @@ class XVLM(XVLMBase):
             loss_itm = self._itm_loss(fused[:3 * B, 0, :], B)
         else:
             loss_itm = torch.tensor(0.0)
-        loss_mlm, logits = self.text_encoder.mlm_loss_from_hidden(fused[-B:], masked_pos, masked_ids)
-        self.last_mlm_logits = logits
+        loss_mlm, self.last_mlm_lse, self.last_mlm_logits = self.text_encoder.mlm_loss_from_hidden(fused[-B:], masked_pos, masked_ids)
         loss = {"loss_itc": loss_itc, "loss_itm": loss_itm, "loss_mlm": loss_mlm}
         # detached: holding graph tensors here would keep the step's autograd graph (and its AccumulateGrad nodes) alive
         # across iterations

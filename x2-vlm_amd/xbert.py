@@ -211,13 +211,14 @@ class BertForMaskedLM(nn.Module):
         self.apply(lambda m: _bert_init(m, config.initializer_range))
         self.cls.predictions.decoder.weight = self.bert.embeddings.word_embeddings.weight
 
-    def mlm_loss_from_hidden(self, sequence_output, masked_pos, labels):
-        """gather masked positions (xbert.py:1588-1589), head, CE.  Returns (loss, logits [B*M, Vp])."""
+    def mlm_loss_from_hidden(self, sequence_output, masked_pos, labels, keep_logits=False):
+        """gather masked positions (xbert.py:1588-1589), head, CE.  Returns (loss, lse [B*M], logits [B*M, Vp] or None: the
+        logits only exist when asked for - the loss comes from softmax statistics reduced inside the decoder GEMM)."""
         B, L, Hd = sequence_output.shape
         flat = (torch.arange(B, device=masked_pos.device).unsqueeze(1) * L + masked_pos).reshape(-1)
         rows = ops.gather_rows(sequence_output.reshape(B * L, Hd), flat)
         pr = self.cls.predictions
-        return MlmLossFn.apply(rows, labels, self.config.layer_norm_eps, pr.transform.dense.weight, pr.transform.dense.bias,
+        return MlmLossFn.apply(rows, labels, self.config.layer_norm_eps, keep_logits, pr.transform.dense.weight, pr.transform.dense.bias,
                                pr.transform.LayerNorm.weight, pr.transform.LayerNorm.bias, pr.bias,
                                self.bert.embeddings.word_embeddings.weight)
 
@@ -228,8 +229,9 @@ class BertForMaskedLM(nn.Module):
         h = self.bert(input_ids, attention_mask=attention_mask, encoder_hidden_states=encoder_hidden_states,
                       encoder_attention_mask=encoder_attention_mask, mode=mode).last_hidden_state
         lab = labels if labels is not None else torch.full_like(masked_pos, -100)
-        loss, logits = self.mlm_loss_from_hidden(h, masked_pos, lab)
-        logits = logits[:, :self.config.vocab_size].view(masked_pos.shape[0], masked_pos.shape[1], -1)
+        loss, _, logits = self.mlm_loss_from_hidden(h, masked_pos, lab, keep_logits=return_logits)
+        if logits is not None:
+            logits = logits[:, :self.config.vocab_size].view(masked_pos.shape[0], masked_pos.shape[1], -1)
         if return_logits:
             return logits
         return SimpleNamespace(loss=loss if labels is not None else None, logits=logits)
