@@ -1,0 +1,58 @@
+"""NT epilogue A/B on the step's shapes: LDS-staged (x2_tune(2, 0)) vs lane-swap (x2_tune(2, 32)), interleaved, plus the
+main-loop-only time (x2_tune(2, 4)) so that the epilogue's share is visible.  python probes/bench_epi_swap.py [large]"""
+import importlib, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+K = importlib.import_module("x2-vlm_amd.kernels")
+lib = importlib.import_module("x2-vlm_amd._lib").lib()
+dev = "cuda"
+
+
+def timeit(fn, iters=10):
+    fn(); fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        fn()
+    b.record(); torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters * 1e3
+
+
+def case(M, N, Kd, epi):
+    A = torch.randn(M, Kd, device=dev).bfloat16(); B = (torch.randn(N, Kd, device=dev) * Kd ** -0.5).bfloat16()
+    bias = torch.randn(N, device=dev)
+    kw = dict(bias=bias)
+    if epi == "gelu":
+        kw.update(aux=torch.empty(M, N, device=dev, dtype=torch.bfloat16), act=1)
+    elif epi == "dgelu":
+        kw = dict(aux=torch.randn(M, N, device=dev).bfloat16(), act=2)
+    elif epi == "lscale":
+        kw.update(resid=torch.randn(M, N, device=dev), gamma=bias, aux=torch.empty(M, N, device=dev, dtype=torch.bfloat16), out_dtype=torch.float32)
+    elif epi == "resid":
+        kw.update(resid=torch.randn(M, N, device=dev), out_dtype=torch.float32)
+    elif epi == "dgrad":
+        kw = {}
+    return lambda: K.gemm_nt(A, B, **kw)
+
+
+BASE = [("fc1 fwd", 12608, 3072, 768, "gelu"), ("fc2 fwd", 12608, 768, 3072, "lscale"), ("qkv fwd", 12608, 2304, 768, "bias"),
+        ("proj fwd", 12608, 768, 768, "lscale"), ("dfc2 dgelu", 12608, 3072, 768, "dgelu"), ("dfc1 dgrad", 12608, 768, 3072, "dgrad"),
+        ("dqkv dgrad", 12608, 768, 2304, "dgrad"), ("fus ffn1", 7680, 3072, 768, "gelu"), ("fus out", 7680, 768, 768, "resid"),
+        ("text out", 3840, 768, 768, "resid")]
+LARGE = [("fc1 fwd", 18464, 4096, 1024, "gelu"), ("fc2 fwd", 18464, 1024, 4096, "lscale"), ("qkv fwd", 18464, 3072, 1024, "bias"),
+         ("dfc2 dgelu", 18464, 4096, 1024, "dgelu")]
+tot = {0: 0.0, 32: 0.0, 4: 0.0}
+for name, M, N, Kd, epi in (LARGE if len(sys.argv) > 1 else BASE):
+    fn = case(M, N, Kd, epi)
+    best = {0: 1e9, 32: 1e9, 4: 1e9}
+    for rep in range(2):
+        for g in (0, 32, 4):
+            lib.x2_tune(2, g)
+            best[g] = min(best[g], timeit(fn))
+    lib.x2_tune(2, 0)
+    for g in best:
+        tot[g] += best[g]
+    print("%-11s M=%5d N=%5d K=%4d %-6s staged %6.1f us   swap %6.1f us (%+5.1f %%)   main loop only %6.1f us" %
+          (name, M, N, Kd, epi, best[0], best[32], 100.0 * (best[32] / best[0] - 1.0), best[4]), flush=True)
+print("sum: staged %.1f  swap %.1f  main loops %.1f us" % (tot[0], tot[32], tot[4]))

@@ -89,6 +89,50 @@ def test_gemm_nt_plain_and_epilogues(K, M, N, K_, nt_tile):
     assert relerr(out, resid + ref + bias) < 1e-5
 
 
+@pytest.mark.parametrize("tile", [1, 2, 3, 4], ids=["tile128", "tile192", "tile64", "tile160"])
+@pytest.mark.parametrize("M,N,K_", [(300, 200, 192), (788, 2304, 128), (1000, 768, 256)])
+def test_gemm_nt_lane_swap_epilogue_matches_the_staged_one(K, M, N, K_, tile):
+    """x2_tune(2, 32): rows assembled by v_permlane16_swap instead of the LDS round trip - same arithmetic in the same order,
+    so every compiled feature set must reproduce the staged epilogue (outputs and saved pre-activations)."""
+    lib = importlib.import_module("x2-vlm_amd._lib").lib()
+    A, B = bf(rnd(M, K_, seed=31)).to(dev), bf(rnd(N, K_, seed=32, scale=K_ ** -0.5)).to(dev)
+    bias, gamma, resid = rnd(N, seed=33).to(dev), rnd(N, seed=34).to(dev), rnd(M, N, seed=35).to(dev)
+    pre, rowscale = bf(rnd(M, N, seed=36)).to(dev), (torch.rand(M, generator=torch.Generator().manual_seed(37)) > 0.2).float().to(dev) * 1.25
+    drop = K.dropout_spec(0.1, 1234, 5)
+
+    def run(kind):
+        aux = torch.zeros(M, N, device=dev, dtype=torch.bfloat16)
+        if kind == "bias_bf16":
+            return K.gemm_nt(A, B, bias=bias), aux
+        if kind == "bias_f32":
+            return K.gemm_nt(A, B, bias=bias, out_dtype=torch.float32), aux
+        if kind == "gelu":
+            return K.gemm_nt(A, B, bias=bias, aux=aux, act=1), aux
+        if kind == "dgelu":
+            return K.gemm_nt(A, B, aux=pre, act=2), aux
+        if kind == "bias_drop_resid":
+            return K.gemm_nt(A, B, bias=bias, resid=resid, out_dtype=torch.float32, drop=drop), aux
+        if kind == "bias_resid":
+            return K.gemm_nt(A, B, bias=bias, resid=resid, out_dtype=torch.float32), aux
+        if kind == "layerscale":
+            return K.gemm_nt(A, B, bias=bias, gamma=gamma, resid=resid, aux=aux, out_dtype=torch.float32), aux
+        return K.gemm_nt(A, B, bias=bias, gamma=gamma, resid=resid, aux=aux, out_dtype=torch.float32, rowscale=rowscale), aux
+
+    lib.x2_tune(1, 1); lib.x2_tune(3, tile)
+    try:
+        for kind in ("bias_bf16", "bias_f32", "gelu", "dgelu", "bias_drop_resid", "bias_resid", "layerscale", "layerscale_droppath"):
+            lib.x2_tune(2, 0)
+            ref, ref_aux = run(kind)
+            lib.x2_tune(2, 32)
+            got, got_aux = run(kind)
+            # same operations in the same order; only the compiler's fma contraction may differ between the two instantiations
+            for g_, r_ in ((got, ref), (got_aux, ref_aux)):
+                tol = 2e-6 if g_.dtype == torch.float32 else 4e-3
+                assert float((g_.float() - r_.float()).abs().max()) <= tol * max(1.0, float(r_.float().abs().max())), kind
+    finally:
+        lib.x2_tune(1, 0); lib.x2_tune(2, 0); lib.x2_tune(3, 0)
+
+
 @pytest.mark.parametrize("M,N,K_,slices", [(768, 768, 30528, 0), (96, 768, 30528, 0), (40, 256, 4096, 0), (300, 200, 1024, 3),
                                            (130, 136, 640, 10), (256, 256, 128, 0), (384, 1024, 30528, 7)])
 def test_gemm_nt_split_contraction(K, M, N, K_, slices):
