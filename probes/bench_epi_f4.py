@@ -1,5 +1,7 @@
-"""NT epilogue A/B on the step's shapes: LDS-staged (x2_tune(2, 0)) vs lane-swap (x2_tune(2, 32)), interleaved, plus the
-main-loop-only time (x2_tune(2, 4)) so that the epilogue's share is visible.  python probes/bench_epi_swap.py [large]"""
+"""NT epilogue A/B on the step's fp32-out shapes: default read-back (a lane = 8 columns of one row, x2_tune(2, 0)) vs
+row-contiguous fp32 stores (a lane = 4 columns of two rows, x2_tune(2, 64)), interleaved, plus the main-loop-only time
+(x2_tune(2, 4)).  python probes/bench_epi_f4.py [large]
+(The lane-swap epilogue without the LDS round trip measured with this script's predecessor: profiles/r02e_epi_swap_probe.txt.)"""
 import importlib, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -31,28 +33,26 @@ def case(M, N, Kd, epi):
         kw.update(resid=torch.randn(M, N, device=dev), gamma=bias, aux=torch.empty(M, N, device=dev, dtype=torch.bfloat16), out_dtype=torch.float32)
     elif epi == "resid":
         kw.update(resid=torch.randn(M, N, device=dev), out_dtype=torch.float32)
-    elif epi == "dgrad":
-        kw = {}
+    elif epi == "f32":
+        kw.update(out_dtype=torch.float32)
     return lambda: K.gemm_nt(A, B, **kw)
 
 
-BASE = [("fc1 fwd", 12608, 3072, 768, "gelu"), ("fc2 fwd", 12608, 768, 3072, "lscale"), ("qkv fwd", 12608, 2304, 768, "bias"),
-        ("proj fwd", 12608, 768, 768, "lscale"), ("dfc2 dgelu", 12608, 3072, 768, "dgelu"), ("dfc1 dgrad", 12608, 768, 3072, "dgrad"),
-        ("dqkv dgrad", 12608, 768, 2304, "dgrad"), ("fus ffn1", 7680, 3072, 768, "gelu"), ("fus out", 7680, 768, 768, "resid"),
-        ("text out", 3840, 768, 768, "resid")]
-LARGE = [("fc1 fwd", 18464, 4096, 1024, "gelu"), ("fc2 fwd", 18464, 1024, 4096, "lscale"), ("qkv fwd", 18464, 3072, 1024, "bias"),
-         ("dfc2 dgelu", 18464, 4096, 1024, "dgelu")]
-tot = {0: 0.0, 32: 0.0, 4: 0.0}
+BASE = [("fc2 fwd", 12608, 768, 3072, "lscale"), ("proj fwd", 12608, 768, 768, "lscale"), ("fus out", 7680, 768, 768, "resid"),
+        ("fus ffn2", 7680, 768, 3072, "resid"), ("text out", 3840, 768, 768, "resid"), ("text ffn2", 3840, 768, 3072, "resid"),
+        ("fus dffn1", 7680, 768, 3072, "resid"), ("mlm dec f32", 768, 30528, 768, "f32")]
+LARGE = [("fc2 fwd", 18464, 1024, 4096, "lscale"), ("proj fwd", 18464, 1024, 1024, "lscale")]
+tot = {0: 0.0, 64: 0.0, 4: 0.0}
 for name, M, N, Kd, epi in (LARGE if len(sys.argv) > 1 else BASE):
     fn = case(M, N, Kd, epi)
-    best = {0: 1e9, 32: 1e9, 4: 1e9}
+    best = {0: 1e9, 64: 1e9, 4: 1e9}
     for rep in range(2):
-        for g in (0, 32, 4):
+        for g in (0, 64, 4):
             lib.x2_tune(2, g)
             best[g] = min(best[g], timeit(fn))
     lib.x2_tune(2, 0)
     for g in best:
         tot[g] += best[g]
-    print("%-11s M=%5d N=%5d K=%4d %-6s staged %6.1f us   swap %6.1f us (%+5.1f %%)   main loop only %6.1f us" %
-          (name, M, N, Kd, epi, best[0], best[32], 100.0 * (best[32] / best[0] - 1.0), best[4]), flush=True)
-print("sum: staged %.1f  swap %.1f  main loops %.1f us" % (tot[0], tot[32], tot[4]))
+    print("%-11s M=%5d N=%5d K=%4d %-6s default %6.1f us   row-contiguous %6.1f us (%+5.1f %%)   main loop only %6.1f us" %
+          (name, M, N, Kd, epi, best[0], best[64], 100.0 * (best[64] / best[0] - 1.0), best[4]), flush=True)
+print("sum: default %.1f  row-contiguous %.1f  main loops %.1f us" % (tot[0], tot[64], tot[4]))

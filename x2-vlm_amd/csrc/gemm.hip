@@ -239,101 +239,74 @@ __device__ __forceinline__ void nt_epilogue(const GemmNT& p, f32x4 (&acc)[TM][4]
   }
 }
 
-// ---- the same epilogue WITHOUT the LDS round trip (x2_tune(2, 32); staged for measurement, not selected by default) ----
-// A lane of the C^T accumulator tile (i, j) holds row m = frow and the 4 columns j*16 + fg*4 .. +3.  One
-// v_permlane16_swap per dword between the tiles j = 2*jp and 2*jp + 1 (odd 16-lane rows of the first operand <-> even
-// rows of the second) leaves every lane with 8 CONSECUTIVE columns of one tile: lanes fg = 0, 2 hold columns 0..7 / 8..15
-// of tile 2*jp, lanes fg = 1, 3 those of tile 2*jp + 1.  From there the arithmetic and the 16-byte stores are those of
-// nt_epilogue (same operation order, bitwise the same results); a store instruction covers 16 rows x 64 contiguous bytes
-// (bf16) instead of 8 rows x 128, and neither LDS traffic nor its waits remain.  Feature sets 0-3, 5, 6.
+// ---- staged epilogue for fp32 outputs with ROW-CONTIGUOUS stores (x2_tune(2, 64); staged for measurement) ----
+// nt_epilogue gives a lane 8 consecutive columns of one row; for fp32 outputs that is two 16-byte stores per lane whose
+// pieces interleave at a 32-byte stride: every store instruction half-fills 16 lines (8 rows x 2).  Here a lane takes 4
+// columns of TWO rows (r and r + 4): a store instruction writes 4 rows x 256 contiguous bytes = 8 full lines; the residual
+// is loaded the same way.  The bf16 side output of feature set 6 (value before the layer scale) becomes 8-byte stores
+// (16 lanes x 8 B = one full 128-byte line per row).  Feature sets 1, 5, 6 (the fp32-out ones), same arithmetic.
 template <int TM, int VAR>
-__device__ __forceinline__ void nt_epilogue_swap(const GemmNT& p, f32x4 (&acc)[TM][4], int lane, int mw0, int nw0) {
+__device__ __forceinline__ void nt_epilogue_f4(const GemmNT& p, f32x4 (&acc)[TM][4], char* smem, int wave, int lane, int mw0, int nw0) {
   using E = EpiTraits<VAR>;
-  static_assert(!E::generic && VAR <= 6, "nt_epilogue_swap: feature sets 0-3, 5, 6");
-  constexpr int act = E::act;
+  static_assert(!E::generic && E::out_f32 && E::act == 0 && VAR <= 6, "nt_epilogue_f4: feature sets 1, 5, 6");
   const bool has_drop = E::drop ? p.drop.thr16 != 0 : false;
   const int frow = lane & 15, fg = lane >> 4;
+  float* stg = reinterpret_cast<float*>(smem) + wave * (32 * 68);
+  const int er = lane >> 4, ec = (lane & 15) * 4;          // rows er and er + 4 of every 8-row group, 4 columns
+  const int n = nw0 + ec;
+  const bool nok = n < p.N;                                // N % 8 == 0
+  float bb[4] = {0.f, 0.f, 0.f, 0.f}, gg[4] = {1.f, 1.f, 1.f, 1.f};
+  if (nok && p.bias) { const float4 b0 = *reinterpret_cast<const float4*>(p.bias + n); bb[0] = b0.x; bb[1] = b0.y; bb[2] = b0.z; bb[3] = b0.w; }
+  if (E::scale && nok && p.gamma) { const float4 g0 = *reinterpret_cast<const float4*>(p.gamma + n); gg[0] = g0.x; gg[1] = g0.y; gg[2] = g0.z; gg[3] = g0.w; }
   const DropSpec drop_ = drop_at_epoch(p.drop, p.drop_epoch);
-  int ncol[2]; bool nok[2];
-  float bb[2][8], gg[2][8];
 #pragma unroll
-  for (int jp = 0; jp < 2; ++jp) {
-    ncol[jp] = nw0 + (2 * jp + (fg & 1)) * 16 + (fg >> 1) * 8;
-    nok[jp] = ncol[jp] < p.N;                          // N % 8 == 0
+  for (int half = 0; half < (TM + 1) / 2; ++half) {
+    const bool full = half * 2 + 1 < TM;
+    float4 rs[4][2];
+    const int nc = nok ? n : 0;
+    if (E::resid) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { bb[jp][e] = 0.f; gg[jp][e] = 1.f; }
-    if (nok[jp] && p.bias) {
-      const float4 b0 = *reinterpret_cast<const float4*>(p.bias + ncol[jp]), b1 = *reinterpret_cast<const float4*>(p.bias + ncol[jp] + 4);
-      bb[jp][0] = b0.x; bb[jp][1] = b0.y; bb[jp][2] = b0.z; bb[jp][3] = b0.w; bb[jp][4] = b1.x; bb[jp][5] = b1.y; bb[jp][6] = b1.z; bb[jp][7] = b1.w;
-    }
-    if (E::scale && nok[jp] && p.gamma) {
-      const float4 g0 = *reinterpret_cast<const float4*>(p.gamma + ncol[jp]), g1 = *reinterpret_cast<const float4*>(p.gamma + ncol[jp] + 4);
-      gg[jp][0] = g0.x; gg[jp][1] = g0.y; gg[jp][2] = g0.z; gg[jp][3] = g0.w; gg[jp][4] = g1.x; gg[jp][5] = g1.y; gg[jp][6] = g1.z; gg[jp][7] = g1.w;
-    }
-  }
+      for (int rr = 0; rr < 4; ++rr) {
+        if (!full && rr >= 2) continue;
 #pragma unroll
-  for (int i0 = 0; i0 < TM; i0 += 2) {
-    // residual / saved pre-activation of the (up to) four (row tile, tile pair) groups requested before any arithmetic
-    float4 r0[4], r1[4];
-    u32x4 pre[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int i = i0 + (q >> 1), jp = q & 1;
-      if (i >= TM) continue;
-      const int mc = min(mw0 + i * 16 + frow, p.M - 1), nc = nok[jp] ? ncol[jp] : 0;
-      if (E::resid) {
-        r0[q] = *reinterpret_cast<const float4*>(p.resid + (size_t)mc * p.ldr + nc);
-        r1[q] = *reinterpret_cast<const float4*>(p.resid + (size_t)mc * p.ldr + nc + 4);
+        for (int h = 0; h < 2; ++h) {
+          const int mc = min(mw0 + half * 32 + rr * 8 + h * 4 + er, p.M - 1);
+          rs[rr][h] = *reinterpret_cast<const float4*>(p.resid + (size_t)mc * p.ldr + nc);
+        }
       }
-      if (act == 2) pre[q] = *reinterpret_cast<const u32x4*>(p.aux + (size_t)mc * p.ldaux + nc);
     }
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int i = i0 + (q >> 1), jp = q & 1;
-      if (i >= TM) continue;
-      f32x4 X = acc[i][2 * jp], Y = acc[i][2 * jp + 1];
+    for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {                   // executed by every lane: no divergence before this point of the iteration
-        const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(X[k]), __float_as_uint(Y[k]), false, false);
-        X[k] = __uint_as_float(r[0]); Y[k] = __uint_as_float(r[1]);
-      }
-      const int m = mw0 + i * 16 + frow, n = ncol[jp];
-      if (m >= p.M || !nok[jp]) continue;
-      float v[8] = {X[0] + bb[jp][0], X[1] + bb[jp][1], X[2] + bb[jp][2], X[3] + bb[jp][3],
-                    Y[0] + bb[jp][4], Y[1] + bb[jp][5], Y[2] + bb[jp][6], Y[3] + bb[jp][7]};
-      if (act == 1) {
-        st16(p.aux + (size_t)m * p.ldaux + n, u32x4{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7])}, false);
+      for (int j = 0; j < 4; ++j)
+        if (full || ii == 0) *reinterpret_cast<f32x4*>(stg + (ii * 16 + frow) * 68 + j * 16 + fg * 4) = acc[full ? half * 2 + ii : half * 2][j];
 #pragma unroll
-        for (int r = 0; r < 8; ++r) v[r] = gelu_f(v[r]);
-      } else if (act == 2) {
+    for (int rr = 0; rr < 4; ++rr) {
+      if (!full && rr >= 2) continue;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { v[2 * r] *= dgelu_f(bf_lo(pre[q][r])); v[2 * r + 1] *= dgelu_f(bf_hi(pre[q][r])); }
-      } else if (E::aux0) {
-        st16(p.aux + (size_t)m * p.ldaux + n, u32x4{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7])}, false);
-      }
-      if (has_drop) {
-        float dm[4];
-        drop_mul4(drop_, (uint32_t)m * (uint32_t)p.N + (uint32_t)n, dm);
-        v[0] *= dm[0]; v[1] *= dm[1]; v[2] *= dm[2]; v[3] *= dm[3];
-        drop_mul4(drop_, (uint32_t)m * (uint32_t)p.N + (uint32_t)n + 4u, dm);
-        v[4] *= dm[0]; v[5] *= dm[1]; v[6] *= dm[2]; v[7] *= dm[3];
-      }
-      if (E::scale) {
-        const float rs_ = p.rowscale ? p.rowscale[m] : 1.f;
+      for (int h = 0; h < 2; ++h) {
+        const int row = rr * 8 + h * 4 + er;
+        const int m = mw0 + half * 32 + row;
+        const float4 a0 = *reinterpret_cast<const float4*>(stg + row * 68 + ec);
+        if (m >= p.M || !nok) continue;
+        float v[4] = {a0.x + bb[0], a0.y + bb[1], a0.z + bb[2], a0.w + bb[3]};
+        if (E::aux0) {
+          const u32x2 pk = u32x2{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])};
+          *reinterpret_cast<u32x2*>(p.aux + (size_t)m * p.ldaux + n) = pk;
+        }
+        if (has_drop) {
+          float dm[4];
+          drop_mul4(drop_, (uint32_t)m * (uint32_t)p.N + (uint32_t)n, dm);
+          v[0] *= dm[0]; v[1] *= dm[1]; v[2] *= dm[2]; v[3] *= dm[3];
+        }
+        if (E::scale) {
+          const float rs_ = p.rowscale ? p.rowscale[m] : 1.f;
 #pragma unroll
-        for (int r = 0; r < 8; ++r) v[r] *= gg[jp][r] * rs_;
-      }
-      if (E::resid) {
-        v[0] += r0[q].x; v[1] += r0[q].y; v[2] += r0[q].z; v[3] += r0[q].w;
-        v[4] += r1[q].x; v[5] += r1[q].y; v[6] += r1[q].z; v[7] += r1[q].w;
-      }
-      if (E::out_f32) {
-        float* c = reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n;
-        st16(c, u32x4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])}, false);
-        st16(c + 4, u32x4{__float_as_uint(v[4]), __float_as_uint(v[5]), __float_as_uint(v[6]), __float_as_uint(v[7])}, false);
-      } else {
-        st16(reinterpret_cast<bf16_t*>(p.C) + (size_t)m * p.ldc + n,
-             u32x4{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7])}, false);
+          for (int r = 0; r < 4; ++r) v[r] *= gg[r] * rs_;
+        }
+        if (E::resid) { v[0] += rs[rr][h].x; v[1] += rs[rr][h].y; v[2] += rs[rr][h].z; v[3] += rs[rr][h].w; }
+        st16(reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n,
+             u32x4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])}, false);
       }
     }
   }
@@ -344,8 +317,8 @@ __device__ __forceinline__ void nt_epilogue_swap(const GemmNT& p, f32x4 (&acc)[T
 // row r stored at chunk position c ^ (r & 7)  -> conflict-free ds_read_b128 fragment reads.
 // ---------------------------------------------------------------------------------------------
 // TM: 16-row MFMA tiles per wave along M: 4 -> 128x128 block tile, 6 -> 192x128 (2 x 80 KB LDS = exactly 2 blocks / CU);
-// SW: the epilogue that assembles rows by lane swaps instead of the LDS round trip (nt_epilogue_swap)
-template <int TM, int VAR, bool SW = false>
+// F4: fp32 outputs stored row-contiguously (nt_epilogue_f4; feature sets 1, 5, 6 only)
+template <int TM, int VAR, bool F4 = false>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNT p) {
   constexpr int BMT = 32 * TM;                       // block rows (2 waves along M)
   if constexpr (VAR == 7) {                          // slice blockIdx.y of the contraction -> its own M x N partial in the workspace
@@ -458,11 +431,11 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNT p) {
   if (kt + 1 < nk) { step(kt, std::false_type{}, std::true_type{}); ++kt; }
   step(kt, std::false_type{}, std::false_type{});
 
-  if constexpr (SW) {                                // no LDS in this epilogue: the waves need not meet again
-    nt_epilogue_swap<TM, VAR>(p, acc, lane, m0 + wm * 16 * TM, n0 + wn * 64);
+  __syncthreads();                                   // every wave is done reading the last operand tiles
+  if constexpr (F4) {
+    nt_epilogue_f4<TM, VAR>(p, acc, smem, wave, lane, m0 + wm * 16 * TM, n0 + wn * 64);
     return;
   }
-  __syncthreads();                                   // every wave is done reading the last operand tiles
   if (p.dbg & 4) { if (acc[0][0][0] == 12345.678f) reinterpret_cast<float*>(p.C)[0] = acc[1][1][1] + acc[2][2][2] + acc[3][3][3]; return; }
   nt_epilogue<TM, VAR>(p, acc, smem, wave, lane, m0 + wm * 16 * TM, n0 + wn * 64);
 }
@@ -550,7 +523,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_w8_kernel(GemmNT p) {
 
 // knobs for A/B measurements and for the tests that pin a kernel variant (0 = automatic everywhere); [7] 1: no 160x128 NT tiles
 //   [0] GROUP_M of the NT tile raster            [1] 2: NT on the 8-wave 256x128 kernel
-//   [2] NT ablation bits (4 no epilogue, 16 sc1 stores, 32 lane-swap epilogue)          [6] 1: always the generic (run-time flags) NT epilogue
+//   [2] NT ablation bits (4 no epilogue, 16 sc1 stores, 64 row-contiguous fp32 stores)          [6] 1: always the generic (run-time flags) NT epilogue
 //   [3] NT tile: 1 = 128x128, 2 = 192x128, 3 = 64x128, 4 = 160x128        [4] NT start stagger (x 4 us)
 //   [5] TN: 1 = always 128x128 tiles, 2 = 256x256 tiles whenever the contraction lengths allow
 static int g_tune[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -568,15 +541,15 @@ extern "C" int x2_tune(int key, int value) {
 }
 
 // one NT launch: LDS = two stages of a (32 * TM) x 64 A tile + a 128 x 64 B tile; above 64 KB the limit is raised once
-template <int TM, int V, bool SW>
+template <int TM, int V, bool F4>
 static void launch_nt(const GemmNT& p, int tiles, hipStream_t stream) {
   constexpr int lds = 2 * (32 * TM * 128 + TILE_BYTES);
   static bool raised = false;
   if (lds > 65536 && !raised) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<TM, V, SW>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<TM, V, F4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     raised = true;
   }
-  hipLaunchKernelGGL((gemm_nt_kernel<TM, V, SW>), dim3(tiles), dim3(256), lds, stream, p);
+  hipLaunchKernelGGL((gemm_nt_kernel<TM, V, F4>), dim3(tiles), dim3(256), lds, stream, p);
 }
 
 extern "C" int x2_gemm_nt(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
@@ -633,8 +606,8 @@ extern "C" int x2_gemm_nt(const void* A, const void* B, void* C, int M, int N, i
     else if (act == 0 && !aux && !resid && plain) var = out_f32 ? 1 : 0;
     else if (act == 0 && !aux && resid && out_f32 && !gamma && !rowscale && !colsum) var = 5;
     else if (act == 0 && aux && resid && out_f32 && gamma && !drop_thr16 && !colsum) var = 6;
-    // [2] & 32: the lane-swap epilogue (nt_epilogue_swap) where it exists (every compiled feature set but the generic one)
-    const bool sw = (g_tune[2] & 32) != 0 && var != 4;
+    // [2] & 64: row-contiguous stores for the fp32-out feature sets (nt_epilogue_f4)
+    const bool f4 = (g_tune[2] & 64) != 0 && (var == 1 || var == 5 || var == 6);
 #define X2_NT_LAUNCH(V, SW)                                                                          \
     do {                                                                                              \
       if (use64) launch_nt<2, V, SW>(p, t64, (hipStream_t)stream);                                    \
@@ -642,9 +615,12 @@ extern "C" int x2_gemm_nt(const void* A, const void* B, void* C, int M, int N, i
       else if (use192) launch_nt<6, V, SW>(p, t192, (hipStream_t)stream);                             \
       else launch_nt<4, V, SW>(p, t128, (hipStream_t)stream);                                         \
     } while (0)
-#define X2_NT_CASE(V) case V: if (sw) X2_NT_LAUNCH(V, true); else X2_NT_LAUNCH(V, false); break
+#define X2_NT_CASE(V) case V: if (f4) X2_NT_LAUNCH(V, true); else X2_NT_LAUNCH(V, false); break
     switch (var) {
-      X2_NT_CASE(0); X2_NT_CASE(1); X2_NT_CASE(2); X2_NT_CASE(3); X2_NT_CASE(5); X2_NT_CASE(6);
+      case 0: X2_NT_LAUNCH(0, false); break;
+      case 2: X2_NT_LAUNCH(2, false); break;
+      case 3: X2_NT_LAUNCH(3, false); break;
+      X2_NT_CASE(1); X2_NT_CASE(5); X2_NT_CASE(6);
       default: X2_NT_LAUNCH(4, false); break;
     }
 #undef X2_NT_CASE
