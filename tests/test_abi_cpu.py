@@ -49,6 +49,15 @@ def test_argument_checks_fail_loudly_without_launching():
     assert rc == -1 and b"x2_layernorm_fwd" in h.x2_last_error()
     rc = h.x2_sample_negatives(None, 5000, None, None, None, None)
     assert rc == -1
+    one = ctypes.c_void_p(16)                 # any non-null address: the checks below return before anything is dereferenced
+    rc = h.x2_gemm_nt_splitk(one, one, one, 128, 128, 100, 104, 104, 128, 0, None, 0, None)
+    assert rc == -1 and b"x2_gemm_nt_splitk" in h.x2_last_error()
+    rc = h.x2_mlm_ce_fwd(one, one, None, one, 8, 1000, 1000, 128, 128, 128, one, one, None)      # vocabulary rows not padded to 64
+    assert rc == -1 and b"x2_mlm_ce_fwd" in h.x2_last_error()
+    rc = h.x2_mlm_ce_bwd(one, one, None, one, one, one, one, 1.0, 8, 1024, 1000, 128, 128, 128, one, 1000, None)   # ldd < Vp
+    assert rc == -1 and b"x2_mlm_ce_bwd" in h.x2_last_error()
+    rc = h.x2_ce_combine(None, 16, None, None, 8, None, None, None, None)
+    assert rc == -1 and b"x2_ce_combine" in h.x2_last_error()
 
 
 def test_communicator_entry_points_check_arguments_and_find_rccl():
