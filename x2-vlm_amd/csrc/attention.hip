@@ -619,6 +619,212 @@ __global__ __launch_bounds__(64 * QW, 32 / QW) void attn_bwd_dq_grouped_kernel(A
   }
 }
 
+// ------------------------------------------------------------------------------------------ strip-walking resident forms
+// STAGED, NOT YET MEASURED (X2_ATTN_VARIANT bits 4096 forward / 8192 dQ; nothing selects them by default).
+// The resident kernels above launch ceil(Lq / 128) workgroups per (sequence, head) and each loads ALL of K and V: at
+// N = 197 that is two workgroups, K / V read twice (126 MB moved per forward launch for 77 MB of operands) and three rounds
+// of 64 KB workgroups.  Here ONE four-wave workgroup per (sequence, head) keeps K / V as sixteen-row strips - WALK_ROWS =
+// 208 rows each, 52 KB, so three workgroups share a CU and all 768 (image, head) pairs of the base step are resident at
+// once - and every wave walks the 16-query strips wave, wave + 4, ... in sequence (the loop of the grouped kernels, plus
+// the relative-position bias and the dS stream).  LDS image: the operand that is read TRANSPOSED (V in the forward, K in
+// dQ) comes first and the other one behind it, so that the transposing fragment reads of a partial last key tile (rows up
+// to 16 past the 208) land on real rows of the other operand: finite values that meet P = 0 / dS = 0.
+#define WALK_ROWS 208
+#define WALK_BYTES (WALK_ROWS * 128)
+template <int NT>
+__device__ __forceinline__ void tile_store_bounded(const TileRegs<NT>& t, char* region, int row0, int tid) {
+#pragma unroll
+  for (int i = 0; i < (512 + NT - 1) / NT; ++i) {
+    const int c = tid + i * NT;
+    if (c < 512) {
+      const int r = row0 + (c >> 3), ch = c & 7;
+      if (r < WALK_ROWS) *reinterpret_cast<u32x4*>(region + r * 128 + ((ch ^ (r & 7)) << 4)) = t.v[i];
+    }
+  }
+}
+template <int NT>
+__device__ __forceinline__ void walk_load_kv(const AttnArgs& a, const bf16_t* Kp, const bf16_t* Vp, char* kreg, char* vreg, int nkt, int tid) {
+  TileRegs<NT> rka[4], rva[4];
+#pragma unroll
+  for (int kt = 0; kt < 4; ++kt)
+    if (kt < nkt) { tile_load<NT>(rka[kt], Kp, a.k_rs, kt * KT, a.Lk, tid); tile_load<NT>(rva[kt], Vp, a.v_rs, kt * KT, a.Lk, tid); }
+#pragma unroll
+  for (int kt = 0; kt < 4; ++kt)
+    if (kt < nkt) { tile_store_bounded<NT>(rva[kt], vreg, kt * KT, tid); tile_store_bounded<NT>(rka[kt], kreg, kt * KT, tid); }
+}
+
+template <int QW>
+__global__ __launch_bounds__(64 * QW, 3) void attn_fwd_walk_kernel(AttnArgs a) {
+  const DropSpec drop_ = drop_at_epoch(a.drop, a.drop_epoch);
+  constexpr int NT = 64 * QW;
+  __shared__ __attribute__((aligned(16))) char smem[2 * WALK_BYTES];        // V rows | K rows
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fi = lane & 15, g = lane >> 4;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const float sc2 = a.scale * LOG2E;
+  const int lkp = (a.Lk + 63) & ~63;
+  const int nkt = (a.Lk + KT - 1) / KT;
+  walk_load_kv<NT>(a, a.K + b * a.k_bs + h * HD, a.V + b * a.v_bs + h * HD, smem + WALK_BYTES, smem, nkt, tid);
+  __syncthreads();
+  const uint32_t vbase = lds_addr(smem), kbase = vbase + WALK_BYTES;      // transposed reads (V) may run 16 rows over: into K rows
+  for (int base = wave * 16; base < a.Lq; base += QW * 16) {              // no barrier below: waves run on their own
+    const bool qok = base + fi < a.Lq;
+    const int q1[1] = {min(base + fi, a.Lq - 1)};
+    const int q = q1[0];
+    bf16x8 qf[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+      qf[ks] = *reinterpret_cast<const bf16x8*>(a.Q + b * a.q_bs + (long)q * a.q_rs + h * HD + ks * 32 + g * 8);
+    f32x4 o[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m_i = NEG_BIG, l_i = 0.f;
+    for (int kt = 0; kt < nkt; ++kt) {
+      const uint32_t ktile = kbase + kt * KT * 128, vtile = vbase + kt * KT * 128;
+      const int nsub = min(4, (a.Lk - kt * KT + 15) >> 4);
+      float4 bbv[1][4], mmv[4];
+      load_bias_mask<1>(a, h, b, q1, kt * KT, g, nsub, bbv, mmv);
+      f32x4 st[4];
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) st[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          if (nt >= nsub) continue;
+          st[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(ktile, nt * 16 + fi, ks * 4 + g), qf[ks], st[nt], 0, 0, 0);
+        }
+      float mx = NEG_BIG;
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        if (nt >= nsub) continue;
+        st[nt] = apply_bias_mask(st[nt], bbv[0][nt], mmv[nt], kt * KT + nt * 16 + g * 4, a.Lk, sc2);
+        mx = fmaxf(fmaxf(mx, fmaxf(st[nt][0], st[nt][1])), fmaxf(st[nt][2], st[nt][3]));
+      }
+      mx = group_max(mx);
+      const float m_new = fmaxf(m_i, mx), alpha = exp2f(m_i - m_new);
+      float rs = 0.f;
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        if (nt >= nsub) continue;               // skipped sub-tiles keep P = 0
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { st[nt][r] = exp2f(st[nt][r] - m_new); rs += st[nt][r]; }
+      }
+      l_i = l_i * alpha + group_sum(rs);
+      m_i = m_new;
+      if (drop_.thr16) {
+        const uint32_t e0 = (uint32_t)(((long)b * a.H + h) * a.Lq + q) * (uint32_t)lkp + (uint32_t)(kt * KT + g * 4);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+          if (nt >= nsub) continue;
+          float dm[4];
+          drop_mul4(drop_, e0 + nt * 16, dm);
+          st[nt][0] *= dm[0]; st[nt][1] *= dm[1]; st[nt][2] *= dm[2]; st[nt][3] *= dm[3];
+        }
+      }
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) o[dt] *= alpha;
+      const bf16x8 pf[2] = {pack8(st[0], st[1]), pack8(st[2], st[3])};
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          if (2 * s2 >= nsub) continue;
+          o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_cols(vtile, s2, dt, lane), pf[s2], o[dt], 0, 0, 0);
+        }
+    }
+    if (qok) {
+      const float inv = 1.0f / l_i;
+      bf16_t* op = a.Out + b * a.o_bs + (long)q * a.o_rs + h * HD + g * 4;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+        *reinterpret_cast<u32x2*>(op + dt * 16) = u32x2{pack_bf16(o[dt][0] * inv, o[dt][1] * inv), pack_bf16(o[dt][2] * inv, o[dt][3] * inv)};
+      if (g == 0) a.LSE[((long)b * a.H + h) * a.Lq + q] = m_i + log2f(l_i);   // log2 domain
+    }
+  }
+}
+
+template <int QW>
+__global__ __launch_bounds__(64 * QW, 3) void attn_bwd_dq_walk_kernel(AttnArgs a) {
+  const DropSpec drop_ = drop_at_epoch(a.drop, a.drop_epoch);
+  constexpr int NT = 64 * QW;
+  __shared__ __attribute__((aligned(16))) char smem[2 * WALK_BYTES];        // K rows | V rows (here the transposed reads are K's)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fi = lane & 15, g = lane >> 4;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const float sc2 = a.scale * LOG2E;
+  const int lkp = (a.Lk + 63) & ~63;
+  const int nkt = (a.Lk + KT - 1) / KT;
+  walk_load_kv<NT>(a, a.K + b * a.k_bs + h * HD, a.V + b * a.v_bs + h * HD, smem, smem + WALK_BYTES, nkt, tid);
+  __syncthreads();
+  const uint32_t kbase = lds_addr(smem), vbase = kbase + WALK_BYTES;
+  for (int base = wave * 16; base < a.Lq; base += QW * 16) {
+    const bool qok = base + fi < a.Lq;
+    const int q1[1] = {min(base + fi, a.Lq - 1)};
+    const int q = q1[0];
+    bf16x8 qf[2], dof[2];
+    float dl = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      qf[ks] = *reinterpret_cast<const bf16x8*>(a.Q + b * a.q_bs + (long)q * a.q_rs + h * HD + ks * 32 + g * 8);
+      dof[ks] = *reinterpret_cast<const bf16x8*>(a.dO + b * a.do_bs + (long)q * a.do_rs + h * HD + ks * 32 + g * 8);
+      const bf16x8 of = *reinterpret_cast<const bf16x8*>(a.O + b * a.o_bs + (long)q * a.o_rs + h * HD + ks * 32 + g * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) dl += bf2f((bf16_t)dof[ks][e]) * bf2f((bf16_t)of[e]);
+    }
+    const float delta = group_sum(dl);
+    const float lse = a.LSE[((long)b * a.H + h) * a.Lq + q];
+    if (qok && g == 0) a.Delta[((long)b * a.H + h) * a.Lq + q] = delta;
+    f32x4 dq[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int kt = 0; kt < nkt; ++kt) {
+      const uint32_t ktile = kbase + kt * KT * 128, vtile = vbase + kt * KT * 128;
+      const int nsub = min(4, (a.Lk - kt * KT + 15) >> 4);
+      float4 bbv[1][4], mmv[4];
+      load_bias_mask<1>(a, h, b, q1, kt * KT, g, nsub, bbv, mmv);
+      f32x4 ds[4];
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        if (nt >= nsub) { ds[nt] = f32x4{0.f, 0.f, 0.f, 0.f}; continue; }
+        f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(ktile, nt * 16 + fi, ks * 4 + g), qf[ks], s, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(vtile, nt * 16 + fi, ks * 4 + g), dof[ks], dp, 0, 0, 0);
+        }
+        const int key0 = kt * KT + nt * 16 + g * 4;
+        s = apply_bias_mask(s, bbv[0][nt], mmv[nt], key0, a.Lk, sc2);
+        if (drop_.thr16) {
+          float dm[4];
+          drop_mul4(drop_, (uint32_t)(((long)b * a.H + h) * a.Lq + q) * (uint32_t)lkp + (uint32_t)key0, dm);
+          dp[0] *= dm[0]; dp[1] *= dm[1]; dp[2] *= dm[2]; dp[3] *= dm[3];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ds[nt][r] = exp2f(s[r] - lse) * (dp[r] - delta);
+        if (a.dS && qok && key0 < a.ds_ld)
+          *reinterpret_cast<u32x2*>(a.dS + (((long)b * a.H + h) * a.Lq + q) * a.ds_ld + key0) =
+              u32x2{pack_bf16(ds[nt][0], ds[nt][1]), pack_bf16(ds[nt][2], ds[nt][3])};
+      }
+      const bf16x8 dsf[2] = {pack8(ds[0], ds[1]), pack8(ds[2], ds[3])};
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          if (2 * s2 >= nsub) continue;
+          dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_cols(ktile, s2, dt, lane), dsf[s2], dq[dt], 0, 0, 0);
+        }
+    }
+    if (qok) {
+      bf16_t* op = a.dQ + b * a.dq_bs + (long)q * a.dq_rs + h * HD + g * 4;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+        *reinterpret_cast<u32x2*>(op + dt * 16) = u32x2{pack_bf16(dq[dt][0] * a.scale, dq[dt][1] * a.scale),
+                                                         pack_bf16(dq[dt][2] * a.scale, dq[dt][3] * a.scale)};
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------ backward: dK, dV
 // KW waves, KG groups of 16 keys per wave; the workgroup walks every (sequence using this K/V batch, 64-query tile).
 template <int KW, int KG, bool RES, int NS = (RES ? 4 : 2)>
@@ -802,7 +1008,8 @@ __global__ __launch_bounds__(64 * KW, (KW == 4 && !RES) ? 3 : 4) void attn_bwd_d
 // bit 1: dq with 2 query groups per wave, bit 2: fwd with 2 query groups per wave,
 // bit 3: grouped (shared K/V) forward kernel for cross-attention; bit 4: per-row dQ kernel instead of the grouped one.  Measured on the
 // fusion shapes (256 rows on 64 images): 62 vs 68 us forward, 132 vs 147 us backward in isolation, but -3 % on the whole
-// step (64 KB workgroups co-reside worse with the other streams' kernels), so off by default
+// step (64 KB workgroups co-reside worse with the other streams' kernels), so off by default;
+// bit 12 (4096) / bit 13 (8192): strip-walking resident forward / dQ kernels (staged, unmeasured: see their header)
 static int attn_variant() {
   static int v = -1;
   if (v < 0) { const char* e = getenv("X2_ATTN_VARIANT"); v = e ? atoi(e) : 0; }
@@ -839,6 +1046,8 @@ extern "C" int x2_attn_fwd(const AttnArgs* pa, void* stream) {
     hipLaunchKernelGGL((attn_fwd_kernel<8, 1, false>), dim3((a.Lq + 127) / 128, a.H, a.B), dim3(512), 0, st, a);
   else if (a.Lq <= 64 || a.Lk > 256) hipLaunchKernelGGL((attn_fwd_kernel<4, 1, false>), dim3((a.Lq + 63) / 64, a.H, a.B), dim3(256), 0, st, a);
   else if (attn_variant() & 4) hipLaunchKernelGGL((attn_fwd_kernel<4, 2, true>), dim3((a.Lq + 127) / 128, a.H, a.B), dim3(256), 0, st, a);
+  else if ((attn_variant() & 4096) && !a.kv_idx && a.Lk <= WALK_ROWS)      // staged: one strip-walking workgroup per (sequence, head)
+    hipLaunchKernelGGL((attn_fwd_walk_kernel<4>), dim3(1, a.H, a.B), dim3(256), 0, st, a);
   else hipLaunchKernelGGL((attn_fwd_kernel<8, 1, true>), dim3((a.Lq + 127) / 128, a.H, a.B), dim3(512), 0, st, a);
   return x2_check_launch("x2_attn_fwd");
 }
@@ -864,6 +1073,8 @@ extern "C" int x2_attn_bwd(const AttnArgs* pa, void* stream) {
     hipLaunchKernelGGL((attn_bwd_dq_kernel<8, 1, false>), dim3((a.Lq + 127) / 128, a.H, a.B), dim3(512), 0, st, a);
   else if (a.Lq <= 64 || a.Lk > 256) hipLaunchKernelGGL((attn_bwd_dq_kernel<4, 1, false>), dim3((a.Lq + 63) / 64, a.H, a.B), dim3(256), 0, st, a);
   else if (attn_variant() & 2) hipLaunchKernelGGL((attn_bwd_dq_kernel<4, 2, true>), dim3((a.Lq + 127) / 128, a.H, a.B), dim3(256), 0, st, a);
+  else if ((attn_variant() & 8192) && !a.kv_idx && a.Lk <= WALK_ROWS)
+    hipLaunchKernelGGL((attn_bwd_dq_walk_kernel<4>), dim3(1, a.H, a.B), dim3(256), 0, st, a);
   else hipLaunchKernelGGL((attn_bwd_dq_kernel<8, 1, true>), dim3((a.Lq + 127) / 128, a.H, a.B), dim3(512), 0, st, a);
   if (int e = x2_check_launch("x2_attn_bwd(dq)")) return e;
   const bool res = !a.seq_off && a.Lq > 64 && a.Lq <= 256;   // one sequence per K/V batch, 2..4 query tiles: resident Q/dO
