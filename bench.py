@@ -119,6 +119,9 @@ def main():
     ap.add_argument("--with-optimizer", action="store_true",
                     help="also run clip + fused AdamW inside every step (the headline metric is fwd+bwd only)")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying the captured hipGraph")
+    ap.add_argument("--graph", choices=["segments", "whole"], default=os.environ.get("X2_BENCH_GRAPH", "segments"),
+                    help="segments (default, any N): linear hipGraph segments joined by events, collectives between them "
+                         "(graph.SegmentedStep); whole (N = 1 only): the step as one multi-stream hipGraph (graph.GraphedStep)")
     ap.add_argument("--serialize", action="store_true",
                     help="profiling aid: one HIP stream only (no concurrent text tower / weight-gradient stream), so that "
                          "per-kernel durations are not inflated by co-running kernels")
@@ -239,26 +242,34 @@ def main():
     graph = importlib.import_module("x2-vlm_amd.graph")
     if os.environ.get("X2_HACK_NT_ABLATE"):           # timing experiment only (garbage outputs): NT GEMM ablation bits, gemm.hip
         importlib.import_module("x2-vlm_amd._lib").lib().x2_tune(2, int(os.environ["X2_HACK_NT_ABLATE"]))
-    use_graph = not args.no_graph and world == 1
-    if use_graph and os.environ.get("X2_GRAPH_CANARY", "1") == "1" and not args.tiny:
-        # Multi-stream capture leans on ROCm behaviour found by probing (graph.py): a runtime that breaks it tends to crash
+    use_graph = not args.no_graph and (world == 1 or args.graph == "segments")
+    if use_graph and os.environ.get("X2_GRAPH_CANARY", "1") == "1" and not args.tiny and world == 1:
+        # Stream capture leans on ROCm behaviour found by probing (graph.py): a runtime that breaks it tends to crash
         # inside hipStreamEndCapture, which cannot be caught in-process.  A 2-layer copy of this step is captured in a child
-        # process first (~10 s); if that does not come back with launch_mode == "hipgraph" the benchmark launches eagerly.
+        # process first (~10 s); if that does not come back with a hipgraph launch mode the benchmark launches eagerly.
         import subprocess
         try:
             r = subprocess.run([sys.executable, os.path.abspath(__file__), "--tiny", "--config", args.config, "--batch", "4", "--steps", "1",
-                                "--warmup", "1", "--no-cpu-baseline"], capture_output=True, text=True, timeout=240,
+                                "--warmup", "1", "--no-cpu-baseline", "--graph", args.graph], capture_output=True, text=True, timeout=240,
                                env=dict(os.environ, X2_GRAPH_CANARY="0"))
-            use_graph = r.returncode == 0 and '"launch_mode": "hipgraph"' in r.stdout
+            use_graph = r.returncode == 0 and '"launch_mode": "hipgraph' in r.stdout
         except Exception:      # noqa: BLE001
             use_graph = False
         if not use_graph and rank == 0:
             print("bench: hipGraph canary failed, launching eagerly", file=sys.stderr, flush=True)
-    # N > 1: eager launches.  The bucketed all-reduce waits on events of the weight-gradient and text-tower streams, i.e.
-    # side stream -> side stream edges, which ROCm 7's stream capture does not survive (probes/graph_capture_probe.py);
-    # issuing every collective on the capture's origin stream instead would serialise ~1 GB of all-reduce with the
-    # critical path.  Eager multi-GPU steps keep the overlap (and are host-bound at ~30 ms, as in round 1).
-    runner = graph.GraphedStep(fwd_bwd, warmup=1, enabled=use_graph, verbose=(rank == 0))
+    if args.graph == "segments" and not args.serialize:
+        # Linear hipGraph segments (towers | features | tail + its backward | tower backwards) on two streams, the ITC
+        # all-gather and the gradient all-reduces issued eagerly between / behind them: the same launch path for N = 1 and
+        # N > 1, ~1 ms of host time per step.  Without capture (use_graph False) the same segments run eagerly.
+        if ddp is not None:
+            ddp.close()
+            ddp = None
+        runner = graph.SegmentedStep(model, batch, world=world, rank=rank, warmup=1, enabled=use_graph, verbose=(rank == 0))
+    else:
+        # N = 1: the whole step as ONE multi-stream hipGraph (fork / join edges: ~15 us of host time per node).
+        # N > 1 on this path: eager launches with bucketed all-reduces overlapped on a side stream (accelerator.GradientBuckets).
+        fwd_bwd.parameters = lambda: params
+        runner = graph.GraphedStep(fwd_bwd, warmup=1, enabled=use_graph and world == 1, verbose=(rank == 0))
 
     def step():
         loss = runner()

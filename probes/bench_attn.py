@@ -38,6 +38,17 @@ def case(B, H, Lq, Lk, bias, mask):
                    K.view3(dqkv, B, Lq, 0), K.view3(dkv, B, Lk, HD), K.view3(dkv, B, Lk, 2 * HD), dS=dS, **kw)
     return fwd, bwd
 
+LIB = importlib.import_module("x2-vlm_amd._lib").lib()
+# in-process A/B of the strip-walking resident kernels at N = 197 (x2_tune(8, bits): attention.hip attn_variant())
+fwd, bwd = case(64, 12, 197, 197, True, False)
+for rnd in range(3):
+    row = []
+    for bits in (0, 4096, 8192, 4096 | 8192):
+        LIB.x2_tune(8, bits)
+        row.append("v%-5d fwd %6.1f bwd %6.1f" % (bits, timeit(fwd), timeit(bwd)))
+    print("vision N=197 round %d: " % rnd + "   ".join(row))
+LIB.x2_tune(8, -1)
+
 for name, B, H, Lq, Lk, bias, mask in [("vision large", 32, 16, 577, 577, True, False), ("vision", 64, 12, 197, 197, True, False), ("text self", 128, 12, 30, 30, False, True),
                                        ("fusion self", 256, 12, 30, 30, False, True)]:
     fwd, bwd = case(B, H, Lq, Lk, bias, mask)

@@ -119,6 +119,42 @@ def _bucket_case(rank, world):
     return out
 
 
+def _hooked_case(rank, world):
+    """A gradient hook makes autograd store hook(view) instead of adopting the arena view: the early-reduced arena no
+    longer is .grad, and finish() must notice and send that parameter with the leftovers."""
+    acc = importlib.import_module("x2-vlm_amd.accelerator")
+    torch.manual_seed(0)
+    l0, head = torch.nn.Linear(4, 4), torch.nn.Linear(4, 2)
+    model = torch.nn.Sequential(l0, head)
+    a = acc.RocmDDPAccelerator(dict(RNG_SEED=1), None)
+    a.world_size = world
+    a.buckets = gb = acc.GradientBuckets(model, world)
+    l0.weight.register_hook(lambda g: g * 1.0)                 # returns a NEW tensor
+    g = torch.Generator().manual_seed(70 + rank)
+    x = torch.randn(5, 4, generator=g)
+    h = _ArenaLinear.apply(x, l0.weight, l0.bias, ("t", 0))
+    a.backward_step(head(torch.tanh(h)).square().sum(), None)
+    out = dict(g=[p.grad.clone() for p in model.parameters()], demoted=gb.demoted, x=x,
+               p=[p.detach().clone() for p in model.parameters()])
+    gb.close()
+    return out
+
+
+def test_early_reduced_arena_that_autograd_did_not_adopt_is_demoted():
+    out = _run("_hooked_case")
+    P = out[0]["p"]
+
+    def local(x):
+        w0, b0, wh, bh = [t.clone().requires_grad_(True) for t in P]
+        (torch.tanh(x @ w0.t() + b0) @ wh.t() + bh).square().sum().backward()
+        return [t.grad for t in (w0, b0, wh, bh)]
+    want = [sum(gs) / len(out) for gs in zip(*[local(o["x"]) for o in out])]
+    for o in out:
+        assert o["demoted"] == 1
+        for got, w in zip(o["g"], want):
+            assert torch.allclose(got, w, atol=1e-5)
+
+
 def _local_grads(params0, x, shared_l1=False):
     """Plain-autograd gradients of the same little network on one rank's input."""
     w0, b0, w1, b1, wh, bh = [t.clone().requires_grad_(True) for t in params0]

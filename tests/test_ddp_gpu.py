@@ -151,6 +151,70 @@ def test_two_ranks_match_oracle_ddp_semantics(case, synthetic):
         assert torch.allclose(out[0]["g2"][n], out[1]["g2"][n], rtol=1e-5, atol=1e-7), n
 
 
+def _two_rank_segmented_worker(rank, world, port, case, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), X2_DIST_BACKEND="gloo")
+    synthetic = importlib.import_module("x2-vlm_amd.synthetic")
+    mp_ = importlib.import_module("x2-vlm_amd.model_pretrain")
+    acc = importlib.import_module("x2-vlm_amd.accelerator")
+    c = CASES[case]
+    model = mp_.XVLM(config=model_config(case, tempfile.mkdtemp()), load_vision_params=False, load_text_params=False, pretraining=True)
+    synthetic.synth_state_dict(model, c["wseed"])
+    model.eval()
+    a = acc.RocmDDPAccelerator(dict(RNG_SEED=7), None)
+    ddp, _, _ = a.set_up(model, None, None, local_rank=0, world_size=world, rank=rank)
+    try:
+        out = {}
+        b1, n1 = _rank_batch(synthetic, c, rank)
+        b2, n2 = _rank_batch(synthetic, c, rank, shift=1000)
+        static = {k: v.cuda() for k, v in b1.items()}
+        neg = [torch.tensor(n, dtype=torch.int32, device="cuda") for n in n1]
+        model.injected_negatives = tuple(neg)
+        step = a.segmented_step(ddp, static, clamp_temp=False)
+        out["mode"], out["error"] = step.mode, step.error
+        loss = step()
+        torch.cuda.synchronize()
+        out["loss1"] = {k: float(v) for k, v in loss.items()}
+        out["g1"] = {n: p.grad.detach().cpu() for n, p in model.named_parameters() if p.grad is not None}
+        out["messages"] = step.messages
+        # a second iteration on new data through the SAME graphs: static inputs are overwritten, gradients are rewritten
+        step.copy_inputs(static, {k: v.cuda() for k, v in b2.items()})
+        for t, n in zip(neg, n2):
+            t.copy_(torch.tensor(n, dtype=torch.int32))
+        for p in model.parameters():
+            p.grad = None                                    # what optimizer.zero_grad(set_to_none=True) does between iterations
+        step()
+        torch.cuda.synchronize()
+        out["g2"] = {n: p.grad.detach().cpu() for n, p in model.named_parameters() if p.grad is not None}
+        ret[rank] = out
+    finally:
+        a.buckets.close()
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case", ["tiny", "base_shallow"])
+def test_two_ranks_replayed_segments_match_oracle_ddp_semantics(case, synthetic):
+    """The N > 1 step as REPLAYED hipGraph segments (graph.SegmentedStep through RocmDDPAccelerator.segmented_step): ITC
+    all-gather between two segments, per-segment gradient all-reduces behind them.  Same oracle, same tolerances as the
+    eager two-rank test above; two successive iterations through the same graphs."""
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_two_rank_segmented_worker, args=(world, _free_port(), case, ret), nprocs=world, join=True)
+    out = [ret[r] for r in range(world)]
+    c = CASES[case]
+    g_a, loss_a = _oracle_ddp(synthetic, c, world, 0)
+    g_b, _ = _oracle_ddp(synthetic, c, world, 1000)
+    for r in range(world):
+        assert out[r]["mode"] == "hipgraph-segments", out[r]["error"]
+        for k, v in loss_a[r].items():
+            assert abs(out[r]["loss1"][k] - v) <= 5e-3 * max(abs(v), 1e-6), (r, k, out[r]["loss1"][k], v)
+        assert out[r]["messages"] >= 2 + 3                  # two feature gathers + at least one message per gradient segment
+        _compare(out[r]["g1"], g_a, "rank %d, first replay" % r)
+        _compare(out[r]["g2"], g_b, "rank %d, second replay (new data)" % r)
+    for n in out[0]["g2"]:                                  # replicas end up with the same gradients
+        assert torch.allclose(out[0]["g2"][n], out[1]["g2"][n], rtol=1e-5, atol=1e-7), n
+
+
 def _rccl_worker(rank, world, port, ret, comm_mode):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), X2_DDP_SINGLE_RANK_COLLECTIVES="1", X2_COMM=comm_mode)
     os.environ.pop("X2_DIST_BACKEND", None)
@@ -182,6 +246,7 @@ def _rccl_worker(rank, world, port, ret, comm_mode):
         norm = a.optimizer_step(opt, ddp, 1.0)
         opt.step()
         torch.cuda.synchronize()
+        moved = float((model.vision_proj.weight.detach() - before).abs().max()) > 0.0
         # the same step without any process group in the way
         for p in model.parameters():
             p.grad = None
@@ -193,7 +258,7 @@ def _rccl_worker(rank, world, port, ret, comm_mode):
         worst = max(float((grads[k] - p.grad).abs().max()) / (float(p.grad.abs().max()) + 1e-12)
                     for k, p in model.named_parameters() if p.grad is not None)
         ret[0] = dict(msgs=msgs, norm=norm, gather_ok=bool(torch.equal(y.detach(), t.detach()) and torch.equal(t.grad, torch.ones_like(t))),
-                      moved=float((model.vision_proj.weight.detach() - before).abs().max()) >= 0.0, worst=worst,
+                      moved=moved, worst=worst,
                       losses={k: float(v) for k, v in loss.items()})
     finally:
         dist.destroy_process_group()
@@ -206,7 +271,7 @@ def test_single_rank_rccl_through_the_accelerator(comm_mode):
     ret = mgr.dict()
     mp.spawn(_rccl_worker, args=(1, _free_port(), ret, comm_mode), nprocs=1, join=True)
     r = ret[0]
-    assert r["msgs"] >= 3 and r["gather_ok"]
+    assert r["msgs"] >= 3 and r["gather_ok"] and r["moved"]      # the optimizer step changed the weights
     assert np.isfinite(r["norm"]) and r["norm"] > 0
     assert all(np.isfinite(v) for v in r["losses"].values())
     assert r["worst"] <= 1e-6, r["worst"]                   # AVG over one rank is the identity

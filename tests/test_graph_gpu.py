@@ -101,3 +101,64 @@ def test_replays_draw_new_dropout_masks(synthetic):
         seen.append(tuple(round(float(v), 6) for v in loss.values()))
     assert all(all(x == x and abs(x) < 1e4 for x in s) for s in seen)   # finite
     assert len(set(seen)) == 4, seen                                    # same inputs, four different masks
+
+
+def test_segmented_replay_is_the_eager_step(synthetic):
+    """graph.SegmentedStep (linear hipGraph segments on two streams, autograd cut at the tower outputs, tied word-embedding
+    gradient in one buffer) against the plain eager model(...) + backward at five successive (weights, batch) states."""
+    graph = importlib.import_module("x2-vlm_amd.graph")
+    model, c = _build(synthetic, train=False)
+    data = _batches(synthetic, c, 5)
+    static = {k: v.clone() for k, v in data[0].items()}
+    params = list(model.parameters())
+    names = [n for n, _ in model.named_parameters()]
+
+    def fwd_bwd():
+        for p in params:
+            p.grad = None
+        loss = model(static["image"], static["text_ids"], static["text_atts"], text_ids_masked=static["text_ids_masked"],
+                     masked_pos=static["masked_pos"], masked_ids=static["masked_ids"])
+        sum(loss.values()).backward()
+        return loss
+
+    step = graph.SegmentedStep(model, static, clamp_temp=False)
+    assert step.mode == "hipgraph-segments", step.error
+    assert sorted(step.graphs) == ["F1", "F2", "T", "Tb", "V", "Vb"]
+    captured = [p.grad for p in params]                      # static tensors the segments write on every replay
+    seen = []
+    for i, b in enumerate(data):
+        graph.SegmentedStep.copy_inputs(static, b)
+        le = {k: float(v) for k, v in fwd_bwd().items()}     # eager launches (re-binds .grad to fresh tensors)
+        torch.cuda.synchronize()
+        eager = [None if p.grad is None else p.grad.detach().clone() for p in params]
+        lg = {k: float(v) for k, v in step().items()}        # the same state through the segments (re-attaches .grad)
+        torch.cuda.synchronize()
+        for k in le:
+            assert abs(le[k] - lg[k]) <= 1e-6 * max(1.0, abs(le[k])), (i, k, le[k], lg[k])
+        total = sum(float(g.double().pow(2).sum()) for g in eager if g is not None) ** 0.5
+        for n, p, ge, gg in zip(names, params, eager, captured):
+            assert (ge is None) == (gg is None), n
+            assert p.grad is gg, n
+            if ge is not None and "key.bias" not in n:      # key biases: analytically zero gradient, pure rounding noise
+                err = float((ge.double() - gg.double()).norm()) / max(float(ge.double().norm()), 1e-2 * total)
+                assert err <= 5e-3, (i, n, err)
+        seen.append(le)
+        with torch.no_grad():
+            for p, g in zip(params, eager):
+                if g is not None:
+                    p.data.add_(g, alpha=-0.02)
+    assert seen[0] != seen[-1]
+
+
+def test_segmented_replays_draw_new_dropout_masks(synthetic):
+    graph = importlib.import_module("x2-vlm_amd.graph")
+    model, c = _build(synthetic, train=True)
+    b = _batches(synthetic, c, 1)[0]
+    step = graph.SegmentedStep(model, b)
+    assert step.mode == "hipgraph-segments", step.error
+    seen = []
+    for _ in range(4):
+        loss = step()
+        seen.append(tuple(round(float(v), 6) for v in loss.values()))
+    assert all(all(x == x and abs(x) < 1e4 for x in s) for s in seen)   # finite
+    assert len(set(seen)) == 4, seen                                    # same inputs, four different masks

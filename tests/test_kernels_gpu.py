@@ -335,27 +335,37 @@ def test_attention_text_self_mask(K):
     run_attention(K, B=2, Bkv=2, H=4, Lq=40, Lk=40, use_bias=False, use_mask=True, kv_map=None, seed=220)
 
 
-@pytest.fixture(params=["0", "8", "16"], ids=["default", "grouped_fwd", "per_row_dq"])
-def cross_variant(request):
-    """X2_ATTN_VARIANT (read once per process by the library): default = per-row forward + grouped dQ; bit 3 = grouped
-    forward as well; bit 4 = per-row dQ.  Non-default variants run in a child interpreter."""
-    return request.param
+def _attn_variant(K, bits):
+    """x2_tune(8, bits): attention kernel selection bits (csrc/attention.hip attn_variant()), switched inside the process."""
+    import importlib
+    importlib.import_module("x2-vlm_amd._lib").lib().x2_tune(8, bits)
 
 
-def test_attention_cross_shared_kv(K, cross_variant):
-    if cross_variant != os.environ.get("X2_ATTN_VARIANT", "0"):
-        import subprocess, sys
-        env = dict(os.environ, X2_ATTN_VARIANT=cross_variant)
-        r = subprocess.run([sys.executable, "-m", "pytest", __file__, "-q", "-x", "-m", "gpu", "-k",
-                            "cross_shared_kv and " + {"0": "default", "8": "grouped_fwd", "16": "per_row_dq"}[cross_variant]],
-                           env=env, capture_output=True, text=True, timeout=600)
-        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-        return
-    run_attention(K, B=6, Bkv=3, H=12, Lq=30, Lk=197, use_bias=False, use_mask=True, kv_map=[0, 2, 1, 1, 0, 1], seed=300)
-    run_attention(K, B=4, Bkv=2, H=2, Lq=8, Lk=5, use_bias=False, use_mask=False, kv_map=[1, 0, 1, 1], seed=310)
-    # an image nobody attends to (zero gradient, nothing to do), and more rows per image than one 128-query pass holds
-    run_attention(K, B=4, Bkv=3, H=2, Lq=30, Lk=197, use_bias=False, use_mask=True, kv_map=[0, 2, 2, 0], seed=320)
-    run_attention(K, B=11, Bkv=2, H=3, Lq=30, Lk=70, use_bias=False, use_mask=True, kv_map=[0] * 9 + [1] * 2, seed=330)
+@pytest.mark.parametrize("bits", [4096, 8192, 4096 | 8192], ids=["walk_fwd", "walk_dq", "walk_both"])
+def test_attention_vision_bias_strip_walking_variants(K, bits):
+    """The strip-walking resident forward / dQ kernels (one workgroup per (image, head), K / V loaded once) against the same
+    oracle as the default kernels: N = 197 with the relative-position bias, and a short ragged case (one partial key tile)."""
+    _attn_variant(K, bits)
+    try:
+        run_attention(K, B=3, Bkv=3, H=12, Lq=197, Lk=197, use_bias=True, use_mask=False, kv_map=None, seed=100)
+        run_attention(K, B=2, Bkv=2, H=3, Lq=70, Lk=70, use_bias=True, use_mask=True, kv_map=None, seed=110)
+        run_attention(K, B=2, Bkv=2, H=2, Lq=208, Lk=208, use_bias=True, use_mask=False, kv_map=None, seed=120)
+    finally:
+        _attn_variant(K, -1)
+
+
+@pytest.mark.parametrize("bits", [0, 8, 16], ids=["default", "grouped_fwd", "per_row_dq"])
+def test_attention_cross_shared_kv(K, bits):
+    """default = per-row forward + grouped dQ; bit 3 = grouped forward as well; bit 4 = per-row dQ."""
+    _attn_variant(K, bits)
+    try:
+        run_attention(K, B=6, Bkv=3, H=12, Lq=30, Lk=197, use_bias=False, use_mask=True, kv_map=[0, 2, 1, 1, 0, 1], seed=300)
+        run_attention(K, B=4, Bkv=2, H=2, Lq=8, Lk=5, use_bias=False, use_mask=False, kv_map=[1, 0, 1, 1], seed=310)
+        # an image nobody attends to (zero gradient, nothing to do), and more rows per image than one 128-query pass holds
+        run_attention(K, B=4, Bkv=3, H=2, Lq=30, Lk=197, use_bias=False, use_mask=True, kv_map=[0, 2, 2, 0], seed=320)
+        run_attention(K, B=11, Bkv=2, H=3, Lq=30, Lk=70, use_bias=False, use_mask=True, kv_map=[0] * 9 + [1] * 2, seed=330)
+    finally:
+        _attn_variant(K, -1)
 
 
 def test_attention_long_keys(K):

@@ -45,6 +45,7 @@ class GradientBuckets:
         self.pending = []          # arenas in flight on the side stream (kept alive until finish)
         self.params = [p for p in model.parameters() if p.requires_grad]
         self.messages = 0          # collectives issued (tests / diagnostics)
+        self.demoted = 0           # early-reduced parameters whose .grad turned out not to live in the reduced arena
         engine.GRAD_READY_HOOK = self._on_arena
         engine.STAGE_CALLS.clear()
 
@@ -73,10 +74,26 @@ class GradientBuckets:
             with torch.cuda.stream(self.side):
                 self._all_reduce(flat)
         self.done.update(id(p) for p in params)
-        self.pending.append(flat)
+        self.pending.append((flat, list(params)))
 
     def finish(self):
         """Call after backward: reduce the leftovers, then make the compute stream wait for the side stream."""
+        # An arena was reduced early on the assumption that autograd adopts its views as .grad.  If it did not (a hook, a
+        # second contribution from outside the stage, create_graph, a layout mismatch made AccumulateGrad clone or add),
+        # .grad holds a LOCAL gradient somewhere else: those parameters go out with the leftovers instead.
+        for flat, params in self.pending:
+            lo, hi = flat.data_ptr(), flat.data_ptr() + flat.numel() * flat.element_size()
+            for p in params:
+                g = p.grad
+                if g is not None and not (lo <= g.data_ptr() and g.data_ptr() + g.numel() * g.element_size() <= hi):
+                    if self.side is not None:
+                        # the copy / accumulate that produced this .grad ran on the compute stream while the side stream
+                        # was all-reducing its source in place: its content cannot be trusted
+                        raise RuntimeError("GradientBuckets: the gradient of a %s parameter was reduced early in its layer arena, but "
+                                           "autograd did not adopt the arena view as .grad (gradient hook? create_graph?); "
+                                           "remove the hook or run with engine.GRAD_READY_HOOK = None" % (tuple(p.shape),))
+                    self.done.discard(id(p))
+                    self.demoted += 1
         rest = [p for p in self.params if p.grad is not None and id(p) not in self.done]
         if rest:
             grads = [p.grad for p in rest]
@@ -187,6 +204,16 @@ class RocmDDPAccelerator(Accelerator):
         loss.backward()
         if self.buckets is not None:
             self.buckets.finish()
+
+    def segmented_step(self, model, static_batch, **kw):
+        """The image-text iteration (Pretrain.run_image_iter between zero_grad and optimizer.step) as replayed hipGraph
+        segments with this accelerator's collectives between them: graph.SegmentedStep bound to this rank / world size /
+        communicator.  Replaces model(...) + backward_step(loss) for that iteration; gradients come back averaged."""
+        from .graph import SegmentedStep
+        module = getattr(model, "module", model)
+        rank = dist.get_rank() if dist.is_initialized() else 0
+        comm = self.buckets.comm if self.buckets is not None else None
+        return SegmentedStep(module, static_batch, world=getattr(self, "world_size", 1), rank=rank, comm=comm, **kw)
 
     def optimizer_step(self, optimizer, model, grad_norm):
         """Clip to `grad_norm`, return the total norm as a float (one host sync, like the reference's float(...)).

@@ -1010,8 +1010,11 @@ __global__ __launch_bounds__(64 * KW, (KW == 4 && !RES) ? 3 : 4) void attn_bwd_d
 // fusion shapes (256 rows on 64 images): 62 vs 68 us forward, 132 vs 147 us backward in isolation, but -3 % on the whole
 // step (64 KB workgroups co-reside worse with the other streams' kernels), so off by default;
 // bit 12 (4096) / bit 13 (8192): strip-walking resident forward / dQ kernels (staged, unmeasured: see their header)
+// x2_tune(8, v) (gemm.hip) overrides the environment at run time: tests and probes A/B variants inside one process
+int x2_attn_variant_override = -1;
 static int attn_variant() {
   static int v = -1;
+  if (x2_attn_variant_override >= 0) return x2_attn_variant_override;
   if (v < 0) { const char* e = getenv("X2_ATTN_VARIANT"); v = e ? atoi(e) : 0; }
   return v;
 }

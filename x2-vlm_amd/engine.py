@@ -182,6 +182,15 @@ BANK = WeightBank()
 SPLIT_DECODER_DGRAD = os.environ.get("X2_SPLIT_DECODER_DGRAD", "1") == "1"     # A/B switches (probes/run_ab3.sh)
 FUSED_MLM_CE = os.environ.get("X2_FUSED_MLM_CE", "1") == "1"
 KEEP_MLM_LOGITS = False     # tests: also materialise the MLM logits (inspection only; the loss still comes from the fused path)
+# Tied decoder / word-embedding gradient in ONE buffer (graph.SegmentedStep switches it on for its passes): the MLM head's
+# backward parks its [V, Hd] weight gradient here instead of handing it to autograd, and the embedding backward - which
+# always runs later in the same backward sweep, the embeddings being upstream of everything - scatter-adds its rows on top
+# and returns the sum as THE gradient of the shared parameter.  Saves a 94 MB zero-fill and the 3 x 94 MB accumulate of
+# the second contribution, and - the reason it exists - keeps the parameter's gradient on the stream of the text tower, so
+# the hipGraph segment of the tail needs no edge into that stream.  Only valid when the embedding lookup of the same
+# parameter is part of the same autograd graph, which the caller guarantees.
+TIE_WORD_GRAD = False
+_TIED_DWORD = {}
 
 
 class Grads:
@@ -744,7 +753,10 @@ class EmbeddingsFn(torch.autograd.Function):
         small = torch.zeros(2 * lnw.numel(), device=dy.device, dtype=F32)
         dw, db = small[:lnw.numel()], small[lnw.numel():]
         de, _ = K.layernorm_bwd(dy.contiguous().view(e.shape), e, mean, rstd, lnw, dw, db, drop_in=ctx.drop)
-        dword, dpos, dtyp = torch.zeros_like(word), torch.zeros_like(pos), torch.zeros_like(typ)
+        dpos, dtyp = torch.zeros_like(pos), torch.zeros_like(typ)
+        dword = _TIED_DWORD.pop(_tok(word), None)          # the tied decoder's gradient, if the MLM head left it (TIE_WORD_GRAD)
+        if dword is None:
+            dword = torch.zeros_like(word)
         K.embed_bwd(ids, de, dword, dpos, dtyp)
         return None, None, None, dword, dpos, dtyp, dw, db
 
@@ -821,6 +833,9 @@ class MlmLossFn(torch.autograd.Function):
         drows = K.gemm_nt(dpre_b, wdT, out_dtype=F32)
         ddw = torch.empty_like(dw_)
         K.gemm_tn_grouped([(dl, tb, dword, Vp, Hd), (dpre_b, rb, ddw)])
+        if TIE_WORD_GRAD:
+            _TIED_DWORD[_tok(word)] = dword
+            dword = None
         return drows, None, None, None, ddw, dbd, dlnw, dlnb, dbias[:V], dword
 
 

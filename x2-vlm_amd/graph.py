@@ -36,7 +36,10 @@ from . import kernels as K
 
 class GraphedStep:
     def __init__(self, fn, warmup=2, enabled=True, verbose=False):
+        """fn: the step (forward + backward).  If it carries an attribute `parameters` (callable -> iterable of
+        Parameters), their captured .grad tensors are re-attached after every replay."""
         self.fn, self.graph, self.out = fn, None, None
+        self._grads = []
         self.stream = torch.cuda.Stream()
         self.mode = "eager"
         self.error = None
@@ -55,6 +58,8 @@ class GraphedStep:
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
         trace = os.environ.get("X2_GRAPH_TRACE") == "1"
+        engine.BANK.invalidate()              # the bf16 weight casts must be part of the captured step, whatever warm-up left cached
+        self._grads = []
         try:
             if trace:
                 print("GraphedStep: warm-up done, capturing", flush=True)
@@ -66,7 +71,12 @@ class GraphedStep:
             if trace:
                 print("GraphedStep: graph instantiated", flush=True)
             self.graph, self.mode = g, "hipgraph"
+            # the graph writes gradients into the tensors that were .grad when capture ended: remember them, so that a
+            # training loop that calls optimizer.zero_grad(set_to_none=True) between replays gets them back (__call__)
+            params = getattr(fn, "parameters", None)
+            self._grads = [(p_, p_.grad) for p_ in (params() if callable(params) else ()) if p_.grad is not None]
         except Exception as e:                # noqa: BLE001 - anything that cannot be captured: run eagerly instead
+            K.DROP_EPOCH = None               # eager launches draw their seeds on the host again
             self.error = "%s: %s" % (type(e).__name__, str(e).splitlines()[0] if str(e) else "")
             if verbose:
                 print("GraphedStep: capture failed, running eagerly (%s)" % self.error, flush=True)
@@ -80,6 +90,9 @@ class GraphedStep:
         with torch.cuda.stream(self.stream):
             if self.graph is not None:
                 self.graph.replay()
+                for p_, g_ in self._grads:
+                    if p_.grad is not g_:
+                        p_.grad = g_
             else:
                 if K.DROP_EPOCH is not None:
                     K.DROP_EPOCH.add_(1)
@@ -92,3 +105,330 @@ class GraphedStep:
         """New data into the tensors the step was captured on (one multi-tensor copy)."""
         keys = [k for k in static_batch if k in batch]
         torch._foreach_copy_([static_batch[k] for k in keys], [batch[k] for k in keys])
+
+
+class SegmentedStep:
+    """The X^2-VLM pre-training step as a handful of LINEAR hipGraph segments joined by events outside capture.
+
+    Why: ROCm replays a captured graph that contains fork / join edges node by node (~15 us each: 21 ms of host time per
+    base step, 65 ms per large step - `GraphedStep` above), while a single-stream capture replays in well under a
+    millisecond.  And a graph that spans the whole step leaves no place to issue a collective, so multi-GPU steps had to
+    be launched eagerly (host-bound).  Here every segment is captured on ONE stream; what ran on different streams inside
+    one graph now runs as different graphs on different streams:
+
+        stream A (vision / tail)                           stream B (text)                       stream C (collectives)
+        ----------------------------------------------------------------------------------------------------------------
+        [V   vision tower forward]                         [T  text tower forward, 2B rows]
+        [F1  temp clamp, ITC features]      <- event ----
+         eager: all-gather of the (B, 256) features (rank > 1: RCCL; one rank: a copy)
+        [F2  ITC / hard negatives / 4B-row fusion pass / ITM / MLM, backward down to the tower outputs]
+                                             -- event ->                                         all-reduce(tail gradients)
+        [Vb  vision tower backward]                        [Tb text tower backward]
+                                                            -- event ->                          all-reduce(text gradients)
+         -- event ------------------------------------------------------------------------->     all-reduce(vision gradients)
+        join B, C
+
+    Autograd is cut at the tower outputs (detached leaves): F2 leaves the gradients of the tower outputs in the leaves'
+    .grad, Vb / Tb feed them to the towers' own graphs.  The ITC all-gather sits between F1 and F2 as an eager call; its
+    backward (the local slice of the gathered gradient, xvlm.AllGather) is part of F2.  The tied word-embedding / decoder
+    gradient stays on stream B (engine.TIE_WORD_GRAD), and every parameter's AccumulateGrad node is pinned to the stream of
+    the segment that produces its gradient, so no segment contains an edge into another stream.
+
+    Gradient averaging (world > 1) follows apex's delay_allreduce order at segment granularity: each segment's gradients -
+    whole per-layer arenas in place, large single tensors in place, the small remainder packed into one static buffer - are
+    reduced on stream C as soon as the segment that completes them has been launched.  p.grad of every parameter is a
+    static tensor after capture: do not set gradients to None between replays (`reattach_grads` restores them if the
+    training loop did).
+
+    model: model_pretrain.XVLM.  batch: dict of static device tensors (image, text_ids, text_atts, text_ids_masked,
+    masked_pos, masked_ids [, image_atts, idx_to_group_img, target_bbox, is_image]); new data goes in with
+    GraphedStep.copy_inputs.  Falls back to eager execution of the same segments when capture is disabled or fails."""
+
+    def __init__(self, model, batch, world=1, rank=0, process_group=None, comm=None, warmup=2, enabled=True, verbose=False,
+                 ret_bbox_loss=False, ret_match_loss=True, recast_weights=True, clamp_temp=True, total_loss=None):
+        from . import engine
+        self.engine = engine
+        self.model, self.batch, self.world, self.rank, self.pg, self.comm = model, batch, world, rank, process_group, comm
+        self.ret_bbox_loss, self.ret_match_loss = ret_bbox_loss, ret_match_loss
+        self.recast_weights, self.clamp_temp = recast_weights, clamp_temp
+        self.total_loss = total_loss or (lambda losses: sum(losses.values()))
+        self.sA, self.sB = torch.cuda.Stream(), torch.cuda.Stream()
+        self.sC = torch.cuda.Stream() if world > 1 else None
+        self.t, self.graphs = {}, {}
+        self.mode, self.error = "eager", None
+        self.messages = 0                       # collectives issued per step (tests / diagnostics)
+        self.params = [p for p in model.parameters() if p.requires_grad]
+        self._plan = None                       # per segment: tensors all-reduced in place + (static flat, views, sources)
+        self._arenas = []                       # (segment, flat, params) published while capturing
+        self._touch = {}                        # id(param) -> segment that last wrote its gradient
+        self._pin_accumulators()
+        dev = batch["text_ids"].device
+        B = batch["text_ids"].shape[0]
+        E = model.embed_dim
+        self.t["fi_all"] = torch.zeros(world * B, E, device=dev, requires_grad=True)
+        self.t["ft_all"] = torch.zeros(world * B, E, device=dev, requires_grad=True)
+        if K.DROP_EPOCH is None:
+            K.DROP_EPOCH = torch.zeros(1, dtype=torch.int32, device=dev)
+        cur = torch.cuda.current_stream()
+        self.sA.wait_stream(cur)
+        side, tie, hook = engine.SIDE.enabled, engine.TIE_WORD_GRAD, engine.GRAD_READY_HOOK
+        engine.GRAD_READY_HOOK = None             # an accelerator's early all-reduce hook must not fire from these passes
+        try:
+            for _ in range(max(warmup, 1)):       # eager, on the segments' own streams: caches, workspaces, allocator pools
+                self._run("eager")
+            torch.cuda.synchronize()
+            if enabled and os.environ.get("X2_GRAPH", "1") != "0":
+                self._capture(verbose)
+        finally:
+            engine.SIDE.enabled, engine.TIE_WORD_GRAD, engine.GRAD_READY_HOOK = side, tie, hook
+        cur.wait_stream(self.sA)
+
+    # ------------------------------------------------------------------ set-up
+    def _pin_accumulators(self):
+        """Create (and keep) every parameter's AccumulateGrad node under the stream of the segment that will produce its
+        gradient: autograd accumulates on the node's stream, and a node created lazily on another stream would pull that
+        stream into the segment's capture (a fork / join edge: the slow replay path)."""
+        text = self.model._bert
+        on_b = set(id(p) for p in text.embeddings.parameters())
+        for i in range(text.config.fusion_layer):
+            on_b.update(id(p) for p in text.encoder.layer[i].parameters())
+        self._acc = []
+        for stream, sel in ((self.sB, True), (self.sA, False)):
+            with torch.cuda.stream(stream):
+                for p in self.params:
+                    if (id(p) in on_b) == sel:
+                        self._acc.append(p.view_as(p).grad_fn.next_functions[0][0])
+
+    def _seg(self, mode, name, stream, fn, pool):
+        with torch.cuda.stream(stream):
+            if mode == "replay":
+                self.graphs[name].replay()
+            elif mode == "capture":
+                g = torch.cuda.CUDAGraph()
+                before = self._grad_ids()
+                self._cur_seg = name
+                with torch.cuda.graph(g, pool=pool, stream=stream):
+                    fn()
+                self.graphs[name] = g
+                after = self._grad_ids()
+                for p in self.params:
+                    if after[id(p)] != before[id(p)]:
+                        self._touch[id(p)] = name
+            else:
+                fn()
+
+    def _grad_ids(self):
+        return {id(p): None if p.grad is None else (p.grad.data_ptr(), p.grad._version) for p in self.params}
+
+    # ------------------------------------------------------------------ the segments
+    def _s_text(self):
+        b = self.batch
+        self.t["both"] = self.model.tower_text(b["text_ids"], b["text_atts"], b["text_ids_masked"])
+
+    def _s_vision(self):
+        b = self.batch
+        self.t["vis"] = self.model.tower_vision(b["image"], b.get("image_atts"), b.get("idx_to_group_img"), self.ret_bbox_loss)
+
+    def _s_feat(self):
+        m = self.model
+        if self.clamp_temp and isinstance(m.temp, torch.nn.Parameter):
+            with torch.no_grad():
+                m.temp.clamp_(0.001, 0.5)                 # Pretrain.py:327-328
+        ie, _, full = self.t["vis"]
+        self.t["ie"] = ie.detach().requires_grad_()
+        self.t["full"] = None if full is None else full.detach().requires_grad_()
+        self.t["both_leaf"] = self.t["both"].detach().requires_grad_()
+        self.t["feat"] = m.tail_features(self.t["ie"], self.t["both_leaf"])
+
+    def _gather(self):
+        """ITC features of all ranks into the static leaves (eager, between two segments; xvlm.py:140-160)."""
+        fi, ft = self.t["feat"]
+        for src, dst in ((fi, self.t["fi_all"]), (ft, self.t["ft_all"])):
+            out = dst.detach()
+            if self.world == 1:
+                out.copy_(src.detach())
+            elif self.comm is not None:
+                self.comm.allgather(src.detach().contiguous(), out)
+                self.messages += 1
+            else:
+                import torch.distributed as dist
+                dist.all_gather(list(out.chunk(self.world)), src.detach().contiguous(), group=self.pg)
+                self.messages += 1
+
+    def _s_loss(self):
+        m, b, t = self.model, self.batch, self.t
+        for leaf in (t["fi_all"], t["ft_all"], t["ie"], t["both_leaf"], t["full"]):
+            if leaf is not None:
+                leaf.grad = None
+        fi, ft = t["feat"]
+        loss = m.tail_losses(t["ie"], t["vis"][1], t["both_leaf"], fi, ft, b["text_atts"], b["masked_pos"], b["masked_ids"],
+                             image_embeds_fullatts=t["full"], target_bbox=b.get("target_bbox"), is_image=b.get("is_image"),
+                             ret_bbox_loss=self.ret_bbox_loss, ret_match_loss=self.ret_match_loss,
+                             gathered=(t["fi_all"], t["ft_all"]))
+        self.total_loss(loss).backward()
+        # backward of the all-gather: the local rows of the gathered features' gradient (xvlm.py:156-160), on through the
+        # projection heads into the tower-output leaves
+        B = fi.shape[0]
+        sl = slice(self.rank * B, (self.rank + 1) * B)
+        torch.autograd.backward([fi, ft], [t["fi_all"].grad[sl], t["ft_all"].grad[sl]])
+        t["loss"] = {k: v.detach() for k, v in loss.items()}
+
+    def _s_vision_bwd(self):
+        ie_out, _, full_out = self.t["vis"]
+        outs, grads = [ie_out], [self.t["ie"].grad]
+        if full_out is not None and self.t["full"].grad is not None:
+            outs.append(full_out); grads.append(self.t["full"].grad)
+        torch.autograd.backward(outs, grads)
+
+    def _s_text_bwd(self):
+        torch.autograd.backward([self.t["both"]], [self.t["both_leaf"].grad])
+
+    # ------------------------------------------------------------------ one step
+    def _run(self, mode):
+        eng, A, Bs = self.engine, self.sA, self.sB
+        pa = pb = None
+        if mode == "capture":
+            pa, pb = self._pools
+        if mode != "replay":
+            eng.SIDE.enabled = False          # linear segments: weight-gradient GEMMs in line (the other tower fills the CUs)
+            eng.TIE_WORD_GRAD = True
+            if self.recast_weights:
+                eng.BANK.invalidate()         # as after an optimizer step: fp32 master weights are re-cast inside the step
+            for p in self.params:
+                p.grad = None
+        with torch.cuda.stream(A):
+            K.DROP_EPOCH.add_(1)
+        Bs.wait_stream(A)
+        self._seg(mode, "T", Bs, self._s_text, pb)
+        self._seg(mode, "V", A, self._s_vision, pa)
+        A.wait_stream(Bs)
+        self._seg(mode, "F1", A, self._s_feat, pa)
+        with torch.cuda.stream(A):
+            self._gather()
+        self._seg(mode, "F2", A, self._s_loss, pa)
+        Bs.wait_stream(A)
+        self._reduce("F2", A)
+        self._seg(mode, "Vb", A, self._s_vision_bwd, pa)
+        self._seg(mode, "Tb", Bs, self._s_text_bwd, pb)
+        self._reduce("Tb", Bs)
+        self._reduce("Vb", A)
+        A.wait_stream(Bs)
+        if self.sC is not None:
+            A.wait_stream(self.sC)
+
+    def _capture(self, verbose):
+        eng = self.engine
+        self._pools = (torch.cuda.graph_pool_handle(), torch.cuda.graph_pool_handle())
+        eng.GRAD_READY_HOOK = lambda flat, key, also_after=None, params=(): self._arenas.append((self._cur_seg, flat, list(params)))
+        gc.collect()
+        try:
+            self._run("capture")
+            self._grads = [(p, p.grad) for p in self.params if p.grad is not None]
+            self._make_plan()
+            self.mode = "hipgraph-segments"
+        except Exception as e:                # noqa: BLE001 - anything that cannot be captured: run the segments eagerly
+            self.error = "%s: %s" % (type(e).__name__, str(e).splitlines()[0] if str(e) else "")
+            self.graphs = {}
+            if verbose:
+                print("SegmentedStep: capture failed, running eagerly (%s)" % self.error, flush=True)
+            torch.cuda.synchronize()
+        finally:
+            eng.GRAD_READY_HOOK = None
+
+    # ------------------------------------------------------------------ gradient averaging (world > 1)
+    def _make_plan(self):
+        """Per segment: [tensors to all-reduce in place], (flat, views, sources) for the packed remainder."""
+        self._plan = {}
+        if self.world == 1:
+            return
+        inside = lambda g, flat: flat.data_ptr() <= g.data_ptr() and g.data_ptr() + g.numel() * 4 <= flat.data_ptr() + flat.numel() * 4
+        done = set()
+        for seg in ("F2", "Tb", "Vb"):
+            whole = []
+            for s, flat, params in self._arenas:
+                # an arena goes as one message when every gradient it was published for still lives in it (autograd adopted
+                # the views) and this segment is the last to write any of them
+                if params and all(id(p) not in done and p.grad is not None and inside(p.grad, flat) and self._touch.get(id(p)) == seg
+                                  for p in params):
+                    whole.append(flat)
+                    done.update(id(p) for p in params)
+            rest = [p for p in self.params if p.grad is not None and id(p) not in done and self._touch.get(id(p)) == seg]
+            done.update(id(p) for p in rest)
+            big = [p.grad for p in rest if p.grad.numel() >= (1 << 20) and p.grad.is_contiguous()]
+            small = [p for p in rest if not (p.grad.numel() >= (1 << 20) and p.grad.is_contiguous())]
+            packed = None
+            if small:
+                sizes = [p.grad.numel() for p in small]
+                flat = torch.empty(sum(sizes), device=small[0].grad.device, dtype=small[0].grad.dtype)
+                views = [v.view_as(p.grad) for v, p in zip(flat.split(sizes), small)]
+                packed = (flat, views, [p.grad for p in small])
+                for p, v in zip(small, views):
+                    p.grad = v                    # from now on the optimizer reads the averaged copy
+            self._plan[seg] = (whole + big, packed)
+        self._grads = [(p, p.grad) for p in self.params if p.grad is not None]
+        missing = [p for p in self.params if p.grad is not None and id(p) not in done]
+        assert not missing, "SegmentedStep: %d gradients were assigned to no segment" % len(missing)
+
+    def _all_reduce(self, flat):
+        self.messages += 1
+        if self.comm is not None:
+            self.comm.allreduce_bucket(flat, average=True)
+            return
+        import torch.distributed as dist
+        nccl = dist.get_backend(self.pg) == "nccl"
+        dist.all_reduce(flat, op=dist.ReduceOp.AVG if nccl else dist.ReduceOp.SUM, group=self.pg)
+        if not nccl:
+            flat.div_(self.world)
+
+    def _reduce(self, seg, stream):
+        if self.world == 1 or self._plan is None:        # one rank; or still warming up / capturing
+            return
+        inplace, packed = self._plan.get(seg, ((), None))
+        self.sC.wait_stream(stream)
+        with torch.cuda.stream(self.sC):
+            for flat in inplace:
+                self._all_reduce(flat)
+            if packed is not None:
+                flat, views, srcs = packed
+                torch._foreach_copy_(views, srcs)
+                self._all_reduce(flat)
+
+    def _reduce_eager_fallback(self):
+        """No graphs (capture disabled or failed): one flat message for everything, after the last segment."""
+        grads = [p.grad for p in self.params if p.grad is not None]
+        sizes = [g.numel() for g in grads]
+        flat = torch.empty(sum(sizes), device=grads[0].device, dtype=grads[0].dtype)
+        views = [v.view_as(g) for v, g in zip(flat.split(sizes), grads)]
+        torch._foreach_copy_(views, grads)
+        self._all_reduce(flat)
+        for p, v in zip([p for p in self.params if p.grad is not None], views):
+            p.grad = v
+
+    def reattach_grads(self):
+        """p.grad back to the static tensors the segments write (after an optimizer.zero_grad(set_to_none=True))."""
+        for p, g in self._grads:
+            if p.grad is not g:
+                p.grad = g
+
+    def __call__(self):
+        cur = torch.cuda.current_stream()
+        self.sA.wait_stream(cur)
+        self.messages = 0
+        if self.graphs:
+            self.reattach_grads()
+            self._run("replay")
+        else:
+            eng = self.engine
+            side, tie, hook = eng.SIDE.enabled, eng.TIE_WORD_GRAD, eng.GRAD_READY_HOOK
+            eng.GRAD_READY_HOOK = None
+            try:
+                self._run("eager")
+                if self.world > 1:
+                    with torch.cuda.stream(self.sA):
+                        self._reduce_eager_fallback()
+            finally:
+                eng.SIDE.enabled, eng.TIE_WORD_GRAD, eng.GRAD_READY_HOOK = side, tie, hook
+        cur.wait_stream(self.sA)
+        return self.t["loss"]
+
+    copy_inputs = staticmethod(GraphedStep.copy_inputs)

@@ -20,38 +20,32 @@ class XVLM(XVLMBase):
         self.overlap_towers = True
         self._text_stream = None
 
-    def forward_multimodal(self, image, text_ids, text_atts, text_ids_masked=None, masked_pos=None, masked_ids=None,
-                           image_atts=None, idx_to_group_img=None, target_bbox=None, is_image=None,
-                           ret_bbox_loss=False, ret_match_loss=True):
-        B, L = text_ids.shape
-        dev = text_ids.device
-        # text layers on [clean ; masked] ids in one batch, on a second HIP stream: the text tower (15 % of the FLOPs,
-        # small GEMMs) is independent of the vision tower until the features meet, so their kernels interleave on the
-        # GPU (autograd replays each stage's backward on the stream its forward ran on)
-        ids2, atts2 = torch.cat([text_ids, text_ids_masked]), torch.cat([text_atts, text_atts])
-        overlap = self.overlap_towers and image.is_cuda
-        if overlap:
-            if self._text_stream is None:
-                self._text_stream = torch.cuda.Stream()
-            main = torch.cuda.current_stream()
-            self._text_stream.wait_stream(main)
-            with torch.cuda.stream(self._text_stream):
-                both = self.get_text_embeds(ids2, atts2)
-        if ret_bbox_loss:
-            image_embeds, image_atts, image_embeds_fullatts = \
-                self.get_vision_embeds(image, image_atts=image_atts, idx_to_group_img=idx_to_group_img)
-        else:
-            image_embeds, image_atts = self.get_vision_embeds(image)
-        if overlap:
-            main.wait_stream(self._text_stream)
-            both.record_stream(main)
-            ids2.record_stream(self._text_stream); atts2.record_stream(self._text_stream)
-        else:
-            both = self.get_text_embeds(ids2, atts2)
-        text_embeds = both[:B]
-        image_feat, text_feat = self.get_features(image_embeds, text_embeds)
-        loss_itc = self.get_contrastive_loss(image_feat, text_feat)
+    # ---- the multimodal step in four pieces (towers | features | losses), so that a caller can place them on streams /
+    # hipGraph segments of its own (graph.SegmentedStep) and cut autograd at the tower outputs; forward_multimodal below
+    # composes them for everybody else.
+    def tower_text(self, text_ids, text_atts, text_ids_masked):
+        """Text layers on [clean ; masked] ids as ONE 2B-row batch -> (2B, L, Hd)."""
+        return self.get_text_embeds(torch.cat([text_ids, text_ids_masked]), torch.cat([text_atts, text_atts]))
 
+    def tower_vision(self, image, image_atts=None, idx_to_group_img=None, ret_bbox_loss=False):
+        """-> (image_embeds, image_atts, image_embeds_fullatts or None)."""
+        if ret_bbox_loss:
+            return self.get_vision_embeds(image, image_atts=image_atts, idx_to_group_img=idx_to_group_img)
+        return self.get_vision_embeds(image) + (None,)
+
+    def tail_features(self, image_embeds, both):
+        """-> (image_feat, text_feat), the (B, 256) ITC features of this rank (clean text rows = both[:B])."""
+        return self.get_features(image_embeds, both[:image_embeds.shape[0]])
+
+    def tail_losses(self, image_embeds, image_atts, both, image_feat, text_feat, text_atts, masked_pos, masked_ids,
+                    image_embeds_fullatts=None, target_bbox=None, is_image=None, ret_bbox_loss=False, ret_match_loss=True,
+                    gathered=None):
+        """ITC + hard negatives + the 4B-row fusion pass + ITM + MLM (+ bbox).  gathered: (image_feat_all, text_feat_all)
+        when the caller has already exchanged the features between ranks (None: get_contrastive_loss all-gathers)."""
+        B = image_embeds.shape[0]
+        dev = both.device
+        text_embeds = both[:B]
+        loss_itc = self.get_contrastive_loss(image_feat, text_feat, gathered=gathered)
         ar = torch.arange(B, device=dev, dtype=torch.int32)
         if ret_match_loss:
             ineg, tneg = self.get_hard_negatives(image_feat, text_feat)
@@ -77,6 +71,31 @@ class XVLM(XVLMBase):
             self.last["bbox_coord"] = output_coord.detach()
             loss["loss_bbox"], loss["loss_giou"] = self.get_bbox_loss(output_coord, target_bbox, is_image=is_image)
         return loss
+
+    def forward_multimodal(self, image, text_ids, text_atts, text_ids_masked=None, masked_pos=None, masked_ids=None,
+                           image_atts=None, idx_to_group_img=None, target_bbox=None, is_image=None,
+                           ret_bbox_loss=False, ret_match_loss=True):
+        # text layers on [clean ; masked] ids in one batch, on a second HIP stream: the text tower (15 % of the FLOPs,
+        # small GEMMs) is independent of the vision tower until the features meet, so their kernels interleave on the
+        # GPU (autograd replays each stage's backward on the stream its forward ran on)
+        overlap = self.overlap_towers and image.is_cuda
+        if overlap:
+            if self._text_stream is None:
+                self._text_stream = torch.cuda.Stream()
+            main = torch.cuda.current_stream()
+            self._text_stream.wait_stream(main)
+            with torch.cuda.stream(self._text_stream):
+                both = self.tower_text(text_ids, text_atts, text_ids_masked)
+        image_embeds, image_atts, image_embeds_fullatts = self.tower_vision(image, image_atts, idx_to_group_img, ret_bbox_loss)
+        if overlap:
+            main.wait_stream(self._text_stream)
+            both.record_stream(main)
+        else:
+            both = self.tower_text(text_ids, text_atts, text_ids_masked)
+        image_feat, text_feat = self.tail_features(image_embeds, both)
+        return self.tail_losses(image_embeds, image_atts, both, image_feat, text_feat, text_atts, masked_pos, masked_ids,
+                                image_embeds_fullatts=image_embeds_fullatts, target_bbox=target_bbox, is_image=is_image,
+                                ret_bbox_loss=ret_bbox_loss, ret_match_loss=ret_match_loss)
 
     def forward_text(self, text_ids=None, text_atts=None, text_ids_masked=None, masked_pos=None, masked_ids=None):
         return {"loss_mlm": self.get_mlm_loss(text_ids_masked, text_atts, None, None, masked_pos, masked_ids)}

@@ -220,10 +220,11 @@ class XVLMBase(nn.Module):
         """a @ b^T / temp (fp32)."""
         return ops.linear(a, b) / self.temp
 
-    def get_contrastive_loss(self, image_feat, text_feat, idx=None):
-        """xvlm.py:794-826."""
+    def get_contrastive_loss(self, image_feat, text_feat, idx=None, gathered=None):
+        """xvlm.py:794-826.  gathered: (image_feat_all, text_feat_all) already exchanged between the ranks by the caller
+        (graph.SegmentedStep issues the all-gather between two hipGraph segments); None: all-gather here."""
         assert image_feat.size(-1) == self.embed_dim and text_feat.size(-1) == self.embed_dim
-        fi, ft = allgather(image_feat), allgather(text_feat)
+        fi, ft = gathered if gathered is not None else (allgather(image_feat), allgather(text_feat))
         logits = self._sim(fi, ft)
         n = logits.shape[0]
         if idx is None:
