@@ -104,6 +104,32 @@ def cpu_baseline(conf, seconds=20.0):
                       % (conf["workload"].split(" pre-training")[0], B, n, dt, threads)}
 
 
+def other_configs(args):
+    """BASELINE.json configs[3] (X2VLM-large 384 px, batch 32) and configs[4] (8 x 8-frame video clips) on this GPU, each by a
+    child run of this script (fresh process: its own allocator pools and graphs) - same timing contract, own cpu_baseline."""
+    import subprocess
+    res = {}
+    for name, steps in (("large", 10), ("video", 15)):
+        cmd = [sys.executable, os.path.abspath(__file__), "--config", name, "--steps", str(steps), "--warmup", "3", "--graph", args.graph]
+        if args.no_cpu_baseline:
+            cmd.append("--no-cpu-baseline")
+        if args.no_graph:
+            cmd.append("--no-graph")
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+            line = [l for l in r.stdout.splitlines() if l.startswith("{") and '"metric"' in l][-1]
+            d = json.loads(line)
+            res[name] = {k: d.get(k) for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "ms_per_step_spread",
+                                                "host_enqueue_ms_per_step", "launch_mode", "dtype", "data", "cpu_baseline")}
+            res[name]["config"] = {k: d["config"][k] for k in ("workload", "per_gpu_batch", "mode")}
+            res[name]["whole_step_tflops"] = d["roofline"]["also"]["whole_step_tflops"]
+            res[name]["whole_step_frac"] = d["roofline"]["also"]["whole_step_frac"]
+            res[name]["gemm_nt_isolated"] = {k: d["roofline"][k] for k in ("achieved", "frac", "avg_launch_us", "launches_per_step")}
+        except Exception as e:      # noqa: BLE001 - the headline line must still be printed
+            res[name] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -114,6 +140,9 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the configuration's own)")
     ap.add_argument("--seq-len", type=int, default=30)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="N = 1, --config base only: do not append the large / video configurations (BASELINE.json configs[3] / [4] on "
+                         "one GPU, each timed by its own child run of this script) to the JSON line")
     ap.add_argument("--eval-mode", action="store_true", help="model.eval(): dropout / DropPath off (not the headline number)")
     ap.add_argument("--tiny", action="store_true", help="debug: 2-layer towers (NOT the benchmark configuration)")
     ap.add_argument("--with-optimizer", action="store_true",
@@ -337,6 +366,8 @@ def main():
                "roofline": roof}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(conf)
+        if world == 1 and args.config == "base" and not (args.no_other_configs or args.tiny or args.serialize or args.eval_mode):
+            out["other_configs"] = other_configs(args)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -23,7 +23,7 @@ extern "C" {
 #endif
 
 const char* x2_last_error(void);
-int x2_abi_version(void);          /* == 5 */
+int x2_abi_version(void);          /* == 6 */
 int x2_device_cus(void);           /* compute units of the current HIP device, 0 if none */
 int x2_tune(int key, int value);   /* kernel-variant knobs for probes/ and tests (0 = automatic); keys listed in csrc/gemm.hip */
 
@@ -52,6 +52,12 @@ int x2_gemm_nt(const void* A, const void* B, void* C, int M, int N, int K, int l
                int act, int out_f32, unsigned drop_thr16, unsigned drop_seed, float drop_scale, const unsigned* drop_epoch,
                const float* rowscale, float* colsum, void* stream);      /* colsum[n] += sum_m C[m,n] (fused bias gradient), NULL = off */
 
+/* C = (A . B^T) x GELU'(aux) -> bf16 plus the column sums of C as partial rows colparts[r][N], r < *nrows_out (2 per row tile
+ * of the launch; colparts must hold 2 * ceil(M / 64) rows); the caller adds them with x2_reduce_partials(_multi)(colparts,
+ * *nrows_out, 1, N, out).  Input gradient through the MLP's GELU + bias gradient of its first linear in one kernel
+ * (autograd of beit2.py:62-66, xbert.py:497: GeluBackward + the bias reduction of AddmmBackward). */
+int x2_gemm_nt_dgelu_colparts(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
+                              const void* aux, int ldaux, float* colparts, int* nrows_out, void* stream);
 /* The same product with a split contraction, for few output tiles and a long K: C[M,N] (fp32, no epilogue) =
  * A[M,K] . B[N,K]^T.  The input gradient of the tied MLM decoder (reference: autograd of the F.linear behind
  * xbert.py:822, dt[R,768] = dlogits[R,30528] . E) is 36-72 output tiles of 477 contraction steps - a serial chain on a
@@ -119,12 +125,20 @@ int x2_colsum_bf16(const void* y, float* out, int M, int N, int ld, float* ws /*
 /* defer != 0: only stage 1 (partials into ws); the caller finishes with x2_reduce_partials, possibly on another stream:
  * out_k[c] += sum_blk ws[blk][k][c], k < nk <= 3 */
 int x2_reduce_partials(const float* part, int nblk, int nk, int width, float* o0, float* o1, float* o2, void* stream);
-/* `count` such reductions in one launch (all parameter-gradient sums of one layer's backward);
- * desc: count rows of 7 int64 {part, nblk, nk, width, o0, o1, o2} */
+/* `count` such reductions in one launch (all parameter-gradient sums of one layer's backward), nk <= 4 here;
+ * desc: count rows of 8 int64 {part, nblk, nk, width, o0, o1, o2, o3} (a null output skips that partial row) */
 int x2_reduce_partials_multi(const int64_t* desc, int count, void* stream);
 /* backward of x + gamma * u (beit2.py:206-207): du = gamma*dx (bf16), dgamma += sum dx*u, dbias += sum du */
 int x2_layerscale_bwd(const float* dx, const void* u, const float* gamma, void* du, float* dgamma, float* dbias,
                       const float* rowscale, int M, int D, float* ws /* [ceil(M/32)][2][D] */, int defer, void* stream);
+/* x2_layernorm_bwd and the x2_layerscale_bwd its output feeds in ONE pass over the rows (BEiT pre-LN blocks, beit2.py:
+ * 205-207: every LayerNorm backward of the vision tower feeds exactly one layer-scale backward): dx = dres + LN'(dy) (fp32),
+ * du = gamma * rowscale * dx (bf16), dw += , db += , dgamma += sum dx*rowscale*u, dbias += sum du.
+ * ws: [ceil(rows/16)][4][D] partial rows {dw, db, dgamma, dbias}; defer != 0: the caller reduces them (x2_reduce_partials_multi) */
+int x2_layernorm_bwd_layerscale(const void* dy /* fp32, or bf16 when dy_is_bf16 */, int dy_is_bf16, const float* x, const float* mean,
+                                const float* rstd, const float* w, const float* dres, float* dx, float* dw, float* db,
+                                const void* u, const float* gamma, const float* rowscale, void* du, float* dgamma, float* dbias,
+                                int rows, int D, float* ws, int defer, void* stream);
 int x2_cast_bf16(const float* src, void* dst, long n, void* stream);
 int x2_cast_transpose_bf16(const float* src, void* dst, void* dstT, int R, int C, int ldt, void* stream);
 /* bf16 (W, W^T) copies of many fp32 weights in one launch (what apex O1's per-call weight casts amount to, done once per
@@ -190,6 +204,12 @@ int x2_mlm_ce_bwd(const void* X, const void* E, const float* bias, const long* l
 /* hard negatives, xvlm.py:828-857: softmax(sim)+1e-5 with the diagonal (or same-group entries) zeroed, one
  * inverse-CDF draw per row from u[b] in [0,1); replaces 2*B torch.multinomial(...).item() host syncs */
 int x2_sample_negatives(const float* sim, int n, const long* group, const float* u, int* out, void* stream);
+/* additive key mask of BertModel (get_extended_attention_mask: neg = -10000; invert_attention_mask: -1e9; xbert.py:1105-1160):
+ * out[s][l] = (1 - atts[s][l]) * neg, l < L; 0 in the pad columns L..Lp-1 (the attention kernels read [S][Lp], Lp % 64 == 0) */
+int x2_additive_mask(const long* atts, float* out, int S, int L, int Lp, float neg, void* stream);
+/* CSR "K/V batch -> query sequences using it" from kv[S] (values in [0, Bi)): off[Bi+1], order[S] (stable counting sort);
+ * the seq_off / seq_ids tables of X2AttnArgs for rows that share an image's K/V (the 4-pass fusion batch) */
+int x2_kv_csr(const int* kv, int S, int Bi, int* off, int* order, void* stream);
 int x2_gelu_f32(const float* x, const float* dy, float* out, long n, void* stream);               /* nn.GELU, xvlm.py:167 */
 int x2_colsum_f32(const float* x, float* out, int M, int N, void* stream);
 

@@ -39,6 +39,12 @@ CASES = {
     "large_full": dict(image_res=384, vision_layers=24, vision_width=1024, hidden=1024, heads=16, ffn=4096, vocab=30522,
                        max_pos=512, text_layers=18, fusion_at=12, embed_dim=256, batch=2, seq_len=30,
                        max_masks=12, ragged=True, region=False, frames=0, wseed=71, bseed=72),
+    # the region / bbox iteration (Pretrain.run_region_iter, Pretrain.py:79-111) at the REAL geometry: full X2VLM-base, 224 px,
+    # 8 region texts over 4 images, image_atts with masked-out patches (masked mean pooling over 197 tokens, beit2.py:426-436),
+    # the 5th fusion pass of predict_bbox at base width, L1 + GIoU (xvlm.py:688-698, 910-957)
+    "base_region": dict(image_res=224, vision_layers=12, hidden=768, heads=12, ffn=3072, vocab=30522,
+                        max_pos=512, text_layers=18, fusion_at=12, embed_dim=256, batch=8, n_images=4, seq_len=30,
+                        max_masks=12, ragged=True, region=True, frames=0, wseed=91, bseed=92),
     # BASELINE.json configs[4]: full X2VLM-base video path, 8-frame 224 px clips (avgpool + frame position embedding)
     "video_full": dict(image_res=224, vision_layers=12, hidden=768, heads=12, ffn=3072, vocab=30522,
                        max_pos=512, text_layers=18, fusion_at=12, embed_dim=256, batch=2, seq_len=30,

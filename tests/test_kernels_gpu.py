@@ -38,7 +38,8 @@ def relerr(got, ref):
     return float((got - ref).abs().max() / ref.abs().max().clamp_min(1e-12))
 
 
-@pytest.fixture(params=[(1, 1), (1, 2), (2, 0), (1, 3), (1, 4)], ids=["tile128x128", "tile192x128", "tile256x128w8", "tile64x128", "tile160x128"])
+@pytest.fixture(params=[(1, 1), (1, 2), (2, 0), (1, 3), (1, 4), (3, 8), (3, 7), (3, 6), (3, 5)],
+                ids=["tile128x128", "tile192x128", "tile256x128w8", "tile64x128", "tile160x128", "nt256x256", "nt224x256", "nt192x256", "nt160x256"])
 def nt_tile(request):
     lib = importlib.import_module("x2-vlm_amd._lib").lib()
     lib.x2_tune(1, request.param[0])
@@ -127,6 +128,82 @@ def test_gemm_nt_row_contiguous_fp32_epilogue_matches_the_default_one(K, M, N, K
                 assert float((g_.float() - r_.float()).abs().max()) <= tol * max(1.0, float(r_.float().abs().max())), kind
     finally:
         lib.x2_tune(1, 0); lib.x2_tune(2, 0); lib.x2_tune(3, 0)
+
+
+@pytest.mark.parametrize("tile", [0, 1, 2, 3], ids=["auto", "tile128", "tile192", "tile64"])
+@pytest.mark.parametrize("M,N,K_", [(300, 200, 192), (788, 3072, 128), (3840, 3072, 64), (130, 64, 64)])
+def test_gemm_nt_dgelu_with_column_sums(K, M, N, K_, tile):
+    """x2_gemm_nt_dgelu_colparts (epilogue variant 10): the GELU' input gradient equals the plain variant-3 launch bit for bit
+    (same epilogue arithmetic) and the reduced per-wave partial rows equal its column sums; immediate and deferred reduction."""
+    lib = importlib.import_module("x2-vlm_amd._lib").lib()
+    A, B = bf(rnd(M, K_, seed=51)).to(dev), bf(rnd(N, K_, seed=52, scale=K_ ** -0.5)).to(dev)
+    pre = bf(rnd(M, N, seed=53)).to(dev)
+    lib.x2_tune(1, 1); lib.x2_tune(3, tile)
+    try:
+        ref = K.gemm_nt(A, B, aux=pre, act=2)
+        cs = torch.full((N,), 3.0, device=dev)
+        got = K.gemm_nt_dgelu_colsum(A, B, pre, cs)
+        # same operations in the same order; only the compiler's fma contraction may differ between the two instantiations,
+        # which flips a bf16 rounding here and there
+        same = lambda g_, r_: float((g_.float() - r_.float()).abs().max()) <= 8e-3 * max(1.0, float(r_.float().abs().max()))
+        assert same(got, ref) and float((got != ref).float().mean()) < 1e-3
+        want = ref.float().sum(0).cpu().double() + 3.0          # accumulated onto what was there; fp32 values before the bf16 rounding
+        assert float((cs.cpu().double() - want).abs().max()) <= 4e-3 * float(ref.float().abs().sum(0).max()) + 1e-6
+        exact = (A.float() @ B.float().t() * torch.autograd.functional.jacobian(lambda t: O.gelu(t).sum(), pre.float()).to(dev)).sum(0)
+        assert relerr(cs - 3.0, exact.cpu()) < 2e-4
+        cs2 = torch.zeros(N, device=dev)
+        K.DEFERRED = []
+        try:
+            got2 = K.gemm_nt_dgelu_colsum(A, B, pre, cs2)
+            items, K.DEFERRED = K.DEFERRED, None
+            K.reduce_partials_multi(items)
+        finally:
+            K.DEFERRED = None
+        assert torch.equal(got2, got) and relerr(cs2, (cs - 3.0).cpu()) < 1e-6
+    finally:
+        lib.x2_tune(1, 0); lib.x2_tune(3, 0)
+
+
+@pytest.mark.parametrize("tmw", [8, 7, 6, 5], ids=["nt256x256", "nt224x256", "nt192x256", "nt160x256"])
+@pytest.mark.parametrize("M,N,K_", [(300, 200, 192), (788, 2304, 128), (1000, 768, 64), (2500, 768, 1024)])
+def test_gemm_nt_256_column_kernel_matches_the_default_one(K, M, N, K_, tmw):
+    """x2_tune(1, 3): the 8-wave 256-column kernel (gemm_nt256_kernel, all four tile heights) shares the epilogue code with the
+    128-column kernels, so every compiled feature set - incl. dropout and DropPath row factors, whose masks are functions
+    of the element index - must reproduce their outputs up to the order of the fp32 accumulation."""
+    lib = importlib.import_module("x2-vlm_amd._lib").lib()
+    A, B = bf(rnd(M, K_, seed=41)).to(dev), bf(rnd(N, K_, seed=42, scale=K_ ** -0.5)).to(dev)
+    bias, gamma, resid = rnd(N, seed=43).to(dev), rnd(N, seed=44).to(dev), rnd(M, N, seed=45).to(dev)
+    pre = bf(rnd(M, N, seed=46)).to(dev)
+    rowscale = (torch.rand(M, generator=torch.Generator().manual_seed(47)) > 0.2).float().to(dev) * 1.25
+    drop = K.dropout_spec(0.1, 4321, 3)
+
+    def run(kind):
+        aux = torch.zeros(M, N, device=dev, dtype=torch.bfloat16)
+        if kind == "bias_bf16":
+            return K.gemm_nt(A, B, bias=bias), aux
+        if kind == "bias_f32":
+            return K.gemm_nt(A, B, bias=bias, out_dtype=torch.float32), aux
+        if kind == "gelu":
+            return K.gemm_nt(A, B, bias=bias, aux=aux, act=1), aux
+        if kind == "dgelu":
+            return K.gemm_nt(A, B, aux=pre, act=2), aux
+        if kind == "bias_drop_resid":
+            return K.gemm_nt(A, B, bias=bias, resid=resid, out_dtype=torch.float32, drop=drop), aux
+        if kind == "layerscale":
+            return K.gemm_nt(A, B, bias=bias, gamma=gamma, resid=resid, aux=aux, out_dtype=torch.float32), aux
+        return K.gemm_nt(A, B, bias=bias, gamma=gamma, resid=resid, aux=aux, out_dtype=torch.float32, rowscale=rowscale), aux
+
+    try:
+        for kind in ("bias_bf16", "bias_f32", "gelu", "dgelu", "bias_drop_resid", "layerscale", "layerscale_droppath"):
+            lib.x2_tune(1, 1); lib.x2_tune(3, 1)
+            ref, ref_aux = run(kind)
+            lib.x2_tune(1, 3); lib.x2_tune(3, tmw)
+            got, got_aux = run(kind)
+            for g_, r_ in ((got, ref), (got_aux, ref_aux)):
+                tol = 4e-6 if g_.dtype == torch.float32 else 8e-3
+                assert float((g_.float() - r_.float()).abs().max()) <= tol * max(1.0, float(r_.float().abs().max())), kind
+    finally:
+        lib.x2_tune(1, 0); lib.x2_tune(3, 0)
 
 
 @pytest.mark.parametrize("M,N,K_,slices", [(768, 768, 30528, 0), (96, 768, 30528, 0), (40, 256, 4096, 0), (300, 200, 1024, 3),
@@ -341,10 +418,11 @@ def _attn_variant(K, bits):
     importlib.import_module("x2-vlm_amd._lib").lib().x2_tune(8, bits)
 
 
-@pytest.mark.parametrize("bits", [4096, 8192, 4096 | 8192], ids=["walk_fwd", "walk_dq", "walk_both"])
+@pytest.mark.parametrize("bits", [0, 4096, 8192, 4096 | 8192], ids=["two_workgroups", "walk_fwd", "walk_dq", "walk_both"])
 def test_attention_vision_bias_strip_walking_variants(K, bits):
-    """The strip-walking resident forward / dQ kernels (one workgroup per (image, head), K / V loaded once) against the same
-    oracle as the default kernels: N = 197 with the relative-position bias, and a short ragged case (one partial key tile)."""
+    """The strip-walking resident forward / dQ kernels (one workgroup per (image, head), K / V loaded once; the default) and the
+    two-workgroup resident kernels they replaced (bits 0) against the same oracle: N = 197 with the relative-position bias,
+    a short ragged case (one partial key tile), and the full 208 rows the strips hold."""
     _attn_variant(K, bits)
     try:
         run_attention(K, B=3, Bkv=3, H=12, Lq=197, Lk=197, use_bias=True, use_mask=False, kv_map=None, seed=100)
@@ -402,6 +480,42 @@ def test_layernorm(K, rows, D, period):
     dw2, db2, dcol = torch.zeros(D, device=dev), torch.zeros(D, device=dev), torch.zeros(D, device=dev)
     dx2, _ = K.layernorm_bwd(dy.to(dev), x.to(dev), mean, rstd, w.to(dev), dw2, db2, dcol=dcol, period=period)
     assert relerr(dcol, xl.grad[sel].sum(0)) < 5e-5 and relerr(dx2[sel], xl.grad[sel]) < 2e-5
+
+
+@pytest.mark.parametrize("rows,D,dy_bf16,use_rowscale", [(700, 768, True, True), (333, 1024, True, False), (50, 128, False, True)])
+def test_layernorm_bwd_with_fused_layerscale_bwd(K, rows, D, dy_bf16, use_rowscale):
+    """x2_layernorm_bwd_layerscale == x2_layernorm_bwd followed by x2_layerscale_bwd (same arithmetic in one pass), in both
+    reduction modes: immediate, and deferred with the layer-scale sums registered separately (how the vision backward
+    hands them to the NEXT block's gradient arena)."""
+    x = (rnd(rows, D, seed=1, scale=2.0) + 0.5).to(dev)
+    w = (rnd(D, seed=2) * 0.1 + 1).to(dev)
+    dy = rnd(rows, D, seed=4)
+    dy = (bf(dy) if dy_bf16 else dy).to(dev)
+    dres, u, gamma = rnd(rows, D, seed=5).to(dev), bf(rnd(rows, D, seed=6)).to(dev), rnd(D, seed=7).to(dev)
+    rowscale = ((torch.rand(rows, generator=torch.Generator().manual_seed(8)) > 0.3).float() * 1.25).to(dev) if use_rowscale else None
+    _, _, mean, rstd = K.layernorm_fwd(x, w, torch.zeros(D, device=dev), 1e-6)
+    dw0, db0, dg0, dbias0 = (torch.zeros(D, device=dev) for _ in range(4))
+    dx0, _ = K.layernorm_bwd(dy, x, mean, rstd, w, dw0, db0, dres=dres)
+    du0 = K.layerscale_bwd(dx0, u, gamma, dg0, dbias0, rowscale=rowscale)
+    # immediate reduction
+    dw1, db1, dg1, dbias1 = (torch.zeros(D, device=dev) for _ in range(4))
+    dx1, du1, _ = K.layernorm_bwd_layerscale(dy, x, mean, rstd, w, dw1, db1, dres, u, gamma, dg1, dbias1, rowscale=rowscale)
+    assert torch.equal(dx1, dx0) and relerr(du1, du0.float().cpu()) < 1e-6
+    for a, b_ in ((dw1, dw0), (db1, db0), (dg1, dg0), (dbias1, dbias0)):
+        assert relerr(a, b_.cpu()) < 2e-5
+    # deferred, layer-scale sums registered by the caller
+    dw2, db2, dg2, dbias2 = (torch.zeros(D, device=dev) for _ in range(4))
+    K.DEFERRED = []
+    try:
+        dx2, du2, (ws, nblk) = K.layernorm_bwd_layerscale(dy, x, mean, rstd, w, dw2, db2, dres, u, gamma, rowscale=rowscale)
+        K.DEFERRED.append((ws, nblk, 4, D, (None, None, dg2, dbias2)))
+        items, K.DEFERRED = K.DEFERRED, None
+        K.reduce_partials_multi(items)
+    finally:
+        K.DEFERRED = None
+    assert torch.equal(dx2, dx0) and torch.equal(du2, du1)
+    for a, b_ in ((dw2, dw1), (db2, db1), (dg2, dg1), (dbias2, dbias1)):
+        assert relerr(a, b_.cpu()) < 1e-6
 
 
 def test_colsum_layerscale_casts(K):
@@ -560,3 +674,21 @@ def test_cross_entropy_and_sampling(K):
     x = rnd(1000, seed=5); dy = rnd(1000, seed=6)
     xl = x.clone().requires_grad_(True); O.gelu(xl).backward(dy)
     assert relerr(K.gelu_f32(x.to(dev)), O.gelu(x)) < 1e-6 and relerr(K.gelu_f32(x.to(dev), dy.to(dev)), xl.grad) < 1e-5
+
+
+@pytest.mark.parametrize("S,Bi", [(256, 64), (11, 2), (40, 300), (2048, 1000), (5, 5)])
+def test_kv_csr_and_additive_mask(K, S, Bi):
+    """x2_kv_csr == stable argsort + bincount + cumsum (the torch ops it replaces); x2_additive_mask == (1 - m) * neg padded."""
+    g = torch.Generator().manual_seed(S * 31 + Bi)
+    kv = torch.randint(0, Bi, (S,), generator=g).to(torch.int32)
+    off, order = K.kv_csr(kv.to(dev), Bi)
+    want_order = torch.argsort(kv, stable=True).to(torch.int32)
+    want_off = torch.zeros(Bi + 1, dtype=torch.int32)
+    want_off[1:] = torch.cumsum(torch.bincount(kv, minlength=Bi), 0)
+    assert torch.equal(off.cpu(), want_off) and torch.equal(order.cpu(), want_order)
+    L = 30 if S % 2 == 0 else 197
+    atts = (torch.rand(S, L, generator=g) > 0.3).long()
+    for neg in (-10000.0, -1e9):
+        m = K.additive_mask(atts.to(dev), neg)
+        assert m.shape == (S, K.round_up(L, 64))
+        assert torch.equal(m[:, :L].cpu(), (1.0 - atts.float()) * neg) and float(m[:, L:].abs().max()) == 0.0

@@ -59,7 +59,7 @@ def run_case(case, tmpdir, synthetic):
 
 
 @pytest.mark.parametrize("case", ["tiny", "tiny_region", "tiny_video", "base_shallow", "large_shallow", "base_full", "base_full_b64",
-                                  "large_full", "video_full"])
+                                  "large_full", "video_full", "base_region"])
 def test_step_matches_reference(case, tmp_path, synthetic):
     gold = np.load(os.path.join(GOLD, case + ".npz"))
     model, loss, c = run_case(case, tmp_path, synthetic)

@@ -28,7 +28,7 @@ def close(a, b, rtol, what, floor=1e-6):
     assert err <= rtol, "%s: max err / scale = %.3e > %.1e" % (what, err, rtol)
 
 
-@pytest.mark.parametrize("case", ["tiny", "tiny_region", "tiny_video", "base_shallow", "large_shallow",
+@pytest.mark.parametrize("case", ["tiny", "tiny_region", "tiny_video", "base_shallow", "large_shallow", "base_region",
                                   pytest.param("base_full", marks=pytest.mark.slow),
                                   pytest.param("base_full_b64", marks=pytest.mark.slow),
                                   pytest.param("large_full", marks=pytest.mark.slow),

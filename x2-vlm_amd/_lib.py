@@ -31,11 +31,13 @@ class AttnArgs(C.Structure):
 _SIGS = {
     "x2_gemm_nt": [P, P, P, I, I, I, I, I, I, P, P, P, I, P, I, I, I, U, U, F, P, P, P, P],
     "x2_gemm_nt_splitk": [P, P, P, I, I, I, I, I, I, I, P, L, P],
+    "x2_gemm_nt_dgelu_colparts": [P, P, P, I, I, I, I, I, I, P, I, P, C.POINTER(I), P],
     "x2_gemm_tn_grouped": [P, I, I, I, P, L, P],
     "x2_attn_fwd": [C.POINTER(AttnArgs), P],
     "x2_attn_bwd": [C.POINTER(AttnArgs), P],
     "x2_layernorm_fwd": [P, P, P, P, P, P, P, I, I, F, I, U, U, F, P, P],
     "x2_layernorm_bwd": [P, I, P, P, P, P, P, P, P, P, P, P, I, I, I, U, U, F, U, U, F, P, P, I, P],
+    "x2_layernorm_bwd_layerscale": [P, I, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, P, I, P],
     "x2_colsum_bf16": [P, P, I, I, I, P, I, P],
     "x2_reduce_partials": [P, I, I, I, P, P, P, P],
     "x2_reduce_partials_multi": [P, I, P],
@@ -62,6 +64,8 @@ _SIGS = {
     "x2_ce_combine": [P, I, P, P, I, P, P, P, P],
     "x2_mlm_ce_bwd": [P, P, P, P, P, P, P, F, I, I, I, I, I, I, P, L, P],
     "x2_sample_negatives": [P, I, P, P, P, P],
+    "x2_additive_mask": [P, P, I, I, I, F, P],
+    "x2_kv_csr": [P, I, I, P, P, P],
     "x2_gelu_f32": [P, P, P, L, P],
     "x2_grad_norm": [P, I, I, F, P, P, P],
     "x2_adamw_multi": [P, I, I, P, P, I, F, F, F, P, P],

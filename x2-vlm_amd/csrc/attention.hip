@@ -620,7 +620,8 @@ __global__ __launch_bounds__(64 * QW, 32 / QW) void attn_bwd_dq_grouped_kernel(A
 }
 
 // ------------------------------------------------------------------------------------------ strip-walking resident forms
-// STAGED, NOT YET MEASURED (X2_ATTN_VARIANT bits 4096 forward / 8192 dQ; nothing selects them by default).
+// Selected by default for Lk <= WALK_ROWS without K/V sharing (X2_ATTN_VARIANT bits 4096 forward / 8192 dQ; 0 = the two-workgroup
+// resident kernels above).
 // The resident kernels above launch ceil(Lq / 128) workgroups per (sequence, head) and each loads ALL of K and V: at
 // N = 197 that is two workgroups, K / V read twice (126 MB moved per forward launch for 77 MB of operands) and three rounds
 // of 64 KB workgroups.  Here ONE four-wave workgroup per (sequence, head) keeps K / V as sixteen-row strips - WALK_ROWS =
@@ -1009,13 +1010,15 @@ __global__ __launch_bounds__(64 * KW, (KW == 4 && !RES) ? 3 : 4) void attn_bwd_d
 // bit 3: grouped (shared K/V) forward kernel for cross-attention; bit 4: per-row dQ kernel instead of the grouped one.  Measured on the
 // fusion shapes (256 rows on 64 images): 62 vs 68 us forward, 132 vs 147 us backward in isolation, but -3 % on the whole
 // step (64 KB workgroups co-reside worse with the other streams' kernels), so off by default;
-// bit 12 (4096) / bit 13 (8192): strip-walking resident forward / dQ kernels (staged, unmeasured: see their header)
+// bit 12 (4096) / bit 13 (8192): strip-walking resident forward / dQ kernels (the default; see their header)
 // x2_tune(8, v) (gemm.hip) overrides the environment at run time: tests and probes A/B variants inside one process
 int x2_attn_variant_override = -1;
 static int attn_variant() {
   static int v = -1;
   if (x2_attn_variant_override >= 0) return x2_attn_variant_override;
-  if (v < 0) { const char* e = getenv("X2_ATTN_VARIANT"); v = e ? atoi(e) : 0; }
+  // default: the strip-walking forward and dQ kernels at N <= 208 (measured on [64, 12, 197]: forward 47.3 -> 45.6 us, dQ + dK/dV
+  // 128.1 -> 118.8 us, profiles/r03a_attn_walk_ab.txt)
+  if (v < 0) { const char* e = getenv("X2_ATTN_VARIANT"); v = e ? atoi(e) : (4096 | 8192); }
   return v;
 }
 

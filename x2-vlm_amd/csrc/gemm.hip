@@ -84,18 +84,23 @@ __device__ __forceinline__ void st16(void* p, u32x4 v, bool wt) {
 //   7 partial products of one contraction slice -> fp32 workspace (x2_gemm_nt_splitk; slice = blockIdx.y)
 //   8 bias, then per row and 64-column chunk (max, sum exp) + the logit at the label: softmax statistics, nothing stored
 //   9 bias, then (softmax - onehot) * row scale -> bf16: gradient of the mean cross-entropy w.r.t. the logits
+//  10 = 3 plus the column sums of the result (bias gradient of fc1 / intermediate): every wave adds up its rows and writes ONE
+//     partial row colsum[2 * row tile + wave row][N]; the caller reduces the partial rows (x2_reduce_partials*): replaces a
+//     stand-alone pass over the [M, 4D] gradient (x2_colsum_bf16: 77 MB read per vision block) without the atomics that
+//     made the first fused form slower than that pass
 template <int V> struct EpiTraits {
   static constexpr bool generic = V == 4;
-  static constexpr int act = V == 2 ? 1 : V == 3 ? 2 : 0;
+  static constexpr int act = V == 2 ? 1 : (V == 3 || V == 10) ? 2 : 0;
   static constexpr bool out_f32 = V == 1 || V == 5 || V == 6 || V == 7;
   static constexpr bool resid = V == 5 || V == 6;
   static constexpr bool scale = V == 6;           // gamma and optional rowscale
   static constexpr bool aux0 = V == 6;            // act == 0 with aux: save the value before the layer scale
   static constexpr bool drop = V == 5;            // dropout possible (still a runtime test on thr16, outside the hot variants)
   static constexpr bool colsum = false;
+  static constexpr bool colparts = V == 10;       // column sums of the stored values as one partial row per wave row (no atomics)
 };
 template <int TM, int VAR>
-__device__ __forceinline__ void nt_epilogue(const GemmNT& p, f32x4 (&acc)[TM][4], char* smem, int wave, int lane, int mw0, int nw0) {
+__device__ __forceinline__ void nt_epilogue(const GemmNT& p, f32x4 (&acc)[TM][4], char* smem, int wave, int lane, int mw0, int nw0, int prow = 0) {
   using E = EpiTraits<VAR>;
   const int act = E::generic ? p.act : E::act;
   const bool out_f32 = E::generic ? p.out_f32 != 0 : E::out_f32;
@@ -215,7 +220,7 @@ __device__ __forceinline__ void nt_epilogue(const GemmNT& p, f32x4 (&acc)[TM][4]
         v[0] += r0[rr].x; v[1] += r0[rr].y; v[2] += r0[rr].z; v[3] += r0[rr].w;
         v[4] += r1[rr].x; v[5] += r1[rr].y; v[6] += r1[rr].z; v[7] += r1[rr].w;
       }
-      if (has_colsum) {
+      if (has_colsum || E::colparts) {
 #pragma unroll
         for (int r = 0; r < 8; ++r) cs[r] += v[r];
       }
@@ -227,6 +232,15 @@ __device__ __forceinline__ void nt_epilogue(const GemmNT& p, f32x4 (&acc)[TM][4]
         st16(reinterpret_cast<bf16_t*>(p.C) + (size_t)m * p.ldc + n,
              u32x4{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7])}, wt);
       }
+    }
+  }
+  if constexpr (E::colparts) {     // this wave's rows, folded over the 8 lanes that share a column group: one 256-byte partial-row segment
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { cs[e] += __shfl_xor(cs[e], 8, 64); cs[e] += __shfl_xor(cs[e], 16, 64); cs[e] += __shfl_xor(cs[e], 32, 64); }
+    if (er == 0 && nok) {
+      float* dst = p.colsum + (size_t)prow * p.N + n;
+      *reinterpret_cast<float4*>(dst) = float4{cs[0], cs[1], cs[2], cs[3]};
+      *reinterpret_cast<float4*>(dst + 4) = float4{cs[4], cs[5], cs[6], cs[7]};
     }
   }
   if (has_colsum) {     // lanes sharing (lane & 7) hold the same 8 columns for different rows: fold 8 -> 1, one atomic per column
@@ -437,7 +451,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNT p) {
     return;
   }
   if (p.dbg & 4) { if (acc[0][0][0] == 12345.678f) reinterpret_cast<float*>(p.C)[0] = acc[1][1][1] + acc[2][2][2] + acc[3][3][3]; return; }
-  nt_epilogue<TM, VAR>(p, acc, smem, wave, lane, m0 + wm * 16 * TM, n0 + wn * 64);
+  nt_epilogue<TM, VAR>(p, acc, smem, wave, lane, m0 + wm * 16 * TM, n0 + wn * 64, tm * 2 + wm);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -521,12 +535,160 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_w8_kernel(GemmNT p) {
   nt_epilogue<4, 4>(p, acc, smem, wave, lane, m0 + wm * 64, n0 + wn * 64);
 }
 
+// ---------------------------------------------------------------------------------------------
+// NT, 256-column tiles on the schedule of the 256x256 weight-gradient kernel below (gemm_tn256_kernel): (32 * TMW) x 256
+// outputs per 512-thread workgroup - 8 waves as 2 (rows) x 4 (columns), each a (16 * TMW) x 64 wave tile = TMW x 4 MFMA
+// tiles (TMW = 8: 128 accumulator VGPRs) - one workgroup per CU.  Why: the 128x128 kernel above stages 1/64 byte per
+// flop through L2 -> LDS and reads 0.5 LDS fragments per MFMA; its main loops run at 0.8-1.07 PFLOP/s, bound by that
+// traffic and not by MFMA issue.  A 256x256 tile stages 1/128 byte per flop, a 128x64 wave tile reads 0.375 fragments
+// per MFMA (the weight-gradient kernel's main loop: 1.24 PFLOP/s).
+//   LDS: 2 contraction steps x 4 half-tiles (A0, A1 = the two wave rows' 16*TMW rows of A; B0, B1 = columns n0.., n0+128..)
+//   x 16 KB, each a [rows][64 k] image, chunk c (16 B) of row r at position c ^ (r & 7) as in gemm_nt_kernel.
+//   One contraction step = 4 phases (quadrants rows-lo x cols-lo, rows-lo x cols-hi, rows-hi x cols-hi, rows-hi x cols-lo
+//   of the wave tile), every phase also requests ONE half-tile:
+//     phase 1, 2: A0, A1 of step t+1 into the other buffer (last read in step t-1, behind that step's end barrier)
+//     phase 3, 4: B0, B1 of step t+2 into THIS buffer (every wave holds its B fragments of step t after phase 2: mid barrier)
+//   so 2-4 half-tiles are always in flight across the two barriers of a step: counted s_waitcnt vmcnt(4), never 0 in the loop.
+// TMW = 8 / 7 / 6 / 5 (256 / 224 / 192 / 160 rows): the host picks the height whose tile count fills whole rounds of the
+// 256 CUs best (x2_gemm_nt: nt256_plan) - at these sizes a launch is 1-3 rounds, so the last round's fill decides.
+// Epilogue: nt_epilogue<TMW, VAR> as above (the wave's 64 columns x 16*TMW rows through its 8.5 KB of LDS staging).
+// ---------------------------------------------------------------------------------------------
+#define N2_HALF 16384
+#define N2_LDS_BYTES (8 * N2_HALF)
+template <int TMW, int VAR>
+__global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmNT p) {
+  constexpr int BMT = 32 * TMW, HROWS = 16 * TMW;       // block rows, rows of one A half (= of one wave row)
+  constexpr int TH = (TMW + 1) / 2;                     // row tiles of the first quadrant pair (rows-lo); rows-hi = TMW - TH
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int tiles_n = (p.N + 255) / 256, tiles_m = (p.M + BMT - 1) / BMT;
+  int tm, tn;
+  tile_coords(xcd_remap(blockIdx.x, gridDim.x), tiles_m, tiles_n, p.group_m, tm, tn);
+  const int m0 = tm * BMT, n0 = tn * 256;
+
+  // per-thread global sources: half h of A / B, chunk i (16 B each; a B half is 128 rows x 8 chunks = 2 x 512, an A half
+  // 16*TMW rows x 8 = 128*TMW chunks: the second pass only covers waves below 2*TMW - 8)
+  const bf16_t* srcA[2][2]; const bf16_t* srcB[2][2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int q = i * 512 + tid, row = q >> 3, c = (q & 7) ^ (row & 7);
+      int ra = m0 + h * HROWS + (row < HROWS ? row : HROWS - 1); ra = ra < p.M ? ra : p.M - 1;
+      int rb = n0 + h * 128 + row; rb = rb < p.N ? rb : p.N - 1;
+      srcA[h][i] = p.A + (size_t)ra * p.lda + c * 8;
+      srcB[h][i] = p.B + (size_t)rb * p.ldb + c * 8;
+    }
+  const bool a2 = wave < 2 * TMW - 8;                   // this wave takes part in the second pass over an A half
+  auto issue = [&](int kt, auto slot) {                 // slot 0, 1: A halves; 2, 3: B halves
+    constexpr int S = decltype(slot)::value;
+    char* base = smem + ((kt & 1) * 4 + S) * N2_HALF + wave * 1024;
+    if constexpr (S < 2) {
+      glds16(srcA[S][0] + (size_t)kt * BK, base);
+      if (TMW == 8 || a2) glds16(srcA[S][1] + (size_t)kt * BK, base + 8192);
+    } else {
+      glds16(srcB[S - 2][0] + (size_t)kt * BK, base);
+      glds16(srcB[S - 2][1] + (size_t)kt * BK, base + 8192);
+    }
+  };
+  using S0 = std::integral_constant<int, 0>; using S1 = std::integral_constant<int, 1>;
+  using S2 = std::integral_constant<int, 2>; using S3 = std::integral_constant<int, 3>;
+
+  f32x4 acc[TMW][4];
+#pragma unroll
+  for (int i = 0; i < TMW; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const uint32_t lds0 = lds_addr(smem);
+  const int frow = lane & 15, fg = lane >> 4, fsw = lane & 7;
+  const uint32_t offA = (uint32_t)(wr * N2_HALF + frow * 128);
+  const uint32_t offB = (uint32_t)((2 + (wc >> 1)) * N2_HALF + ((wc & 1) * 64 + frow) * 128);
+  bf16x8 fa[2][TH], fb[2][4];                           // [k-half of the step][tile]: one row group of A, all of B
+  auto readA = [&](uint32_t buf, auto hi_) {            // row tiles [0, TH) or [TH, TMW)
+    constexpr bool hi = decltype(hi_)::value;
+    constexpr int first = hi ? TH : 0, count = hi ? TMW - TH : TH;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < count; ++i)
+        fa[ks][i] = lds_read_b128(buf + offA + (first + i) * 2048 + (uint32_t)(((ks * 4 + fg) ^ fsw) << 4));
+  };
+  auto readB = [&](uint32_t buf, int jh) {              // column tiles 2*jh, 2*jh + 1
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        fb[ks][jh * 2 + j] = lds_read_b128(buf + offB + (jh * 2 + j) * 2048 + (uint32_t)(((ks * 4 + fg) ^ fsw) << 4));
+  };
+  auto quad = [&](auto hi_, auto jh_) {                 // one quadrant: row group x column pair, both k-halves
+    constexpr bool hi = decltype(hi_)::value;
+    constexpr int jh = decltype(jh_)::value, first = hi ? TH : 0, count = hi ? TMW - TH : TH;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < count; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          // operands swapped: the accumulator tile is C^T (a lane holds m = frow and 4 consecutive n), as nt_epilogue expects
+          acc[first + i][jh * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[ks][jh * 2 + j], fa[ks][i], acc[first + i][jh * 2 + j], 0, 0, 0);
+  };
+  using LO = std::false_type; using HI = std::true_type;
+#define N2_FENCE() __builtin_amdgcn_sched_barrier(0)
+  auto ktile = [&](int kt, auto n1_, auto n2_) {        // n1: step kt+1 exists, n2: step kt+2 exists
+    constexpr bool n1 = decltype(n1_)::value, n2 = decltype(n2_)::value;
+    const uint32_t buf = lds0 + (uint32_t)((kt & 1) * 4 * N2_HALF);
+    // phase 1
+    readA(buf, LO{}); readB(buf, 0); readB(buf, 1);
+    if constexpr (n1) issue(kt + 1, S0{});
+    N2_FENCE();
+    quad(LO{}, S0{}); N2_FENCE();
+    // phase 2
+    if constexpr (n1) issue(kt + 1, S1{});
+    N2_FENCE();
+    quad(LO{}, S1{}); N2_FENCE();
+    // phase 3: every wave holds its B fragments of this step before B0 / B1 of this buffer are refilled
+    if constexpr (n2) { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); issue(kt + 2, S2{}); }
+    readA(buf, HI{});
+    N2_FENCE();
+    quad(HI{}, S1{}); N2_FENCE();
+    // phase 4
+    if constexpr (n2) issue(kt + 2, S3{});
+    N2_FENCE();
+    quad(HI{}, S0{}); N2_FENCE();
+    if constexpr (n1) {
+      // step kt+1 complete in LDS for this wave (only B0 / B1 of step kt+2 may still be in flight); then for all waves
+      if constexpr (n2) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+      N2_FENCE();
+    }
+  };
+  const int nk = p.K / BK;
+  issue(0, S0{}); issue(0, S1{}); issue(0, S2{}); issue(0, S3{});
+  if (nk > 1) { issue(1, S2{}); issue(1, S3{}); asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory"); }
+  else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+  int kt = 0;
+  for (; kt + 2 < nk; ++kt) ktile(kt, std::true_type{}, std::true_type{});
+  if (kt + 1 < nk) { ktile(kt, std::true_type{}, std::false_type{}); ++kt; }
+  ktile(kt, std::false_type{}, std::false_type{});
+#undef N2_FENCE
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");       // every wave is done reading operand tiles
+  if (p.dbg & 4) { if (acc[0][0][0] == 12345.678f) reinterpret_cast<float*>(p.C)[0] = acc[1][1][1] + acc[2][2][2] + acc[3][3][3]; return; }
+  nt_epilogue<TMW, VAR>(p, acc, smem, wave, lane, m0 + wr * HROWS, n0 + wc * 64);
+}
+
 // knobs for A/B measurements and for the tests that pin a kernel variant (0 = automatic everywhere); [7] 1: no 160x128 NT tiles
-//   [0] GROUP_M of the NT tile raster            [1] 2: NT on the 8-wave 256x128 kernel
+//   [0] GROUP_M of the NT tile raster            [1] 0: automatic, 1: 128-column kernels only, 2: the 8-wave 256x128 kernel, 3: always the 256-column kernel
 //   [2] NT ablation bits (4 no epilogue, 16 sc1 stores, 64 row-contiguous fp32 stores)          [6] 1: always the generic (run-time flags) NT epilogue
-//   [3] NT tile: 1 = 128x128, 2 = 192x128, 3 = 64x128, 4 = 160x128        [4] NT start stagger (x 4 us)
+//   [3] NT tile: 1 = 128x128, 2 = 192x128, 3 = 64x128, 4 = 160x128; 5..8 = rows / 32 of the 256-column kernel        [4] NT start stagger (x 4 us)
 //   [5] TN: 1 = always 128x128 tiles, 2 = 256x256 tiles whenever the contraction lengths allow
+//   [8] attention kernel variant bits (attention.hip attn_variant(); -1 = back to the X2_ATTN_VARIANT environment value)
+//   [9] percent of perfect CU fill the 256-column NT kernel's plan must reach to be chosen when [1] = 4 (0 = 80)
 static int g_tune[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+static int g_tune_x[4] = {0, 0, 0, 0};          // keys 8.. : [0] unused here (attention variant lives in attention.hip), [1] = key 9
+extern int x2_attn_variant_override;
 extern "C" int x2_device_cus(void);
 // compute units of the current device (256 on MI355X), asked once: grid-fill decisions below are made in units of it
 static int x2_cus() {
@@ -535,9 +697,46 @@ static int x2_cus() {
   return n;
 }
 extern "C" int x2_tune(int key, int value) {
+  if (key == 8) { x2_attn_variant_override = value; return X2_OK; }
+  if (key >= 9 && key < 12) { g_tune_x[key - 8] = value; return X2_OK; }
   if (key < 0 || key >= 8) return X2_ERR_ARG;
   g_tune[key] = value;
   return X2_OK;
+}
+
+// 256-column kernel: tile height for this problem.  A launch is a few rounds of one workgroup per CU, each round as long as
+// its tiles are high: cost = rounds x TMW; efficiency = (M x N work spread perfectly) / cost.  Returns TMW (5..8) of the best
+// height and its efficiency in *eff.
+static int nt256_plan(int M, int N, double* eff) {
+  const int cus = x2_cus(), tiles_n = (N + 255) / 256;
+  const double ideal = (double)M * N / (512.0 * 256.0 * cus);            // in units of one 32-row-per-TMW tile slice
+  int best = 8; double best_cost = 1e30;
+  for (int t = 8; t >= 5; --t) {
+    const long tiles = (long)((M + 32 * t - 1) / (32 * t)) * tiles_n;
+    const double cost = (double)((tiles + cus - 1) / cus) * t / 16.0;
+    if (cost < best_cost - 1e-9) { best_cost = cost; best = t; }
+  }
+  if (eff) *eff = ideal / best_cost;
+  return best;
+}
+template <int TMW, int V>
+static void launch_nt256(const GemmNT& p, hipStream_t stream) {
+  static bool raised = false;
+  if (!raised) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt256_kernel<TMW, V>), hipFuncAttributeMaxDynamicSharedMemorySize, N2_LDS_BYTES);
+    raised = true;
+  }
+  const int tiles = ((p.M + 32 * TMW - 1) / (32 * TMW)) * ((p.N + 255) / 256);
+  hipLaunchKernelGGL((gemm_nt256_kernel<TMW, V>), dim3(tiles), dim3(512), N2_LDS_BYTES, stream, p);
+}
+template <int V>
+static void launch_nt256_h(const GemmNT& p, int tmw, hipStream_t stream) {
+  switch (tmw) {
+    case 5: launch_nt256<5, V>(p, stream); break;
+    case 6: launch_nt256<6, V>(p, stream); break;
+    case 7: launch_nt256<7, V>(p, stream); break;
+    default: launch_nt256<8, V>(p, stream); break;
+  }
 }
 
 // one NT launch: LDS = two stages of a (32 * TM) x 64 A tile + a 128 x 64 B tile; above 64 KB the limit is raised once
@@ -570,7 +769,40 @@ extern "C" int x2_gemm_nt(const void* A, const void* B, void* C, int M, int N, i
   // measured (probes/bench_gemm.py): two independent 4-wave workgroups per CU beat one 8-wave workgroup with a
   // 3-deep ring on every shape of this model (676 vs 583 TFLOP/s on 12608x2304x768), so auto = 128x128
   const bool big = g_tune[1] == 2;
-  if (big) {
+  // epilogue variant (EpiTraits): the feature sets the step uses are compiled separately, anything else runs the generic one
+  int var = 4;
+  {
+    const bool plain = !gamma && !rowscale && !drop_thr16 && !colsum;
+    if (g_tune[6] == 1) var = 4;                                                     // probes / tests: force the generic epilogue
+    else if (act == 1 && !out_f32 && !resid && plain) var = 2;
+    else if (act == 2 && !out_f32 && !resid && plain) var = 3;
+    else if (act == 0 && !aux && !resid && plain) var = out_f32 ? 1 : 0;
+    else if (act == 0 && !aux && resid && out_f32 && !gamma && !rowscale && !colsum) var = 5;
+    else if (act == 0 && aux && resid && out_f32 && gamma && !drop_thr16 && !colsum) var = 6;
+  }
+  // 256-column kernel (gemm_nt256_kernel): [1] = 3 always (tile height from [3] = 5..8 or the plan), [1] = 1 never; the
+  // generic feature set stays on the kernels above
+  double eff256 = 0.0;
+  int tmw = nt256_plan(M, N, &eff256);
+  if (g_tune[3] >= 5 && g_tune[3] <= 8) tmw = g_tune[3];
+  // Automatic choice ([1] = 0), from the per-shape A/B of probes/bench_nt256.py (profiles/r03b_nt256_per_shape.txt): with one
+  // workgroup per CU nothing covers a tile's load prologue and its epilogue, so the 256-column kernel wins where those are
+  // a small part of the tile - long contractions (K >= 2048: 1.19 vs 1.07 PFLOP/s main loops) or single-output bf16 / fp32
+  // epilogues - and its plan fills >= 80 % of the CU rounds; never for the short fp32 + residual launches of the text rows.
+  const bool light = var == 0 || var == 1;
+  const bool auto256 = (light || K >= 2048) && eff256 * 100.0 >= (g_tune_x[1] > 0 ? g_tune_x[1] : 80) && !(resid && M < 8192);
+  const bool use256 = var != 4 && N % 8 == 0 && (g_tune[1] == 3 || ((g_tune[1] == 0 || g_tune[1] == 4) && g_tune[3] == 0 && auto256));
+  if (use256) {
+    p.dbg &= ~64;
+    switch (var) {
+      case 0: launch_nt256_h<0>(p, tmw, (hipStream_t)stream); break;
+      case 1: launch_nt256_h<1>(p, tmw, (hipStream_t)stream); break;
+      case 2: launch_nt256_h<2>(p, tmw, (hipStream_t)stream); break;
+      case 3: launch_nt256_h<3>(p, tmw, (hipStream_t)stream); break;
+      case 5: launch_nt256_h<5>(p, tmw, (hipStream_t)stream); break;
+      default: launch_nt256_h<6>(p, tmw, (hipStream_t)stream); break;
+    }
+  } else if (big) {
     static bool attr_set = false;
     if (!attr_set) {
       hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_w8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, W8_LDS_BYTES);
@@ -597,15 +829,6 @@ extern "C" int x2_gemm_nt(const void* A, const void* B, void* C, int M, int N, i
     // (balanced would be 148): x2_tune(7, 1) switches the rule off
     const int t160 = ((M + 159) / 160) * ((N + BN - 1) / BN);
     const bool use160 = g_tune[3] == 4 || (use192 && g_tune[3] == 0 && g_tune[7] != 1 && t160 <= slots);
-    // epilogue variant (EpiTraits): the feature sets the step uses are compiled separately, anything else runs the generic one
-    int var = 4;
-    const bool plain = !gamma && !rowscale && !drop_thr16 && !colsum;
-    if (g_tune[6] == 1) var = 4;                                                     // probes / tests: force the generic epilogue
-    else if (act == 1 && !out_f32 && !resid && plain) var = 2;
-    else if (act == 2 && !out_f32 && !resid && plain) var = 3;
-    else if (act == 0 && !aux && !resid && plain) var = out_f32 ? 1 : 0;
-    else if (act == 0 && !aux && resid && out_f32 && !gamma && !rowscale && !colsum) var = 5;
-    else if (act == 0 && aux && resid && out_f32 && gamma && !drop_thr16 && !colsum) var = 6;
     // [2] & 64: row-contiguous stores for the fp32-out feature sets (nt_epilogue_f4)
     const bool f4 = (g_tune[2] & 64) != 0 && (var == 1 || var == 5 || var == 6);
 #define X2_NT_LAUNCH(V, SW)                                                                          \
@@ -627,6 +850,28 @@ extern "C" int x2_gemm_nt(const void* A, const void* B, void* C, int M, int N, i
 #undef X2_NT_LAUNCH
   }
   return x2_check_launch("x2_gemm_nt");
+}
+
+// C = (A . B^T) x GELU'(aux) -> bf16 (epilogue variant 10) plus the column sums of C as partial rows: colparts[r][N], r <
+// *nrows_out = 2 x row tiles of the launch (a row past the last wave row that holds data is all zeros); the caller adds
+// them up with x2_reduce_partials(_multi)(colparts, *nrows_out, 1, N, out).  colparts must hold 2 * ceil(M / 64) rows.
+// Input gradient through the GELU of the MLPs + the bias gradient of fc1 / intermediate.dense (beit2.py:62-66, xbert.py:497).
+extern "C" int x2_gemm_nt_dgelu_colparts(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
+                                         const void* aux, int ldaux, float* colparts, int* nrows_out, void* stream) {
+  X2_REQUIRE(A && B && C && aux && colparts && nrows_out, "x2_gemm_nt_dgelu_colparts: null argument");
+  X2_REQUIRE(M > 0 && N > 0 && K > 0 && K % BK == 0 && N % 8 == 0, "x2_gemm_nt_dgelu_colparts: M=%d N=%d K=%d", M, N, K);
+  X2_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && ldc % 8 == 0 && ldaux % 8 == 0, "x2_gemm_nt_dgelu_colparts: leading dims must keep 16-byte rows");
+  GemmNT p{(const bf16_t*)A, (const bf16_t*)B, C, nullptr, nullptr, nullptr, (bf16_t*)aux, M, N, K, lda, ldb, ldc, 0, ldaux, 2, 0,
+           g_tune[0] > 0 ? g_tune[0] : 8, DropSpec{0u, 0u, 1.f}, nullptr, nullptr, colparts, 0, 0, 0};
+  // the tile rule of x2_gemm_nt for this feature set (never the 160-row tile: it exists to balance N = 768 outputs)
+  const int tiles_n = (N + BN - 1) / BN, t128 = ((M + 127) / 128) * tiles_n, t192 = ((M + 191) / 192) * tiles_n, t64 = ((M + 63) / 64) * tiles_n;
+  const int slots = 2 * x2_cus();
+  const bool use64 = g_tune[3] == 3 || (g_tune[3] == 0 && (t128 <= slots || (t128 <= slots + slots / 6 && K <= 1024)));
+  const bool use192 = !use64 && (g_tune[3] == 2 || (g_tune[3] == 0 && t128 > slots && t192 <= slots));
+  if (use64) { launch_nt<2, 10, false>(p, t64, (hipStream_t)stream); *nrows_out = 2 * ((M + 63) / 64); }
+  else if (use192) { launch_nt<6, 10, false>(p, t192, (hipStream_t)stream); *nrows_out = 2 * ((M + 191) / 192); }
+  else { launch_nt<4, 10, false>(p, t128, (hipStream_t)stream); *nrows_out = 2 * ((M + 127) / 128); }
+  return x2_check_launch("x2_gemm_nt_dgelu_colparts");
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -326,6 +326,58 @@ extern "C" int x2_sample_negatives(const float* sim, int n, const long* group, c
   return x2_check_launch("x2_sample_negatives");
 }
 
+// ------------------------------------------------------------------------------------ attention-mask / K-V sharing tables
+// out[s][l] = (1 - atts[s][l]) * neg for l < L, 0 in the pad columns L..Lp-1: the additive key mask of BertModel
+// (get_extended_attention_mask: neg = -10000; invert_attention_mask: -1e9; xbert.py:1105-1160) in the padded fp32 layout the
+// attention kernels read.  One launch instead of five elementwise torch kernels per mask.
+__global__ __launch_bounds__(256) void additive_mask_kernel(const long* __restrict__ atts, float* __restrict__ out, int S, int L, int Lp, float neg) {
+  const long e = blockIdx.x * 256L + threadIdx.x;
+  if (e >= (long)S * Lp) return;
+  const int s_ = (int)(e / Lp), l = (int)(e % Lp);
+  out[e] = l < L ? (1.0f - (float)atts[(long)s_ * L + l]) * neg : 0.f;
+}
+extern "C" int x2_additive_mask(const long* atts, float* out, int S, int L, int Lp, float neg, void* stream) {
+  X2_REQUIRE(atts && out && S > 0 && L > 0 && Lp >= L, "x2_additive_mask: S=%d L=%d Lp=%d", S, L, Lp);
+  hipLaunchKernelGGL(additive_mask_kernel, dim3((unsigned)(((long)S * Lp + 255) / 256)), dim3(256), 0, (hipStream_t)stream, atts, out, S, L, Lp, neg);
+  return x2_check_launch("x2_additive_mask");
+}
+// CSR of "which query sequences use K/V batch b" from kv[s] (s < S, values in [0, Bi)): off[Bi + 1], order[S] = the sequence
+// ids grouped by kv value, ascending inside a group (a stable counting sort: the same tables on every run).  Replaces
+// argsort + scatter_add + cumsum (a dozen launches) - kv changes every step with the sampled hard negatives.  One workgroup.
+__global__ __launch_bounds__(256) void kv_csr_kernel(const int* __restrict__ kv, int S, int Bi, int* __restrict__ off, int* __restrict__ order) {
+  extern __shared__ int cnt[];                      // [Bi + 1]
+  __shared__ int part[256];
+  for (int b = threadIdx.x; b <= Bi; b += 256) cnt[b] = 0;
+  __syncthreads();
+  for (int e = threadIdx.x; e < S; e += 256) atomicAdd(&cnt[kv[e]], 1);
+  __syncthreads();
+  // exclusive scan of cnt[0..Bi): every thread sums a chunk, thread 0 scans the 256 chunk totals, chunks are rewritten
+  const int per = (Bi + 255) / 256, b0 = threadIdx.x * per, b1 = min(Bi, b0 + per);
+  int sum = 0;
+  for (int b = b0; b < b1; ++b) sum += cnt[b];
+  part[threadIdx.x] = sum;
+  __syncthreads();
+  if (threadIdx.x == 0) { int run = 0; for (int t = 0; t < 256; ++t) { const int v = part[t]; part[t] = run; run += v; } }
+  __syncthreads();
+  int run = part[threadIdx.x];
+  for (int b = b0; b < b1; ++b) { const int v = cnt[b]; cnt[b] = run; run += v; }
+  __syncthreads();
+  if (threadIdx.x == 0) cnt[Bi] = S;
+  __syncthreads();
+  for (int b = threadIdx.x; b <= Bi; b += 256) off[b] = cnt[b];
+  // thread per K/V batch walks the sequences in increasing order: stable
+  for (int b = threadIdx.x; b < Bi; b += 256) {
+    int pos = cnt[b];
+    const int end = cnt[b + 1];
+    for (int e = 0; e < S && pos < end; ++e) if (kv[e] == b) order[pos++] = e;
+  }
+}
+extern "C" int x2_kv_csr(const int* kv, int S, int Bi, int* off, int* order, void* stream) {
+  X2_REQUIRE(kv && off && order && S > 0 && Bi > 0 && Bi <= 8192, "x2_kv_csr: S=%d Bi=%d (Bi <= 8192)", S, Bi);
+  hipLaunchKernelGGL(kv_csr_kernel, dim3(1), dim3(256), (size_t)(Bi + 1) * sizeof(int), (hipStream_t)stream, kv, S, Bi, off, order);
+  return x2_check_launch("x2_kv_csr");
+}
+
 // ------------------------------------------------------------------------------------ elementwise
 // y = gelu(x) (fp32, exact erf) and its backward dx = dy * gelu'(x); used by the two small MLP heads
 __global__ __launch_bounds__(256) void gelu_f32_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* out, long n) {

@@ -181,6 +181,12 @@ class WeightBank:
 BANK = WeightBank()
 SPLIT_DECODER_DGRAD = os.environ.get("X2_SPLIT_DECODER_DGRAD", "1") == "1"     # A/B switches (probes/run_ab3.sh)
 FUSED_MLM_CE = os.environ.get("X2_FUSED_MLM_CE", "1") == "1"
+FUSE_DGELU_COLSUM = os.environ.get("X2_FUSE_DGELU_COLSUM", "1") == "1"       # fc1 / intermediate bias gradient from the GELU' GEMM's epilogue
+# layer-scale backward inside the LayerNorm backward that feeds it (x2_layernorm_bwd_layerscale).  Measured in the step (same
+# box, profiles/r03c_ab_switches.txt): 25.16 ms with it, 24.92 without - the fused kernel needs 156 VGPRs (3 waves per SIMD
+# instead of 4) and the HBM-bound LayerNorm backward loses more to the lower occupancy than the saved 38.7 MB read and
+# launch give back.  Off by default; the kernel stays (parity-tested) for a register-leaner rewrite.
+FUSE_LAYERSCALE_BWD = os.environ.get("X2_FUSE_LAYERSCALE_BWD", "0") == "1"
 KEEP_MLM_LOGITS = False     # tests: also materialise the MLM logits (inspection only; the loss still comes from the fused path)
 # Tied decoder / word-embedding gradient in ONE buffer (graph.SegmentedStep switches it on for its passes): the MLM head's
 # backward parks its [V, Hd] weight gradient here instead of handing it to autograd, and the embedding backward - which
@@ -289,8 +295,10 @@ SIDE = SideStream()
 
 
 def _begin_layer_backward():
-    """Collect the layer's stage-2 parameter-gradient reductions instead of launching them in line."""
-    K.DEFERRED = [] if (SIDE.enabled and torch.cuda.is_available()) else None
+    """Collect the layer's stage-2 parameter-gradient reductions instead of launching them in line: they go out as ONE
+    multi-tensor launch per layer (pair) in front of its weight-gradient GEMMs - on the side stream when there is one,
+    in line otherwise (single-stream hipGraph segments: 170 reduction launches per base step became 15)."""
+    K.DEFERRED = [] if torch.cuda.is_available() else None
 
 
 class _LayerPairs:
@@ -458,6 +466,7 @@ class VisionEncoderFn(torch.autograd.Function):
         F4 = p["blocks.0.mlp.fc1.weight"].shape[0]
         dpath = meta.get("drop_path")
         pairs = _LayerPairs()
+        dy2_fused = None
         for i in reversed(range(meta["depth"])):
             b = "blocks.%d." % i
             rs1, rs2 = dpath[i] if dpath is not None else (None, None)
@@ -475,12 +484,25 @@ class VisionEncoderFn(torch.autograd.Function):
             _, w1T = BANK.linear(p[b + "mlp.fc1.weight"])
             _, wprojT = BANK.linear(p[b + "attn.proj.weight"])
             _, wqkvT = BANK.linear(p[b + "attn.qkv.weight"])
-            dy2 = K.layerscale_bwd(dx, aux2, p[b + "gamma_2"], G["gamma_2"], G["mlp.fc2.bias"], rowscale=rs2)
-            dpre = K.gemm_nt(dy2, w2T, aux=pre, act=2)
-            K.colsum_bf16(dpre, G["mlp.fc1.bias"])        # two-stage sums: 20 us; fused into the GEMM epilogue (atomics) 30 us
+            # dy2 = gamma_2 * DropPath * dx comes from the LayerNorm backward that produced dx (norm1 of the block above, fused
+            # below); only the topmost block, whose dx comes from fc_norm, runs the stand-alone layer-scale backward
+            if dy2_fused is None:
+                dy2 = K.layerscale_bwd(dx, aux2, p[b + "gamma_2"], G["gamma_2"], G["mlp.fc2.bias"], rowscale=rs2)
+            else:
+                dy2, (ws_, nblk_) = dy2_fused
+                K.DEFERRED.append((ws_, nblk_, 4, D, (None, None, G["gamma_2"], G["mlp.fc2.bias"])))
+            if FUSE_DGELU_COLSUM:     # fc1's bias gradient as per-wave partial rows from the GEMM epilogue (no pass over dpre, no atomics)
+                dpre = K.gemm_nt_dgelu_colsum(dy2, w2T, pre, G["mlp.fc1.bias"])
+            else:
+                dpre = K.gemm_nt(dy2, w2T, aux=pre, act=2)
+                K.colsum_bf16(dpre, G["mlp.fc1.bias"])    # two-stage sums: 20 us; fused into the GEMM epilogue with atomics: 30 us
             dh2 = K.gemm_nt(dpre, w1T)            # bf16, like the fp16 grad_input of the reference's O1 linears: half the bytes
-            dx1, _ = K.layernorm_bwd(dh2, x1, mean2, rstd2, p[b + "norm2.weight"], G["norm2.weight"], G["norm2.bias"], dres=dx)
-            dy1 = K.layerscale_bwd(dx1, aux1, p[b + "gamma_1"], G["gamma_1"], G["attn.proj.bias"], rowscale=rs1)
+            if FUSE_LAYERSCALE_BWD:
+                dx1, dy1, _ = K.layernorm_bwd_layerscale(dh2, x1, mean2, rstd2, p[b + "norm2.weight"], G["norm2.weight"], G["norm2.bias"], dx,
+                                                         aux1, p[b + "gamma_1"], G["gamma_1"], G["attn.proj.bias"], rowscale=rs1)
+            else:
+                dx1, _ = K.layernorm_bwd(dh2, x1, mean2, rstd2, p[b + "norm2.weight"], G["norm2.weight"], G["norm2.bias"], dres=dx)
+                dy1 = K.layerscale_bwd(dx1, aux1, p[b + "gamma_1"], G["gamma_1"], G["attn.proj.bias"], rowscale=rs1)
             datt = K.gemm_nt(dy1, wprojT)
             dqkv = torch.empty_like(qkv)
             delta = torch.empty_like(lse)
@@ -492,7 +514,16 @@ class VisionEncoderFn(torch.autograd.Function):
             G.alias("attn.q_bias", G["qkv_bias"][:D])
             G.alias("attn.v_bias", G["qkv_bias"][2 * D:])
             dh1 = K.gemm_nt(dqkv, wqkvT)
-            dxn, _ = K.layernorm_bwd(dh1, x, mean1, rstd1, p[b + "norm1.weight"], G["norm1.weight"], G["norm1.bias"], dres=dx1)
+            dy2_fused = None
+            if FUSE_LAYERSCALE_BWD and i > 0 and K.DEFERRED is not None:
+                # the block below's MLP branch: its gamma_2 / fc2-bias sums are registered with ITS arena in the next iteration
+                bb = "blocks.%d." % (i - 1)
+                rs2b = dpath[i - 1][1] if dpath is not None else None
+                dxn, dyb, pend = K.layernorm_bwd_layerscale(dh1, x, mean1, rstd1, p[b + "norm1.weight"], G["norm1.weight"], G["norm1.bias"], dx1,
+                                                            ctx.saved[i - 1][16], p[bb + "gamma_2"], rowscale=rs2b)
+                dy2_fused = (dyb, pend)
+            else:
+                dxn, _ = K.layernorm_bwd(dh1, x, mean1, rstd1, p[b + "norm1.weight"], G["norm1.weight"], G["norm1.bias"], dres=dx1)
             tn = [(dy2, act, G["mlp.fc2.weight"]), (dpre, h2, G["mlp.fc1.weight"]),
                   (dy1, att, G["attn.proj.weight"]), (dqkv, h1, G["attn.qkv.weight"])]
             pairs.add(G, tn)
@@ -670,8 +701,11 @@ class BertLayersFn(torch.autograd.Function):
                                         drop_out=BertLayersFn._drop(meta, i, 4))
             _, woutT = BANK.linear(p[b + "output.dense.weight"])
             _, wiT = BANK.linear(p[b + "intermediate.dense.weight"])
-            dpre = K.gemm_nt(ds3b, woutT, aux=pre, act=2)
-            K.colsum_bf16(dpre, G["intermediate.dense.bias"])
+            if FUSE_DGELU_COLSUM:
+                dpre = K.gemm_nt_dgelu_colsum(ds3b, woutT, pre, G["intermediate.dense.bias"])
+            else:
+                dpre = K.gemm_nt(ds3b, woutT, aux=pre, act=2)
+                K.colsum_bf16(dpre, G["intermediate.dense.bias"])
             dh2 = K.gemm_nt(dpre, wiT, resid=ds3, out_dtype=F32)
             tn += [(ds3b, act, G["output.dense.weight"]), (dpre, h2b, G["intermediate.dense.weight"])]
             if cr is not None:

@@ -145,12 +145,16 @@ class SegmentedStep:
     GraphedStep.copy_inputs.  Falls back to eager execution of the same segments when capture is disabled or fails."""
 
     def __init__(self, model, batch, world=1, rank=0, process_group=None, comm=None, warmup=2, enabled=True, verbose=False,
-                 ret_bbox_loss=False, ret_match_loss=True, recast_weights=True, clamp_temp=True, total_loss=None):
+                 ret_bbox_loss=False, ret_match_loss=True, recast_weights=True, clamp_temp=True, total_loss=None, side_stream=None):
+        """side_stream: weight-gradient GEMMs of the stream-A segments (tail, vision backward) on engine.SIDE, forked from and
+        joined into stream A inside the segment.  Those segments then replay node by node (~15 us of host time each, still
+        well under the GPU time of a step) but keep the 3 % the side stream is worth on one GPU.  Default: X2_SEG_SIDE or off."""
         from . import engine
         self.engine = engine
         self.model, self.batch, self.world, self.rank, self.pg, self.comm = model, batch, world, rank, process_group, comm
         self.ret_bbox_loss, self.ret_match_loss = ret_bbox_loss, ret_match_loss
         self.recast_weights, self.clamp_temp = recast_weights, clamp_temp
+        self.side_stream = (os.environ.get("X2_SEG_SIDE", "0") == "1") if side_stream is None else bool(side_stream)
         self.total_loss = total_loss or (lambda losses: sum(losses.values()))
         self.sA, self.sB = torch.cuda.Stream(), torch.cuda.Stream()
         self.sC = torch.cuda.Stream() if world > 1 else None
@@ -171,7 +175,7 @@ class SegmentedStep:
             K.DROP_EPOCH = torch.zeros(1, dtype=torch.int32, device=dev)
         cur = torch.cuda.current_stream()
         self.sA.wait_stream(cur)
-        side, tie, hook = engine.SIDE.enabled, engine.TIE_WORD_GRAD, engine.GRAD_READY_HOOK
+        side, tie, hook, rule = engine.SIDE.enabled, engine.TIE_WORD_GRAD, engine.GRAD_READY_HOOK, engine.SIDE.only_from
         engine.GRAD_READY_HOOK = None             # an accelerator's early all-reduce hook must not fire from these passes
         try:
             for _ in range(max(warmup, 1)):       # eager, on the segments' own streams: caches, workspaces, allocator pools
@@ -180,7 +184,7 @@ class SegmentedStep:
             if enabled and os.environ.get("X2_GRAPH", "1") != "0":
                 self._capture(verbose)
         finally:
-            engine.SIDE.enabled, engine.TIE_WORD_GRAD, engine.GRAD_READY_HOOK = side, tie, hook
+            engine.SIDE.enabled, engine.TIE_WORD_GRAD, engine.GRAD_READY_HOOK, engine.SIDE.only_from = side, tie, hook, rule
         cur.wait_stream(self.sA)
 
     # ------------------------------------------------------------------ set-up
@@ -290,7 +294,10 @@ class SegmentedStep:
         if mode == "capture":
             pa, pb = self._pools
         if mode != "replay":
-            eng.SIDE.enabled = False          # linear segments: weight-gradient GEMMs in line (the other tower fills the CUs)
+            # linear segments: weight-gradient GEMMs in line (the other tower fills the CUs) - unless side_stream asks for the
+            # fork / join form on stream A, the capture origin of its segments (engine.SideStream.only_from)
+            eng.SIDE.enabled = self.side_stream
+            eng.SIDE.only_from = self.sA.cuda_stream
             eng.TIE_WORD_GRAD = True
             if self.recast_weights:
                 eng.BANK.invalidate()         # as after an optimizer step: fp32 master weights are re-cast inside the step
@@ -419,7 +426,7 @@ class SegmentedStep:
             self._run("replay")
         else:
             eng = self.engine
-            side, tie, hook = eng.SIDE.enabled, eng.TIE_WORD_GRAD, eng.GRAD_READY_HOOK
+            side, tie, hook, rule = eng.SIDE.enabled, eng.TIE_WORD_GRAD, eng.GRAD_READY_HOOK, eng.SIDE.only_from
             eng.GRAD_READY_HOOK = None
             try:
                 self._run("eager")
@@ -427,7 +434,7 @@ class SegmentedStep:
                     with torch.cuda.stream(self.sA):
                         self._reduce_eager_fallback()
             finally:
-                eng.SIDE.enabled, eng.TIE_WORD_GRAD, eng.GRAD_READY_HOOK = side, tie, hook
+                eng.SIDE.enabled, eng.TIE_WORD_GRAD, eng.GRAD_READY_HOOK, eng.SIDE.only_from = side, tie, hook, rule
         cur.wait_stream(self.sA)
         return self.t["loss"]
 

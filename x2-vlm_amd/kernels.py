@@ -104,10 +104,10 @@ def reduce_partials(ws, nblk, nk, width, outs):
 
 
 def reduce_partials_multi(items):
-    """Several stage-2 reductions (tuples as collected in DEFERRED) in one launch."""
+    """Several stage-2 reductions (tuples as collected in DEFERRED; up to 4 outputs each) in one launch."""
     flat = []
     for ws, nblk, nk, width, outs in items:
-        o = list(outs) + [None] * (3 - len(outs))
+        o = list(outs) + [None] * (4 - len(outs))
         flat += [ws.data_ptr(), nblk, nk, width] + [0 if t is None else t.data_ptr() for t in o]
     call("x2_reduce_partials_multi", (C.c_int64 * len(flat))(*flat), len(items))
 
@@ -155,6 +155,27 @@ def gemm_nt(A, B, *, bias=None, gamma=None, resid=None, aux=None, act=0, out=Non
         call("x2_gemm_nt", ptr(A), ptr(B), ptr(out), M, N, K, _rows(A), _rows(B), _rows(out), ptr(bias), ptr(gamma),
              ptr(resid), _rows(resid) if resid is not None else 0, ptr(aux), _rows(aux) if aux is not None else 0,
              act, 1 if out.dtype == F32 else 0, drop[0], drop[1], drop[2], ptr(drop[3]), ptr(rowscale), ptr(colsum))
+    return out
+
+
+def gemm_nt_dgelu_colsum(A, B, pre, colsum):
+    """out[M,N] bf16 = (A @ B^T) * GELU'(pre) and colsum[N] += column sums of out: the GELU input gradient of an MLP and
+    the bias gradient of its first linear from ONE kernel (epilogue variant 10: one partial row per wave row, reduced with the
+    layer's other deferred reductions or right here)."""
+    assert A.dtype == BF16 and B.dtype == BF16 and A.shape[1] == B.shape[1] and pre.dtype == BF16
+    M, K = A.shape
+    N = B.shape[0]
+    assert pre.shape == (M, N) and colsum.dtype == F32 and colsum.numel() == N
+    out = torch.empty(M, N, device=A.device, dtype=BF16)
+    ws, defer = _ws_and_defer(A.device, 2 * ((M + 63) // 64) * N)
+    nrows = C.c_int(0)
+    with _timed(2.0 * M * N * K):
+        call("x2_gemm_nt_dgelu_colparts", ptr(A), ptr(B), ptr(out), M, N, K, _rows(A), _rows(B), _rows(out), ptr(pre), _rows(pre),
+             ptr(ws), C.byref(nrows))
+    if defer:
+        DEFERRED.append((ws, nrows.value, 1, N, (colsum,)))
+    else:
+        reduce_partials(ws, nrows.value, 1, N, (colsum,))
     return out
 
 
@@ -296,6 +317,29 @@ def layernorm_bwd(dy, x, mean, rstd, w, dw, db, *, dres=None, dcol=None, period=
     if defer:
         DEFERRED.append((ws, nblk, 3, D, (dw, db, dcol)))
     return dx, dxb
+
+
+def layernorm_bwd_layerscale(dy, x, mean, rstd, w, dw, db, dres, u, gamma, dgamma=None, dbias=None, rowscale=None):
+    """LayerNorm backward whose result leaves through a layer-scale branch as well (BEiT blocks): returns (dx fp32 = dres +
+    LN-input gradient, du bf16 = gamma * rowscale * dx, pending); dw / db (LayerNorm) are accumulated, and so are dgamma /
+    dbias (layer scale, bias of the branch's last linear) when given.  dgamma = None (only while a layer's reductions are
+    being deferred): the layer-scale sums belong to ANOTHER layer's gradient arena that does not exist yet - `pending` =
+    (ws, nblk) lets the caller register them later: DEFERRED.append((ws, nblk, 4, D, (None, None, dgamma, dbias))).
+    = layernorm_bwd followed by layerscale_bwd in one pass over the rows."""
+    assert dy.dtype in (F32, BF16) and x.dtype == F32 and dy.is_contiguous() and x.is_contiguous() and u.dtype == BF16 and u.is_contiguous()
+    D = x.shape[-1]
+    R = mean.numel()
+    assert x.numel() == R * D and u.numel() == x.numel() and (dres is None or dres.numel() == x.numel())
+    assert dgamma is not None or DEFERRED is not None
+    dx = torch.empty_like(x)
+    du = torch.empty_like(u)
+    nblk = (R + 15) // 16
+    ws, defer = _ws_and_defer(x.device, nblk * 4 * D)
+    call("x2_layernorm_bwd_layerscale", ptr(dy), 1 if dy.dtype == BF16 else 0, ptr(x), ptr(mean), ptr(rstd), ptr(w), ptr(dres), ptr(dx),
+         ptr(dw), ptr(db), ptr(u), ptr(gamma), ptr(rowscale), ptr(du), ptr(dgamma), ptr(dbias), R, D, ptr(ws), defer)
+    if defer:
+        DEFERRED.append((ws, nblk, 4, D, (dw, db, dgamma, dbias)))
+    return dx, du, (ws, nblk)
 
 
 def colsum_bf16(y, out):
@@ -530,6 +574,26 @@ def sample_negatives(sim, u, group=None):
     out = torch.empty(n, device=sim.device, dtype=torch.int32)
     call("x2_sample_negatives", ptr(sim), n, ptr(group), ptr(u), ptr(out))
     return out
+
+
+def additive_mask(atts, neg):
+    """[S, L] 0/1 attention mask (int64) -> [S, round_up(L, 64)] fp32 additive key mask (1 - m) * neg, pad columns 0."""
+    assert atts.dtype == torch.int64 and atts.dim() == 2 and atts.is_contiguous()
+    S, L = atts.shape
+    out = torch.empty(S, round_up(L, 64), device=atts.device, dtype=F32)
+    call("x2_additive_mask", ptr(atts), ptr(out), S, L, out.shape[1], float(neg))
+    return out
+
+
+def kv_csr(kv, Bi):
+    """kv int32 [S] (K/V batch of every query sequence) -> (off int32 [Bi + 1], order int32 [S]): the sequences grouped by the
+    K/V batch they use, ascending inside a group."""
+    assert kv.dtype == torch.int32 and kv.dim() == 1 and kv.is_contiguous()
+    S = kv.numel()
+    off = torch.empty(Bi + 1, device=kv.device, dtype=torch.int32)
+    order = torch.empty(S, device=kv.device, dtype=torch.int32)
+    call("x2_kv_csr", ptr(kv), S, Bi, ptr(off), ptr(order))
+    return off, order
 
 
 def gelu_f32(x, dy=None):

@@ -18,6 +18,13 @@ from .engine import BertLayersFn, EmbeddingsFn, MlmLossFn, _mask_pad, bert_layer
 _FIXED_SEEDS = []
 
 
+def _key_mask(atts, neg):
+    """0/1 attention mask [S, L] -> additive fp32 key mask (1 - m) * neg in the attention kernels' padded layout."""
+    if atts.is_cuda and atts.dtype == torch.int64:
+        return K.additive_mask(atts.contiguous(), neg)
+    return _mask_pad((1.0 - atts.float()) * neg, atts.shape[1])
+
+
 def next_dropout_seed():
     """Per-call dropout seed from the host RNG (torch.manual_seed governs it; no device sync).
     Tests push explicit seeds onto _FIXED_SEEDS."""
@@ -126,23 +133,24 @@ class BertEncoder(nn.Module):
         if self.training and (cfg.hidden_dropout_prob > 0 or cfg.attention_probs_dropout_prob > 0):
             drop = dict(seed=next_dropout_seed(), p_hidden=cfg.hidden_dropout_prob, p_attn=cfg.attention_probs_dropout_prob)
         meta = dict(lo=lo, hi=hi, fusion_at=cfg.fusion_layer, heads=cfg.num_attention_heads, eps=cfg.layer_norm_eps,
-                    self_mask=_mask_pad((1.0 - text_atts.float()) * -10000.0, L), enc_mask=None, kv_idx=None,
+                    self_mask=_key_mask(text_atts, -10000.0), enc_mask=None, kv_idx=None,
                     seq_off=None, seq_ids=None, drop=drop)
         cross = enc is not None and hi > cfg.fusion_layer
         if cross:
-            Bi, T = enc.shape[0], enc.shape[1]
+            Bi = enc.shape[0]
             # transformers 4.12.5 invert_attention_mask, fp32 branch: (1 - m) * -1e9
-            meta["enc_mask"] = _mask_pad((1.0 - enc_atts.float()) * -1e9, T)
+            meta["enc_mask"] = _key_mask(enc_atts, -1e9)
             if kv_idx is None:
                 assert Bi == S, "encoder batch %d != text batch %d and no kv_idx given" % (Bi, S)
             else:
-                kv = kv_idx.to(torch.int32)
-                order = torch.argsort(kv, stable=True).to(torch.int32)
-                counts = torch.zeros(Bi, device=kv.device, dtype=torch.int32).scatter_add_(
-                    0, kv.long(), torch.ones_like(kv))
-                off = torch.zeros(Bi + 1, device=kv.device, dtype=torch.int32)
-                off[1:] = torch.cumsum(counts, 0)
-                meta.update(kv_idx=kv.contiguous(), seq_off=off, seq_ids=order.contiguous())
+                kv = kv_idx.to(torch.int32).contiguous()
+                if kv.is_cuda:
+                    off, order = K.kv_csr(kv, Bi)          # one launch: kv changes every step with the sampled negatives
+                else:
+                    order = torch.argsort(kv, stable=True).to(torch.int32).contiguous()
+                    off = torch.zeros(Bi + 1, device=kv.device, dtype=torch.int32)
+                    off[1:] = torch.cumsum(torch.bincount(kv, minlength=Bi), 0)
+                meta.update(kv_idx=kv, seq_off=off, seq_ids=order)
         cache = self.__dict__.setdefault("_param_lists", {})      # see beit2.VisionTransformer._params
         params = cache.get((lo, hi, cross))
         if params is None:
