@@ -123,7 +123,7 @@ def test_segmented_replay_is_the_eager_step(synthetic):
 
     step = graph.SegmentedStep(model, static, clamp_temp=False)
     assert step.mode == "hipgraph-segments", step.error
-    assert sorted(step.graphs) == ["F1", "F2", "T", "Tb", "V", "Vb"]
+    assert sorted(step.graphs) == ["F1", "F2", "Fw", "T", "Tb", "V", "Vb"]
     captured = [p.grad for p in params]                      # static tensors the segments write on every replay
     seen = []
     for i, b in enumerate(data):

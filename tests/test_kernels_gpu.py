@@ -548,15 +548,16 @@ def test_multi_tensor_cast_and_reduce(K):
         assert torch.equal(plain.cpu(), ref) and torch.equal(tr.cpu(), ref.t())
     assert len(bank._c) == len(groups)
     items, refs = [], []
-    for i, (nblk, nk, width) in enumerate([(37, 3, 768), (5, 1, 100), (200, 2, 3072)] * 7):
+    for i, (nblk, nk, width) in enumerate([(37, 3, 768), (5, 1, 100), (200, 2, 3072), (788, 4, 768), (13, 2, 30), (65, 1, 8)] * 4):
         part = rnd(nblk, nk, width, seed=100 + i).to(dev)
-        outs = tuple(torch.full((width,), float(k), device=dev) for k in range(nk))
+        # a null output (slot 1 of the 4-row sets) skips that partial row: how one workspace serves two gradient arenas
+        outs = tuple(None if (nk == 4 and k == 1) else torch.full((width,), float(k), device=dev) for k in range(nk))
         items.append((part, nblk, nk, width, outs))
         refs.append([part[:, k].double().sum(0).cpu() + k for k in range(nk)])
     K.reduce_partials_multi(items)
     for (part, nblk, nk, width, outs), ref in zip(items, refs):
         for o, r in zip(outs, ref):
-            assert relerr(o, r) < 1e-5
+            assert o is None or relerr(o, r) < 1e-5
 
 
 def test_linear_f32_split_k(K):

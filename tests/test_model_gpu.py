@@ -2,17 +2,20 @@
 Pretrain.py:59 / :90) against the golden vectors the REAL reference produced (tests/golden/*.npz),
 on identical seeded weights, batches and injected hard negatives.
 
-Tolerances (bf16 GEMM/attention operands, fp32 everything else, vs the reference's fp32 CPU run):
-  losses              1e-3 relative at the headline batch (case base_full_b64, BASELINE.json configs[1]:
-                      the north-star tolerance); 5e-3 for the 3..6-sample toy batches, whose losses
-                      average the same per-sample bf16 operand-rounding noise over 16x fewer samples
-  activations/logits  2.5e-2 of the tensor's max-abs pointwise (one bf16 rounding is 2^-9 of an element; ~36 GEMMs deep;
-                      measured 0.2-1.9e-2); 2e-3 for whole-tensor moments, 1e-3 for the MLM log-partition, 5e-3 for bbox
-                      coordinates (measured 6e-4, 7e-5, 1.7e-3)
-  parameter grads     per-tensor norm error <= 3e-2 of max(its norm, 1e-2 x total gradient norm): tensors whose
-                      true gradient is ~0 by cancellation (q/k projections of saturated attention, key biases)
-                      are held to 3e-4 of the total norm instead of to their own norm;
-                      total gradient norm within 1e-2 relative
+Tolerances (bf16 GEMM/attention operands, fp32 everything else, vs the reference's fp32 CPU run): each bound is ~1.3-2x the worst
+deviation measured over the ten cases on MI355X (profiles/r03d_parity_worst.txt), so that a regression shows:
+  losses              1e-3 relative at the headline batch (case base_full_b64, BASELINE.json configs[1]: the north-star
+                      tolerance; measured 6e-5); 5e-3 for the 2..8-sample toy batches, whose losses average the same per-sample
+                      bf16 operand-rounding noise over 16x fewer samples (measured 4.7e-3, tiny_video)
+  activations/logits  pointwise, of the tensor's max-abs (one bf16 rounding is 2^-9 of an element; ~36 GEMMs deep): vision tokens /
+                      features 8e-3 (4.7e-3), text tokens / features 1.6e-2 (1.1e-2), ITC / MLM logits 2e-2 (1.4e-2), ITM logits
+                      2.5e-2 (1.9e-2); whole-tensor moments 1e-3 (6.3e-4); MLM log-partition 2e-4 (9.7e-5); bbox coordinates 5e-3
+                      (3.7e-3 at the real geometry, case base_region)
+  parameter grads     per-tensor norm error <= 3e-2 of max(its norm, 1e-2 x total gradient norm) (measured 2.98e-2): tensors whose
+                      true gradient is ~0 by cancellation (q/k projections of saturated attention, key biases) are held to
+                      3e-4 of the total norm instead of to their own norm; small tensors stored in full: 4.5e-2 pointwise (3.0e-2);
+                      total gradient norm: 2e-3 at batch 64 (8.8e-4), 3e-3 for the other full-geometry cases (1.8e-3), 1.2e-2 for
+                      the 32-px toy models (8.7e-3)
 """
 import importlib
 import os
@@ -25,6 +28,9 @@ from cases import CASES, model_config, reduce_out
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
+# pointwise bounds per tensor, as a fraction of its max-abs (see the table above)
+POINTWISE = dict(mlm_lse=2e-4, bbox_coord=5e-3, image_embeds=8e-3, image_feat=8e-3, text_embeds=1.6e-2, text_feat=1.6e-2,
+                 itc_logits=2e-2, mlm_logits=2e-2, itm_logits=2.5e-2)
 
 
 def run_case(case, tmpdir, synthetic):
@@ -90,7 +96,7 @@ def test_step_matches_reference(case, tmp_path, synthetic):
         scale = max(np.abs(ref).max(), 1e-6)
         # whole-tensor moments and the MLM log-partition are averages over thousands of elements: held to ~1e-3;
         # bbox coordinates are sigmoid outputs of an fp32 head fed by one bf16 fusion pass
-        tol = 2e-3 if kind == "moments" else 1e-3 if name == "mlm_lse" else 5e-3 if name == "bbox_coord" else 2.5e-2
+        tol = 1e-3 if kind == "moments" else POINTWISE.get(name, 2.5e-2)
         report.append(("act " + name + "/" + kind, float(np.abs(got - ref).max() / scale), tol))
     sd = dict(model.named_parameters())
     total = float(gold["total_grad_norm"])
@@ -115,8 +121,8 @@ def test_step_matches_reference(case, tmp_path, synthetic):
             name = k[len("grad/"):]
             ref = gold[k].astype(np.float64)
             got = sd[name].grad.detach().cpu().double().numpy()
-            report.append(("grad " + name, float(np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-2 * total / max(ref.size, 1) ** 0.5)), 6e-2))
-    report.append(("total_grad_norm", abs(sq ** 0.5 - total) / total, 1e-2))
+            report.append(("grad " + name, float(np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-2 * total / max(ref.size, 1) ** 0.5)), 4.5e-2))
+    report.append(("total_grad_norm", abs(sq ** 0.5 - total) / total, 2e-3 if c["batch"] >= 64 else 1.2e-2 if c["image_res"] < 64 else 3e-3))
     worst = sorted(report, key=lambda r: -r[1] / r[2])[:12]
     print("\n[%s] worst deviations (value / tolerance):" % case)
     for name, err, tol in worst:

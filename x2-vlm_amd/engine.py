@@ -337,6 +337,15 @@ class _LayerPairs:
             if deferred:
                 K.reduce_partials_multi(deferred)
             K.gemm_tn_grouped(tn)
+        if WGRAD_QUEUE is not None:
+            # the caller (graph.SegmentedStep) runs this layer's parameter-gradient work later, in a segment of its own on another
+            # stream: the closure keeps the operands alive; the gradient views autograd receives now are filled then
+            def later():
+                work()
+                for G, _, _ in entries:
+                    G.publish(None)
+            WGRAD_QUEUE.append(later)
+            return
         keep = [t for pr in tn for t in pr[:2]] + [G.flat for G, _, _ in entries] + [d[0] for d in deferred]
         done = SIDE.launch(work, keep)
         for G, _, _ in entries:
@@ -349,6 +358,12 @@ def _finish_layer_backward(G, tn):
     _LayerPairs._launch([(G, tn, deferred)])
 
 
+# None, or a list that collects the weight-gradient work of every layer backward instead of launching it (closures: stage-2
+# reductions + grouped TN GEMM + arena publication).  graph.SegmentedStep sets it around the tail segment: the fusion layers'
+# weight gradients (1.3 ms of 256x256-tile GEMMs per base step) leave the step's critical path - they run as a segment of
+# their own on the text stream, concurrently with the vision tower's backward.  Only valid when nothing reads or accumulates
+# into those gradients before the queue has run (one contribution per parameter and step).
+WGRAD_QUEUE = None
 GRAD_READY_HOOK = None      # set by accelerator.GradientBuckets: f(flat_fp32_arena, key, side_stream_event, parameters)
 STAGE_CALLS = {}            # key -> number of forward calls since the last reset (see GradientBuckets)
 

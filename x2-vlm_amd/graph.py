@@ -125,6 +125,8 @@ class SegmentedStep:
                                              -- event ->                                         all-reduce(tail gradients)
         [Vb  vision tower backward]                        [Tb text tower backward]
                                                             -- event ->                          all-reduce(text gradients)
+                                                           [Fw weight gradients of the tail's fusion layers (queued by F2)]
+                                                            -- event ->                          all-reduce(fusion gradients)
          -- event ------------------------------------------------------------------------->     all-reduce(vision gradients)
         join B, C
 
@@ -155,6 +157,9 @@ class SegmentedStep:
         self.ret_bbox_loss, self.ret_match_loss = ret_bbox_loss, ret_match_loss
         self.recast_weights, self.clamp_temp = recast_weights, clamp_temp
         self.side_stream = (os.environ.get("X2_SEG_SIDE", "0") == "1") if side_stream is None else bool(side_stream)
+        # fusion-layer weight gradients as a segment of their own on stream B (engine.WGRAD_QUEUE); X2_SEG_TAIL_WGRAD=0: in line
+        self.defer_tail_wgrad = os.environ.get("X2_SEG_TAIL_WGRAD", "1") == "1"
+        self._queue = None
         self.total_loss = total_loss or (lambda losses: sum(losses.values()))
         self.sA, self.sB = torch.cuda.Stream(), torch.cuda.Stream()
         self.sC = torch.cuda.Stream() if world > 1 else None
@@ -287,6 +292,11 @@ class SegmentedStep:
     def _s_text_bwd(self):
         torch.autograd.backward([self.t["both"]], [self.t["both_leaf"].grad])
 
+    def _s_tail_wgrad(self):
+        work, self._queue = self._queue, None
+        for fn in work or ():
+            fn()
+
     # ------------------------------------------------------------------ one step
     def _run(self, mode):
         eng, A, Bs = self.engine, self.sA, self.sB
@@ -312,12 +322,20 @@ class SegmentedStep:
         self._seg(mode, "F1", A, self._s_feat, pa)
         with torch.cuda.stream(A):
             self._gather()
+        if mode != "replay":
+            eng.WGRAD_QUEUE = [] if self.defer_tail_wgrad else None
         self._seg(mode, "F2", A, self._s_loss, pa)
+        if mode != "replay":
+            self._queue, eng.WGRAD_QUEUE = eng.WGRAD_QUEUE, None
         Bs.wait_stream(A)
         self._reduce("F2", A)
         self._seg(mode, "Vb", A, self._s_vision_bwd, pa)
         self._seg(mode, "Tb", Bs, self._s_text_bwd, pb)
         self._reduce("Tb", Bs)
+        if self.defer_tail_wgrad:
+            # the tail's (fusion layers') weight gradients: off stream A's critical path, under the vision backward
+            self._seg(mode, "Fw", Bs, self._s_tail_wgrad, pb)
+            self._reduce("Fw", Bs)
         self._reduce("Vb", A)
         A.wait_stream(Bs)
         if self.sC is not None:
@@ -350,16 +368,24 @@ class SegmentedStep:
             return
         inside = lambda g, flat: flat.data_ptr() <= g.data_ptr() and g.data_ptr() + g.numel() * 4 <= flat.data_ptr() + flat.numel() * 4
         done = set()
-        for seg in ("F2", "Tb", "Vb"):
+        order = {"F2": 0, "Tb": 1, "Fw": 2, "Vb": 3}       # the order the reductions are issued in (_run)
+        # a gradient is complete after the later of: the segment whose autograd pass last wrote .grad, the segment that
+        # published its arena (deferred weight-gradient work fills the views after autograd has handed them over)
+        ready = dict(self._touch)
+        for s, flat, params in self._arenas:
+            for p in params:
+                if id(p) in ready and order[s] > order[ready[id(p)]]:
+                    ready[id(p)] = s
+        for seg in ("F2", "Tb", "Fw", "Vb"):
             whole = []
             for s, flat, params in self._arenas:
                 # an arena goes as one message when every gradient it was published for still lives in it (autograd adopted
-                # the views) and this segment is the last to write any of them
-                if params and all(id(p) not in done and p.grad is not None and inside(p.grad, flat) and self._touch.get(id(p)) == seg
+                # the views) and all of them are complete after this segment
+                if params and all(id(p) not in done and p.grad is not None and inside(p.grad, flat) and ready.get(id(p)) == seg
                                   for p in params):
                     whole.append(flat)
                     done.update(id(p) for p in params)
-            rest = [p for p in self.params if p.grad is not None and id(p) not in done and self._touch.get(id(p)) == seg]
+            rest = [p for p in self.params if p.grad is not None and id(p) not in done and ready.get(id(p)) == seg]
             done.update(id(p) for p in rest)
             big = [p.grad for p in rest if p.grad.numel() >= (1 << 20) and p.grad.is_contiguous()]
             small = [p for p in rest if not (p.grad.numel() >= (1 << 20) and p.grad.is_contiguous())]
