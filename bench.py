@@ -35,6 +35,14 @@ CONFIGS = {
                   metric="image-text pairs/sec (fwd+bwd) X2VLM-large 384px bs=32/GPU",
                   workload="X2VLM-large (BEiT2-large 24 blocks + BERT-large-12l 12+6, 593M) pre-training step fwd+bwd, "
                            "ITC+ITM+MLM, 384px"),
+    # the region / bbox iteration (Pretrain.run_region_iter, Pretrain.py:79-111) at configs/pretrain/x2vlm_base_4m.yaml's
+    # regions block: up to 26 images and 128 (region text, box) rows per GPU; masked mean pooling over 197 tokens, 5th fusion
+    # pass (predict_bbox), L1 + GIoU on top of ITC + ITM + MLM.  f_min: measured - the GEMM FLOPs the step launches (bench.py
+    # counts 2MNK per GEMM launch; attention and row kernels excluded, < 4 %), see `f_min_note` in the line.
+    "region": dict(size="base", res=224, batch=128, images=26, frames=0, f_min=None, unit="pairs/s",
+                   metric="region-text pairs/sec (fwd+bwd) X2VLM-base 224px, 128 region texts over 26 images/GPU",
+                   workload="X2VLM-base region iteration (run_region_iter: 26 images, 128 region texts, masked mean pooling, "
+                            "predict_bbox pass) fwd+bwd, ITC+ITM+MLM+bbox(L1+GIoU), 224px"),
     "video": dict(size="base", res=224, batch=8, frames=8, f_min=921.1, unit="clips/s",
                   metric="video-text clips/sec (fwd+bwd) X2VLM-base 8x8-frame 224px clips/GPU",
                   workload="X2VLM-base video path (avgpool over 8 frames + frame position embedding) pre-training step "
@@ -81,15 +89,20 @@ def cpu_baseline(conf, seconds=20.0):
     else:
         cfg = O.OracleConfig(image_res=conf["res"], frames=conf["frames"])
     sd = O.make_params(cfg, 0, synthetic.synth_tensor)
-    B = 4 if conf is CONFIGS["base"] else 2
-    b = synthetic_batch(0, B, 30, conf["res"], frames=conf["frames"])
+    B = 4 if conf is CONFIGS["base"] else 8 if "images" in conf else 2
+    kw = {}
+    if "images" in conf:        # 8 region texts over 2 images: the same ~4.9 texts per image as the benchmark batch
+        b = synthetic.synth_region_batch(1234, 2, B, 30, conf["res"], 16, 30522, 12)
+        kw = dict(ret_bbox_loss=True)
+    else:
+        b = synthetic_batch(0, B, 30, conf["res"], frames=conf["frames"])
     neg = synthetic.synth_negatives(0, B)
     n, t0, first = 0, time.time(), None
     while True:
         for t in sd.values():
             t.grad = None
         ts = time.time()
-        losses, _ = O.xvlm_forward(sd, cfg, b, neg)
+        losses, _ = O.xvlm_forward(sd, cfg, b, neg, **kw)
         sum(losses.values()).backward()
         if first is None:
             first = time.time() - ts          # warm-up iteration, not counted
@@ -105,11 +118,12 @@ def cpu_baseline(conf, seconds=20.0):
 
 
 def other_configs(args):
-    """BASELINE.json configs[3] (X2VLM-large 384 px, batch 32) and configs[4] (8 x 8-frame video clips) on this GPU, each by a
-    child run of this script (fresh process: its own allocator pools and graphs) - same timing contract, own cpu_baseline."""
+    """BASELINE.json configs[3] (X2VLM-large 384 px, batch 32) and configs[4] (8 x 8-frame video clips) on this GPU, plus the region
+    / bbox iteration of the default pre-training yaml, each by a child run of this script (fresh process: its own allocator
+    pools and graphs) - same timing contract, own cpu_baseline."""
     import subprocess
     res = {}
-    for name, steps in (("large", 10), ("video", 15)):
+    for name, steps in (("large", 10), ("video", 15), ("region", 15)):
         cmd = [sys.executable, os.path.abspath(__file__), "--config", name, "--steps", str(steps), "--warmup", "3", "--graph", args.graph]
         if args.no_cpu_baseline:
             cmd.append("--no-cpu-baseline")
@@ -191,7 +205,15 @@ def main():
         model.overlap_towers = False
         importlib.import_module("x2-vlm_amd.engine").SIDE.enabled = False
     ddp = acc.GradientBuckets(model, world) if world > 1 else None
-    batch = {k: v.to(dev) for k, v in synthetic_batch(rank, args.batch, args.seq_len, conf["res"], frames=conf["frames"]).items()}
+    region = "images" in conf
+    if region:
+        synth = importlib.import_module("x2-vlm_amd.synthetic")
+        batch = {k: v.to(dev) for k, v in synth.synth_region_batch(1234 + rank, conf["images"], args.batch, args.seq_len, conf["res"], 16,
+                                                                   30522, 12).items()}
+    else:
+        batch = {k: v.to(dev) for k, v in synthetic_batch(rank, args.batch, args.seq_len, conf["res"], frames=conf["frames"]).items()}
+    region_kw = dict(image_atts=batch["image_atts"], idx_to_group_img=batch["idx_to_group_img"], target_bbox=batch["target_bbox"],
+                     is_image=batch["is_image"], ret_bbox_loss=True) if region else {}
 
     eng = importlib.import_module("x2-vlm_amd.engine")
 
@@ -209,8 +231,8 @@ def main():
         for p_ in params:                                # = model.zero_grad(set_to_none=True) without the module walk
             p_.grad = None
         loss = model(batch["image"], batch["text_ids"], batch["text_atts"], text_ids_masked=batch["text_ids_masked"],
-                     masked_pos=batch["masked_pos"], masked_ids=batch["masked_ids"])
-        total = loss["loss_itc"] + loss["loss_itm"] + loss["loss_mlm"]
+                     masked_pos=batch["masked_pos"], masked_ids=batch["masked_ids"], **region_kw)
+        total = sum(loss.values())              # Pretrain.py:67-68 / 98-100: the plain sum of the returned losses
         total.backward()
         if ddp is not None:
             ddp.finish()
@@ -293,7 +315,8 @@ def main():
         if ddp is not None:
             ddp.close()
             ddp = None
-        runner = graph.SegmentedStep(model, batch, world=world, rank=rank, warmup=1, enabled=use_graph, verbose=(rank == 0))
+        runner = graph.SegmentedStep(model, batch, world=world, rank=rank, warmup=1, enabled=use_graph, verbose=(rank == 0),
+                                     ret_bbox_loss=region)
     else:
         # N = 1: the whole step as ONE multi-stream hipGraph (fork / join edges: ~15 us of host time per node).
         # N > 1 on this path: eager launches with bucketed all-reduces overlapped on a side stream (accelerator.GradientBuckets).
@@ -325,6 +348,13 @@ def main():
     per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
 
     roof = None
+    f_min, f_note = conf["f_min"], None
+    if f_min is None:
+        # executed GEMM FLOPs of one step (NT + TN launches of the instrumented eager steps; the MLM head's recomputed decoder
+        # GEMM is not counted), per unit of the metric
+        gf = sum(fl for name, (ms, fl, n) in stat_iso.items() if name in ("gemm_nt", "gemm_tn")) / 2 if rank == 0 else 0.0
+        f_min = gf / 1e9 / args.batch
+        f_note = "measured: 2MNK of the GEMM launches of one step / units per step (attention and row kernels not counted)"
     if rank == 0:
         def summary(stat, name):
             ms, fl, n = stat.get(name, (0.0, 0.0, 0))
@@ -344,8 +374,9 @@ def main():
                 "also": {"gemm_nt concurrent (three-stream eager schedule; a launch also waits for CUs other streams hold)":
                              summary(stat_conc, "gemm_nt"),
                          "gemm_tn256_kernel isolated (weight gradients; two layers per grouped launch)": summary(stat_iso, "gemm_tn"),
-                         "whole_step_tflops": round(pairs_s / world * conf["f_min"] / 1e3, 1),
-                         "whole_step_frac": round(pairs_s / world * conf["f_min"] / 1e3 / PEAK_TFLOPS, 4)}}
+                         "whole_step_tflops": round(pairs_s / world * f_min / 1e3, 1),
+                         "whole_step_frac": round(pairs_s / world * f_min / 1e3 / PEAK_TFLOPS, 4),
+                         "gflop_per_unit": round(f_min, 1), **({"f_min_note": f_note} if f_note else {})}}
     if world > 1:
         dist.barrier()
     if rank == 0:

@@ -112,13 +112,15 @@ class VisionTransformer(nn.Module):
     def get_num_layers(self):
         return len(self.blocks)
 
-    def _params(self):
+    def _params(self, lo=0, hi=None):
         # resolved once: walking named_parameters() costs ~1 ms of host time per call (Parameter objects are stable:
         # .to() / load_state_dict() update them in place)
-        cached = self.__dict__.get("_param_list")
+        hi = self.depth if hi is None else hi
+        cache = self.__dict__.setdefault("_param_lists", {})
+        cached = cache.get((lo, hi))
         if cached is None:
             sd = dict(self.named_parameters())
-            cached = self.__dict__["_param_list"] = [sd[n] for n in vision_param_names(self.depth)]
+            cached = cache[(lo, hi)] = [sd[n] for n in vision_param_names(self.depth, lo, hi)]
         return cached
 
     def drop_path_scales(self, B, T, device, keep=None):
@@ -142,7 +144,19 @@ class VisionTransformer(nn.Module):
             dp = self.drop_path_scales(x.shape[0], T, x.device, getattr(self, "fixed_drop_path_keep", None))
         meta = dict(depth=self.depth, heads=self.num_heads, patch=self.patch_embed.patch_size[0], eps=self.eps,
                     rel_index=self.blocks[0].attn.relative_position_index, pool_w=pool_w, drop_path=dp)
-        return VisionEncoderFn.apply(x.float(), meta, *self._params())
+        cuts = [c for c in (getattr(self, "chunk_at", None) or ()) if 0 < c < self.depth]
+        if not cuts:
+            return VisionEncoderFn.apply(x.float(), meta, *self._params())
+        # the tower as a chain of stages over block ranges (same arithmetic): `chunk_hook(i, tokens)` sees the residual stream
+        # between two stages and returns what the next one consumes (graph.SegmentedStep cuts autograd there)
+        x = x.float()
+        hook = getattr(self, "chunk_hook", None)
+        bounds = [0] + sorted(cuts) + [self.depth]
+        for ci, (lo, hi) in enumerate(zip(bounds[:-1], bounds[1:])):
+            x = VisionEncoderFn.apply(x, dict(meta, lo=lo, hi=hi), *self._params(lo, hi))
+            if hook is not None and hi < self.depth:
+                x = hook(ci, x)
+        return x
 
     def forward(self, x, idx_to_group_img=None, image_atts=None, output_attentions=None, output_hidden_states=None):
         """beit2.py:378-436.  Returns (B,1+P,D); with idx_to_group_img the pair

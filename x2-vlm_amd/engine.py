@@ -339,11 +339,20 @@ class _LayerPairs:
             K.gemm_tn_grouped(tn)
         if WGRAD_QUEUE is not None:
             # the caller (graph.SegmentedStep) runs this layer's parameter-gradient work later, in a segment of its own on another
-            # stream: the closure keeps the operands alive; the gradient views autograd receives now are filled then
+            # stream: the closure keeps the operands alive; the gradient views autograd receives now are filled then.  It must
+            # NOT hold the view objects autograd is about to receive (AccumulateGrad adopts a gradient tensor only when nobody else
+            # references it, and would otherwise store a copy of the still empty arena): fresh aliases of the same memory instead.
+            tn_a = [tuple(pr[:2]) + (pr[2].detach(),) + tuple(pr[3:]) for pr in tn]
+            def_a = [(ws, nblk, nk, width, tuple(None if o is None else o.detach() for o in outs)) for ws, nblk, nk, width, outs in deferred]
+            pubs = [(G.flat, G.key, list(G.params)) for G, _, _ in entries]
+
             def later():
-                work()
-                for G, _, _ in entries:
-                    G.publish(None)
+                if def_a:
+                    K.reduce_partials_multi(def_a)
+                K.gemm_tn_grouped(tn_a)
+                if GRAD_READY_HOOK is not None:
+                    for flat, key, params in pubs:
+                        GRAD_READY_HOOK(flat, key, None, params)
             WGRAD_QUEUE.append(later)
             return
         keep = [t for pr in tn for t in pr[:2]] + [G.flat for G, _, _ in entries] + [d[0] for d in deferred]
@@ -383,9 +392,16 @@ def _mask_pad(add_mask, Lk):
 
 # ----------------------------------------------------------------------------- vision encoder
 
-def vision_param_names(depth):
-    names = ["cls_token", "patch_embed.proj.weight", "patch_embed.proj.bias", "fc_norm.weight", "fc_norm.bias"]
-    for i in range(depth):
+def vision_param_names(depth, lo=0, hi=None):
+    """Parameters of blocks [lo, hi) of a depth-block encoder, plus the stem's (lo == 0: cls token, patch embedding) and the
+    head's (hi == depth: fc_norm), in the order VisionEncoderFn takes them."""
+    hi = depth if hi is None else hi
+    names = []
+    if lo == 0:
+        names += ["cls_token", "patch_embed.proj.weight", "patch_embed.proj.bias"]
+    if hi == depth:
+        names += ["fc_norm.weight", "fc_norm.bias"]
+    for i in range(lo, hi):
         b = "blocks.%d." % i
         names += [b + s for s in ("gamma_1", "gamma_2", "norm1.weight", "norm1.bias", "attn.q_bias", "attn.v_bias",
                                   "attn.relative_position_bias_table", "attn.qkv.weight", "attn.proj.weight",
@@ -395,34 +411,50 @@ def vision_param_names(depth):
 
 
 class VisionEncoderFn(torch.autograd.Function):
-    """image (B,3,R,R) fp32 -> tokens (B,1+P,D) fp32: patch embed, pre-LN blocks with rel-pos-bias
-    attention and layer scale, fc_norm over patches, token 0 = (weighted) mean of patches.
+    """Blocks [lo, hi) of the BEiT-2 encoder as ONE autograd stage.  The whole encoder (lo = 0, hi = depth, the default):
+    image (B,3,R,R) fp32 -> tokens (B,1+P,D) fp32: patch embed, pre-LN blocks with rel-pos-bias attention and layer scale,
+    fc_norm over patches, token 0 = (weighted) mean of patches.  A chunk that does not start at block 0 takes the residual
+    stream (B,1+P,D) fp32 instead of the image; one that does not end at the last block returns the residual stream.  Chunks
+    let a caller cut the tower's backward into pieces (graph.SegmentedStep: gradient all-reduce of the upper blocks behind the
+    backward of the lower ones); chained they compute exactly what the single stage does.
 
-    meta: dict(depth, heads, patch, eps, rel_index[int64 (T,T)], pool_w [B,P] fp32 or None,
-               drop_path: None or list per block of (rs1, rs2): fp32 [B*T] per-row keep/(1-p) factors of the
-               attention / MLP branch (stochastic depth, beit2.py:205-207))."""
+    meta: dict(depth, [lo, hi,] heads, patch, eps, rel_index[int64 (T,T)], pool_w [B,P] fp32 or None,
+               drop_path: None or list per block of the ENCODER (indexed by absolute block number) of (rs1, rs2): fp32 [B*T]
+               per-row keep/(1-p) factors of the attention / MLP branch (stochastic depth, beit2.py:205-207))."""
 
     @staticmethod
     def forward(ctx, image, meta, *params):
-        names = vision_param_names(meta["depth"])
+        depth = meta["depth"]
+        lo, hi = meta.get("lo", 0), meta.get("hi", depth)
+        stem, head = lo == 0, hi == depth
+        names = vision_param_names(depth, lo, hi)
         p = dict(zip(names, params))
-        B, R, ps = image.shape[0], image.shape[-1], meta["patch"]
-        P_ = (R // ps) ** 2
-        T, H = P_ + 1, meta["heads"]
-        D = p["cls_token"].numel()
+        H = meta["heads"]
+        if stem:
+            B, R, ps = image.shape[0], image.shape[-1], meta["patch"]
+            P_ = (R // ps) ** 2
+            T = P_ + 1
+            D = p["cls_token"].numel()
+        else:
+            B, T, D = image.shape
+            P_ = T - 1
         M = B * T
         assert D == 64 * H, "vision width %d / %d heads: the attention kernels are built for head dim 64" % (D, H)
         scale = (D // H) ** -0.5
-        BANK.prepare([(p["patch_embed.proj.weight"],)] + [(p["blocks.%d.%s.weight" % (i, n)],) for i in range(meta["depth"])
-                                                            for n in ("attn.qkv", "attn.proj", "mlp.fc1", "mlp.fc2")])
-        BANK.prepare_vectors([(p["blocks.%d.attn.q_bias" % i], D, p["blocks.%d.attn.v_bias" % i]) for i in range(meta["depth"])])
-        cols = K.patchify(image.contiguous(), ps)
-        wpe, _ = BANK.linear(p["patch_embed.proj.weight"])
-        patch = K.gemm_nt(cols, wpe, bias=p["patch_embed.proj.bias"], out_dtype=F32)
-        x = K.assemble_tokens(patch, p["cls_token"].reshape(-1), B, P_).view(M, D)
+        BANK.prepare(([(p["patch_embed.proj.weight"],)] if stem else []) +
+                     [(p["blocks.%d.%s.weight" % (i, n)],) for i in range(lo, hi) for n in ("attn.qkv", "attn.proj", "mlp.fc1", "mlp.fc2")])
+        BANK.prepare_vectors([(p["blocks.%d.attn.q_bias" % i], D, p["blocks.%d.attn.v_bias" % i]) for i in range(lo, hi)])
+        cols = None
+        if stem:
+            cols = K.patchify(image.contiguous(), ps)
+            wpe, _ = BANK.linear(p["patch_embed.proj.weight"])
+            patch = K.gemm_nt(cols, wpe, bias=p["patch_embed.proj.bias"], out_dtype=F32)
+            x = K.assemble_tokens(patch, p["cls_token"].reshape(-1), B, P_).view(M, D)
+        else:
+            x = image.contiguous().view(M, D)          # read only below: the caller's tensor is never written
         saved = []
         dpath = meta.get("drop_path")
-        for i in range(meta["depth"]):
+        for i in range(lo, hi):
             b = "blocks.%d." % i
             rs1, rs2 = dpath[i] if dpath is not None else (None, None)
             h1, _, mean1, rstd1 = K.layernorm_fwd(x, p[b + "norm1.weight"], p[b + "norm1.bias"], meta["eps"])
@@ -448,14 +480,21 @@ class VisionEncoderFn(torch.autograd.Function):
                            rowscale=rs2)
             saved.append((x, h1, mean1, rstd1, qkv, bias, biasT, att, lse, aux1, x1, h2, mean2, rstd2, pre, act, aux2))
             x = x2
-        out = torch.empty(B, T, D, device=x.device, dtype=F32)
-        _, _, meanf, rstdf = K.layernorm_fwd(x, p["fc_norm.weight"], p["fc_norm.bias"], meta["eps"], rows=B * P_, period=P_,
-                                             want_bf16=False, y_f32=out.view(M, D))
-        K.pool_tokens(out, meta.get("pool_w"))
-        for i in range(meta["depth"]):
+        final = None
+        if head:
+            out = torch.empty(B, T, D, device=x.device, dtype=F32)
+            _, _, meanf, rstdf = K.layernorm_fwd(x, p["fc_norm.weight"], p["fc_norm.bias"], meta["eps"], rows=B * P_, period=P_,
+                                                 want_bf16=False, y_f32=out.view(M, D))
+            K.pool_tokens(out, meta.get("pool_w"))
+            final = (x, meanf, rstdf)
+            _count_call(("vit-head", id(p["fc_norm.weight"])))
+        else:
+            out = x.view(B, T, D) if hi > lo else x.view(B, T, D).clone()
+        for i in range(lo, hi):
             _count_call(("vit", id(p["blocks.%d.gamma_1" % i])))
-        _count_call(("vit-stem", id(params[0])))
-        ctx.meta, ctx.saved, ctx.final = meta, saved, (x, meanf, rstdf, cols)
+        if stem:
+            _count_call(("vit-stem", id(p["cls_token"])))
+        ctx.meta, ctx.saved, ctx.final, ctx.cols = meta, saved, final, cols
         ctx.params = params
         ctx.dims = (B, P_, T, H, D, M, scale)
         return out
@@ -464,29 +503,36 @@ class VisionEncoderFn(torch.autograd.Function):
     def backward(ctx, dout):
         meta, params = ctx.meta, ctx.params
         BANK.note_backward()
-        names = vision_param_names(meta["depth"])
+        depth = meta["depth"]
+        lo, hi = meta.get("lo", 0), meta.get("hi", depth)
+        stem, head = lo == 0, hi == depth
+        names = vision_param_names(depth, lo, hi)
         p = dict(zip(names, params))
         B, P_, T, H, D, M, scale = ctx.dims
         dev = dout.device
         out = {}
-        x_last, meanf, rstdf, cols = ctx.final
-        Gt = Grads(dev, [(n, p[n].shape, True) for n in ("cls_token", "patch_embed.proj.weight", "patch_embed.proj.bias",
-                                                          "fc_norm.weight", "fc_norm.bias")], key=("vit-stem", id(params[0])),
-                   params=[p[n] for n in ("cls_token", "patch_embed.proj.weight", "patch_embed.proj.bias", "fc_norm.weight", "fc_norm.bias")])
-        g = dout.contiguous().clone()
-        K.pool_tokens(g, meta.get("pool_w"), bwd=True)
-        dx, _ = K.layernorm_bwd(g.view(M, D), x_last, meanf, rstdf, p["fc_norm.weight"], Gt["fc_norm.weight"], Gt["fc_norm.bias"],
-                                period=P_)
-        dS = torch.empty(B, H, T, K.round_up(T, 64), device=dev, dtype=BF16)
-        F4 = p["blocks.0.mlp.fc1.weight"].shape[0]
+        if head:
+            x_last, meanf, rstdf = ctx.final
+            hn = ("fc_norm.weight", "fc_norm.bias")
+            Gh = Grads(dev, [(n, p[n].shape, True) for n in hn], key=("vit-head", id(p["fc_norm.weight"])), params=[p[n] for n in hn])
+            g = dout.contiguous().clone()
+            K.pool_tokens(g, meta.get("pool_w"), bwd=True)
+            dx, _ = K.layernorm_bwd(g.view(M, D), x_last, meanf, rstdf, p["fc_norm.weight"], Gh["fc_norm.weight"], Gh["fc_norm.bias"],
+                                    period=P_)
+            Gh.publish()
+            out.update(Gh.g)
+        else:
+            dx = dout.contiguous().view(M, D)          # read only below
+        dS = torch.empty(B, H, T, K.round_up(T, 64), device=dev, dtype=BF16) if hi > lo else None
+        F4 = p["blocks.%d.mlp.fc1.weight" % lo].shape[0] if hi > lo else 0
         dpath = meta.get("drop_path")
         pairs = _LayerPairs()
         dy2_fused = None
-        for i in reversed(range(meta["depth"])):
+        for i in reversed(range(lo, hi)):
             b = "blocks.%d." % i
             rs1, rs2 = dpath[i] if dpath is not None else (None, None)
-            (x, h1, mean1, rstd1, qkv, bias, biasT, att, lse, aux1, x1, h2, mean2, rstd2, pre, act, aux2) = ctx.saved[i]
-            ctx.saved[i] = None
+            (x, h1, mean1, rstd1, qkv, bias, biasT, att, lse, aux1, x1, h2, mean2, rstd2, pre, act, aux2) = ctx.saved[i - lo]
+            ctx.saved[i - lo] = None
             G = Grads(dev, [("gamma_1", (D,), True), ("gamma_2", (D,), True), ("norm1.weight", (D,), True), ("norm1.bias", (D,), True),
                             ("qkv_bias", (3 * D,), True), ("attn.relative_position_bias_table", p[b + "attn.relative_position_bias_table"].shape, True),
                             ("attn.proj.bias", (D,), True), ("norm2.weight", (D,), True), ("norm2.bias", (D,), True),
@@ -500,7 +546,7 @@ class VisionEncoderFn(torch.autograd.Function):
             _, wprojT = BANK.linear(p[b + "attn.proj.weight"])
             _, wqkvT = BANK.linear(p[b + "attn.qkv.weight"])
             # dy2 = gamma_2 * DropPath * dx comes from the LayerNorm backward that produced dx (norm1 of the block above, fused
-            # below); only the topmost block, whose dx comes from fc_norm, runs the stand-alone layer-scale backward
+            # below, when FUSE_LAYERSCALE_BWD); otherwise from the stand-alone layer-scale backward
             if dy2_fused is None:
                 dy2 = K.layerscale_bwd(dx, aux2, p[b + "gamma_2"], G["gamma_2"], G["mlp.fc2.bias"], rowscale=rs2)
             else:
@@ -530,12 +576,12 @@ class VisionEncoderFn(torch.autograd.Function):
             G.alias("attn.v_bias", G["qkv_bias"][2 * D:])
             dh1 = K.gemm_nt(dqkv, wqkvT)
             dy2_fused = None
-            if FUSE_LAYERSCALE_BWD and i > 0 and K.DEFERRED is not None:
+            if FUSE_LAYERSCALE_BWD and i > lo and K.DEFERRED is not None:
                 # the block below's MLP branch: its gamma_2 / fc2-bias sums are registered with ITS arena in the next iteration
                 bb = "blocks.%d." % (i - 1)
                 rs2b = dpath[i - 1][1] if dpath is not None else None
                 dxn, dyb, pend = K.layernorm_bwd_layerscale(dh1, x, mean1, rstd1, p[b + "norm1.weight"], G["norm1.weight"], G["norm1.bias"], dx1,
-                                                            ctx.saved[i - 1][16], p[bb + "gamma_2"], rowscale=rs2b)
+                                                            ctx.saved[i - 1 - lo][16], p[bb + "gamma_2"], rowscale=rs2b)
                 dy2_fused = (dyb, pend)
             else:
                 dxn, _ = K.layernorm_bwd(dh1, x, mean1, rstd1, p[b + "norm1.weight"], G["norm1.weight"], G["norm1.bias"], dres=dx1)
@@ -547,15 +593,20 @@ class VisionEncoderFn(torch.autograd.Function):
                     out[n] = G.g[n[len(b):]]
             dx = dxn
         pairs.flush()
-        dpatch = K.assemble_tokens_bwd(dx.view(B, T, D), Gt["cls_token"].view(-1))
-        K.colsum_bf16(dpatch, Gt["patch_embed.proj.bias"])
-        # 36 output tiles only: split the 12k-long contraction over 8 workgroups per tile (fp32 atomics)
-        K.gemm_tn_grouped([(dpatch, cols, Gt["patch_embed.proj.weight"].view(D, -1))], accumulate=True,
-                          split=8 if B * P_ >= 4096 else 1)
+        if stem:
+            sn = ("cls_token", "patch_embed.proj.weight", "patch_embed.proj.bias")
+            Gs = Grads(dev, [(n, p[n].shape, True) for n in sn], key=("vit-stem", id(p["cls_token"])), params=[p[n] for n in sn])
+            dpatch = K.assemble_tokens_bwd(dx.view(B, T, D), Gs["cls_token"].view(-1))
+            K.colsum_bf16(dpatch, Gs["patch_embed.proj.bias"])
+            # 36 output tiles only: split the 12k-long contraction over 8 workgroups per tile (fp32 atomics)
+            K.gemm_tn_grouped([(dpatch, ctx.cols, Gs["patch_embed.proj.weight"].view(D, -1))], accumulate=True,
+                              split=8 if B * P_ >= 4096 else 1)
+            SIDE.join()
+            Gs.publish()
+            out.update(Gs.g)
+            return (None, None) + tuple(out[n] for n in names)
         SIDE.join()
-        Gt.publish()
-        out.update(Gt.g)
-        return (None, None) + tuple(out[n] for n in names)
+        return (dx.view(B, T, D), None) + tuple(out[n] for n in names)
 
 
 # ----------------------------------------------------------------------------- BERT layers

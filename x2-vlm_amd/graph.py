@@ -147,7 +147,8 @@ class SegmentedStep:
     GraphedStep.copy_inputs.  Falls back to eager execution of the same segments when capture is disabled or fails."""
 
     def __init__(self, model, batch, world=1, rank=0, process_group=None, comm=None, warmup=2, enabled=True, verbose=False,
-                 ret_bbox_loss=False, ret_match_loss=True, recast_weights=True, clamp_temp=True, total_loss=None, side_stream=None):
+                 ret_bbox_loss=False, ret_match_loss=True, recast_weights=True, clamp_temp=True, total_loss=None, side_stream=None,
+                 vision_cuts=None):
         """side_stream: weight-gradient GEMMs of the stream-A segments (tail, vision backward) on engine.SIDE, forked from and
         joined into stream A inside the segment.  Those segments then replay node by node (~15 us of host time each, still
         well under the GPU time of a step) but keep the 3 % the side stream is worth on one GPU.  Default: X2_SEG_SIDE or off."""
@@ -160,8 +161,22 @@ class SegmentedStep:
         # fusion-layer weight gradients as a segment of their own on stream B (engine.WGRAD_QUEUE); X2_SEG_TAIL_WGRAD=0: in line
         self.defer_tail_wgrad = os.environ.get("X2_SEG_TAIL_WGRAD", "1") == "1"
         self._queue = None
+        # The vision tower as a chain of stages cut at these block numbers (beit2.VisionTransformer.chunk_at): its backward
+        # becomes one segment per stage, top first; the weight gradients of every stage but the lowest run as segments of
+        # their own on stream B, under the backward of the stages below, and their all-reduce (world > 1) starts there too.
+        depth = model.vision_encoder.depth
+        env = os.environ.get("X2_SEG_VISION_CUT")
+        if vision_cuts is None:
+            # default: thirds (same box, base: no cut 25.07 ms, one cut 24.88, two cuts 24.72 - profiles/r03f_ab_segments.txt)
+            vision_cuts = [int(c) for c in env.split(",") if c] if env is not None else [depth // 3, 2 * depth // 3]
+        self.vcuts = sorted(c for c in vision_cuts if 0 < c < depth)
+        self.defer_vision_wgrad = os.environ.get("X2_SEG_VISION_WGRAD", "1") == "1"
+        self._vq = {}
+        self._held = []
+        self._rorder = []                       # segment names in the order their reductions are issued (recorded at capture)
         self.total_loss = total_loss or (lambda losses: sum(losses.values()))
-        self.sA, self.sB = torch.cuda.Stream(), torch.cuda.Stream()
+        self.sA = torch.cuda.Stream()
+        self.sB = self.sA if os.environ.get("X2_SEG_ONE_STREAM", "0") == "1" else torch.cuda.Stream()    # A/B: everything on one stream
         self.sC = torch.cuda.Stream() if world > 1 else None
         self.t, self.graphs = {}, {}
         self.mode, self.error = "eager", None
@@ -170,6 +185,7 @@ class SegmentedStep:
         self._plan = None                       # per segment: tensors all-reduced in place + (static flat, views, sources)
         self._arenas = []                       # (segment, flat, params) published while capturing
         self._touch = {}                        # id(param) -> segment that last wrote its gradient
+        self._capturing = False
         self._pin_accumulators()
         dev = batch["text_ids"].device
         B = batch["text_ids"].shape[0]
@@ -234,9 +250,20 @@ class SegmentedStep:
         b = self.batch
         self.t["both"] = self.model.tower_text(b["text_ids"], b["text_atts"], b["text_ids_masked"])
 
+    def _vhook(self, ci, x):
+        leaf = x.detach().requires_grad_()
+        self.t["vmid"].append((x, leaf))
+        return leaf
+
     def _s_vision(self):
         b = self.batch
-        self.t["vis"] = self.model.tower_vision(b["image"], b.get("image_atts"), b.get("idx_to_group_img"), self.ret_bbox_loss)
+        enc = self.model.vision_encoder
+        self.t["vmid"] = []
+        enc.chunk_at, enc.chunk_hook = self.vcuts, self._vhook
+        try:
+            self.t["vis"] = self.model.tower_vision(b["image"], b.get("image_atts"), b.get("idx_to_group_img"), self.ret_bbox_loss)
+        finally:
+            enc.chunk_at, enc.chunk_hook = None, None
 
     def _s_feat(self):
         m = self.model
@@ -282,18 +309,33 @@ class SegmentedStep:
         torch.autograd.backward([fi, ft], [t["fi_all"].grad[sl], t["ft_all"].grad[sl]])
         t["loss"] = {k: v.detach() for k, v in loss.items()}
 
-    def _s_vision_bwd(self):
-        ie_out, _, full_out = self.t["vis"]
-        outs, grads = [ie_out], [self.t["ie"].grad]
-        if full_out is not None and self.t["full"].grad is not None:
-            outs.append(full_out); grads.append(self.t["full"].grad)
+    def _s_vision_bwd(self, ci=0):
+        """Backward of the ci-th vision stage counted from the top."""
+        if ci == 0:
+            ie_out, _, full_out = self.t["vis"]
+            outs, grads = [ie_out], [self.t["ie"].grad]
+            if full_out is not None and self.t["full"].grad is not None:
+                outs.append(full_out); grads.append(self.t["full"].grad)
+        else:
+            x, leaf = self.t["vmid"][len(self.vcuts) - ci]
+            outs, grads = [x], [leaf.grad]
         torch.autograd.backward(outs, grads)
+
+    def _s_vision_wgrad(self, ci):
+        work = self._vq.pop(ci, None)
+        self._held.append(work)                # see _s_tail_wgrad
+        for fn in work or ():
+            fn()
 
     def _s_text_bwd(self):
         torch.autograd.backward([self.t["both"]], [self.t["both_leaf"].grad])
 
     def _s_tail_wgrad(self):
+        # The closures' operands were allocated on stream A and are read here on stream B: they stay referenced (self._held)
+        # until stream A has waited for B at the end of the pass - dropped earlier, the allocator would hand their blocks to
+        # the next stream-A kernels (eagerly) or to the next stream-A segment's capture while B still reads them.
         work, self._queue = self._queue, None
+        self._held.append(work)
         for fn in work or ():
             fn()
 
@@ -329,23 +371,40 @@ class SegmentedStep:
             self._queue, eng.WGRAD_QUEUE = eng.WGRAD_QUEUE, None
         Bs.wait_stream(A)
         self._reduce("F2", A)
-        self._seg(mode, "Vb", A, self._s_vision_bwd, pa)
-        self._seg(mode, "Tb", Bs, self._s_text_bwd, pb)
-        self._reduce("Tb", Bs)
-        if self.defer_tail_wgrad:
-            # the tail's (fusion layers') weight gradients: off stream A's critical path, under the vision backward
-            self._seg(mode, "Fw", Bs, self._s_tail_wgrad, pb)
-            self._reduce("Fw", Bs)
-        self._reduce("Vb", A)
+        nstage = len(self.vcuts) + 1
+        for ci in range(nstage):
+            name = "Vb" if ci == 0 else "Vb%d" % ci
+            defer = self.defer_vision_wgrad and ci < nstage - 1
+            if mode != "replay":
+                eng.WGRAD_QUEUE = [] if defer else None
+            self._seg(mode, name, A, lambda ci=ci: self._s_vision_bwd(ci), pa)
+            if mode != "replay":
+                self._vq[ci], eng.WGRAD_QUEUE = eng.WGRAD_QUEUE, None
+            if ci == 0:
+                # stream B behind the tail: text tower backward, then the tail's (fusion layers') weight gradients - off
+                # stream A's critical path, under the vision backward
+                self._seg(mode, "Tb", Bs, self._s_text_bwd, pb)
+                self._reduce("Tb", Bs)
+                if self.defer_tail_wgrad:
+                    self._seg(mode, "Fw", Bs, self._s_tail_wgrad, pb)
+                    self._reduce("Fw", Bs)
+            if defer:
+                Bs.wait_stream(A)             # this stage's input-gradient chain (its (dY, X) pairs) is enqueued on A
+                wname = "Vw" if ci == 0 else "Vw%d" % ci
+                self._seg(mode, wname, Bs, lambda ci=ci: self._s_vision_wgrad(ci), pb)
+                self._reduce(wname, Bs)
+            self._reduce(name, A)
         A.wait_stream(Bs)
         if self.sC is not None:
             A.wait_stream(self.sC)
+        self._held = []
 
     def _capture(self, verbose):
         eng = self.engine
         self._pools = (torch.cuda.graph_pool_handle(), torch.cuda.graph_pool_handle())
         eng.GRAD_READY_HOOK = lambda flat, key, also_after=None, params=(): self._arenas.append((self._cur_seg, flat, list(params)))
         gc.collect()
+        self._capturing = True
         try:
             self._run("capture")
             self._grads = [(p, p.grad) for p in self.params if p.grad is not None]
@@ -359,6 +418,7 @@ class SegmentedStep:
             torch.cuda.synchronize()
         finally:
             eng.GRAD_READY_HOOK = None
+            self._capturing = False
 
     # ------------------------------------------------------------------ gradient averaging (world > 1)
     def _make_plan(self):
@@ -368,7 +428,7 @@ class SegmentedStep:
             return
         inside = lambda g, flat: flat.data_ptr() <= g.data_ptr() and g.data_ptr() + g.numel() * 4 <= flat.data_ptr() + flat.numel() * 4
         done = set()
-        order = {"F2": 0, "Tb": 1, "Fw": 2, "Vb": 3}       # the order the reductions are issued in (_run)
+        order = {seg: i for i, seg in enumerate(self._rorder)}       # the order the reductions are issued in (_run)
         # a gradient is complete after the later of: the segment whose autograd pass last wrote .grad, the segment that
         # published its arena (deferred weight-gradient work fills the views after autograd has handed them over)
         ready = dict(self._touch)
@@ -376,7 +436,7 @@ class SegmentedStep:
             for p in params:
                 if id(p) in ready and order[s] > order[ready[id(p)]]:
                     ready[id(p)] = s
-        for seg in ("F2", "Tb", "Fw", "Vb"):
+        for seg in self._rorder:
             whole = []
             for s, flat, params in self._arenas:
                 # an arena goes as one message when every gradient it was published for still lives in it (autograd adopted
@@ -414,6 +474,8 @@ class SegmentedStep:
             flat.div_(self.world)
 
     def _reduce(self, seg, stream):
+        if self._capturing and seg not in self._rorder:
+            self._rorder.append(seg)
         if self.world == 1 or self._plan is None:        # one rank; or still warming up / capturing
             return
         inplace, packed = self._plan.get(seg, ((), None))
