@@ -101,6 +101,7 @@ typedef struct X2AttnArgs {
   int dbg;                                           /* 0; ablation switches for probes/bench_attn.py */
   int head_dim;                                      /* hidden / heads of the caller: must be 64, checked */
   const unsigned* drop_epoch;                        /* device step counter mixed into drop_seed, or NULL */
+  int grid_nx, grid_ny, grid_nz, grid_map;           /* written by the library (XCD-aware workgroup order of the bias kernels): pass 0 */
 } X2AttnArgs;
 int x2_attn_fwd(const X2AttnArgs* args, void* stream);
 int x2_attn_bwd(const X2AttnArgs* args, void* stream);   /* dQ (+dS, Delta) then dK/dV; no atomics */

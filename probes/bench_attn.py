@@ -48,6 +48,16 @@ for rnd in range(3):
         row.append("v%-5d fwd %6.1f bwd %6.1f" % (bits, timeit(fwd), timeit(bwd)))
     print("vision N=197 round %d: " % rnd + "   ".join(row))
 LIB.x2_tune(8, -1)
+# XCD-aware workgroup order of the bias kernels (attention.hip attn_block) against the plain 3-D grid (bit 14 = 16384)
+for name, B, H, N in (("vision large N=577", 32, 16, 577), ("vision base N=197", 64, 12, 197)):
+    fwd, bwd = case(B, H, N, N, True, False)
+    for rnd in range(2):
+        row = []
+        for bits, tag in ((4096 | 8192, "xcd-order"), (4096 | 8192 | 16384, "3-D grid ")):
+            LIB.x2_tune(8, bits)
+            row.append("%s fwd %6.1f bwd %6.1f" % (tag, timeit(fwd), timeit(bwd)))
+        print("%s round %d: " % (name, rnd) + "   ".join(row))
+LIB.x2_tune(8, -1)
 
 for name, B, H, Lq, Lk, bias, mask in [("vision large", 32, 16, 577, 577, True, False), ("vision", 64, 12, 197, 197, True, False), ("text self", 128, 12, 30, 30, False, True),
                                        ("fusion self", 256, 12, 30, 30, False, True)]:

@@ -17,11 +17,12 @@ def table(path):
 
 
 fetch, write, tag = table(sys.argv[1]), table(sys.argv[2]), sys.argv[3]
-names = [n for n in fetch if n.startswith("gemm_nt_kernel")]
+# the NT family: 128-column kernels, the 256-column kernel; the MLM head's epilogue variants 8 / 9 are NT launches as well
+names = [n for n in fetch if n.startswith("gemm_nt_kernel") or n.startswith("gemm_nt256_kernel")]
 calls = sum(fetch[n][0] for n in names)
 fb = sum(fetch[n][0] * fetch[n][1] for n in names) / calls * 1024 * 2
 wb = sum(write[n][0] * write[n][1] for n in names if n in write) / max(sum(write[n][0] for n in names if n in write), 1) * 1024
-out = {"kernel": "gemm_nt_kernel<2|4|6>", "launches": calls, "fetch_bytes_per_launch": int(fb), "write_bytes_per_launch": int(wb),
+out = {"kernel": "gemm_nt_kernel<*> + gemm_nt256_kernel<*>", "launches": calls, "fetch_bytes_per_launch": int(fb), "write_bytes_per_launch": int(wb),
        "hbm_bytes_per_launch": int(fb + wb),
        "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (probes/run_pmc.sh) over "
                  "`bench.py --serialize --no-graph --steps 2 --warmup 1` (base config); KB units; FETCH_SIZE doubled (gfx950 counts "

@@ -38,7 +38,26 @@ struct AttnArgs {
   int dbg;                             // ablation (probes/bench_attn.py): 1 no bias/mask loads, 2 no exp2, 4 no PV MFMAs, 8 no QK MFMAs
   int head_dim;                        // the caller's head dimension: must be 64 (the only one these kernels are built for)
   const uint32_t* drop_epoch;          // device step counter mixed into drop.seed (x2_common.h drop_at_epoch), or NULL
+  // filled by the entry points (callers pass zeros): logical grid (x = query / key tiles, y = heads, z = batches) and, when
+  // grid_map > 0, the XCD-aware decode of a 1-D launch (attn_block below); grid_map = batch chunks per head
+  int grid_nx, grid_ny, grid_nz, grid_map;
 };
+
+// Workgroup -> (tile, head, batch).  grid_map == 0: the 3-D grid as launched.  grid_map = C > 0 (the kernels with a relative-
+// position bias): a 1-D grid decoded so that an XCD (hardware: workgroup id mod 8) works through whole (head, batch chunk)
+// units, batch-major and tile-minor inside a unit.  Why: the bias of one head is [Lq][Lk] fp32 - 1.5 MB at N = 577, 23.6 MB
+// for the 16 heads of X2VLM-large - and EVERY workgroup reads its [128][Lk] slice of it: 839 MB per launch at batch 32, more
+// than Q, K, V and O together (455 MB), streamed from the Infinity Cache because with heads interleaved over the XCDs no
+// 4 MB L2 keeps a head's bias between two images.  With a head pinned to an XCD its bias is fetched once and stays in that
+// L2 for all images of the chunk, and the query tiles of one (image, head) follow each other, so K / V hit L2 as well.
+__device__ __forceinline__ bool attn_block(const AttnArgs& a, int& bx, int& by, int& bz) {
+  if (a.grid_map == 0) { bx = blockIdx.x; by = blockIdx.y; bz = blockIdx.z; return true; }
+  const int w = blockIdx.x, xcd = w & 7, idx = w >> 3;
+  const int C = a.grid_map, zc = (a.grid_nz + C - 1) / C, per_unit = zc * a.grid_nx;
+  const int u = (idx / per_unit) * 8 + xcd, r = idx % per_unit;
+  by = u / C; bz = (u % C) * zc + r / a.grid_nx; bx = r % a.grid_nx;
+  return by < a.grid_ny && bz < a.grid_nz;
+}
 
 // Staging of a [64 rows][64 d] bf16 tile (rows clamped to `nrows-1`) HBM -> registers -> LDS in two halves, so the
 // global loads of tile t+1 are in flight while tile t is multiplied (issue early / write late).  LDS image:
@@ -144,7 +163,9 @@ __global__ __launch_bounds__(64 * QW, QG > 1 ? 2 : 4) void attn_fwd_kernel(AttnA
   __shared__ __attribute__((aligned(16))) char smem[NS][2 * KT * 128];   // {K tile, V tile} per slot
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fi = lane & 15, g = lane >> 4;
-  const int h = blockIdx.y, b = blockIdx.z, bk = a.kv_idx ? a.kv_idx[b] : b;
+  int bx_, h, b;
+  if (!attn_block(a, bx_, h, b)) return;
+  const int bk = a.kv_idx ? a.kv_idx[b] : b;
   const bf16_t* Kp = a.K + bk * a.k_bs + h * HD;
   const bf16_t* Vp = a.V + bk * a.v_bs + h * HD;
   const float sc2 = a.scale * LOG2E;
@@ -156,7 +177,7 @@ __global__ __launch_bounds__(64 * QW, QG > 1 ? 2 : 4) void attn_fwd_kernel(AttnA
   float m_i[QG], l_i[QG];
 #pragma unroll
   for (int gq = 0; gq < QG; ++gq) {
-    const int q0 = (blockIdx.x * QW * QG + wave * QG + gq) * 16;
+    const int q0 = (bx_ * QW * QG + wave * QG + gq) * 16;
     qok[gq] = q0 + fi < a.Lq;
     q[gq] = min(q0 + fi, a.Lq - 1);
 #pragma unroll
@@ -188,7 +209,7 @@ __global__ __launch_bounds__(64 * QW, QG > 1 ? 2 : 4) void attn_fwd_kernel(AttnA
   __syncthreads();
   // N = 197 is 12.3 sixteen-row MFMA tiles, not 16: a wave whose 16*QG queries all lie past Lq has nothing to do (no
   // barrier follows in the resident form), and 16-key sub-tiles past Lk are skipped instead of multiplied and masked
-  const bool idle = (blockIdx.x * QW * QG + wave * QG) * 16 >= a.Lq;
+  const bool idle = (bx_ * QW * QG + wave * QG) * 16 >= a.Lq;
   if (RES && idle) return;
   for (int kt = 0; kt < nkt; ++kt) {
     const uint32_t ktile = lds_addr(smem[RES ? kt : (kt & 1)]), vtile = ktile + KT * 128;
@@ -287,7 +308,9 @@ __global__ __launch_bounds__(64 * QW, QG > 1 ? 2 : 4) void attn_bwd_dq_kernel(At
   __shared__ __attribute__((aligned(16))) char smem[NS][2 * KT * 128];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fi = lane & 15, g = lane >> 4;
-  const int h = blockIdx.y, b = blockIdx.z, bk = a.kv_idx ? a.kv_idx[b] : b;
+  int bx_, h, b;
+  if (!attn_block(a, bx_, h, b)) return;
+  const int bk = a.kv_idx ? a.kv_idx[b] : b;
   const bf16_t* Kp = a.K + bk * a.k_bs + h * HD;
   const bf16_t* Vp = a.V + bk * a.v_bs + h * HD;
   const float sc2 = a.scale * LOG2E;
@@ -299,7 +322,7 @@ __global__ __launch_bounds__(64 * QW, QG > 1 ? 2 : 4) void attn_bwd_dq_kernel(At
   f32x4 dq[QG][4];
 #pragma unroll
   for (int gq = 0; gq < QG; ++gq) {
-    const int q0 = (blockIdx.x * QW * QG + wave * QG + gq) * 16;
+    const int q0 = (bx_ * QW * QG + wave * QG + gq) * 16;
     qok[gq] = q0 + fi < a.Lq;
     q[gq] = min(q0 + fi, a.Lq - 1);
     float dl = 0.f;
@@ -337,7 +360,7 @@ __global__ __launch_bounds__(64 * QW, QG > 1 ? 2 : 4) void attn_bwd_dq_kernel(At
     tile_store<NT>(rv, smem[0] + KT * 128, tid);
   }
   __syncthreads();
-  const bool idle = (blockIdx.x * QW * QG + wave * QG) * 16 >= a.Lq;       // see attn_fwd_kernel
+  const bool idle = (bx_ * QW * QG + wave * QG) * 16 >= a.Lq;       // see attn_fwd_kernel
   if (RES && idle) return;
   for (int kt = 0; kt < nkt; ++kt) {
     const uint32_t ktile = lds_addr(smem[RES ? kt : (kt & 1)]), vtile = ktile + KT * 128;
@@ -661,7 +684,8 @@ __global__ __launch_bounds__(64 * QW, 3) void attn_fwd_walk_kernel(AttnArgs a) {
   __shared__ __attribute__((aligned(16))) char smem[2 * WALK_BYTES];        // V rows | K rows
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fi = lane & 15, g = lane >> 4;
-  const int h = blockIdx.y, b = blockIdx.z;
+  int bx_, h, b;
+  if (!attn_block(a, bx_, h, b)) return;
   const float sc2 = a.scale * LOG2E;
   const int lkp = (a.Lk + 63) & ~63;
   const int nkt = (a.Lk + KT - 1) / KT;
@@ -752,7 +776,8 @@ __global__ __launch_bounds__(64 * QW, 3) void attn_bwd_dq_walk_kernel(AttnArgs a
   __shared__ __attribute__((aligned(16))) char smem[2 * WALK_BYTES];        // K rows | V rows (here the transposed reads are K's)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fi = lane & 15, g = lane >> 4;
-  const int h = blockIdx.y, b = blockIdx.z;
+  int bx_, h, b;
+  if (!attn_block(a, bx_, h, b)) return;
   const float sc2 = a.scale * LOG2E;
   const int lkp = (a.Lk + 63) & ~63;
   const int nkt = (a.Lk + KT - 1) / KT;
@@ -838,7 +863,8 @@ __global__ __launch_bounds__(64 * KW, (KW == 4 && !RES) ? 3 : 4) void attn_bwd_d
   __shared__ __attribute__((aligned(16))) char smem[NS][2 * KT * 128 + 2 * KT * 4];   // {Q tile, dO tile, LSE[64], Delta[64]} per slot
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fi = lane & 15, g = lane >> 4;
-  const int h = blockIdx.y, bk = blockIdx.z;
+  int bx_, h, bk;
+  if (!attn_block(a, bx_, h, bk)) return;
   const float sc2 = a.scale * LOG2E;
   const int lkp = (a.Lk + 63) & ~63;
 
@@ -847,7 +873,7 @@ __global__ __launch_bounds__(64 * KW, (KW == 4 && !RES) ? 3 : 4) void attn_bwd_d
   f32x4 dk[KG][4], dv[KG][4];
 #pragma unroll
   for (int gk = 0; gk < KG; ++gk) {
-    const int k0 = (blockIdx.x * KW * KG + wave * KG + gk) * 16;
+    const int k0 = (bx_ * KW * KG + wave * KG + gk) * 16;
     kok[gk] = k0 + fi < a.Lk;
     key[gk] = min(k0 + fi, a.Lk - 1);
 #pragma unroll
@@ -899,7 +925,7 @@ __global__ __launch_bounds__(64 * KW, (KW == 4 && !RES) ? 3 : 4) void attn_bwd_d
       commit(0);
     }
     __syncthreads();
-    const bool idle = (blockIdx.x * KW * KG + wave * KG) * 16 >= a.Lk;      // all keys of this wave are padding
+    const bool idle = (bx_ * KW * KG + wave * KG) * 16 >= a.Lk;      // all keys of this wave are padding
     if (RES && idle) return;
     for (int it = 0; it < nit; ++it) {
       const int si = sb + it / nqt, qt = it % nqt;
@@ -1010,7 +1036,8 @@ __global__ __launch_bounds__(64 * KW, (KW == 4 && !RES) ? 3 : 4) void attn_bwd_d
 // bit 3: grouped (shared K/V) forward kernel for cross-attention; bit 4: per-row dQ kernel instead of the grouped one.  Measured on the
 // fusion shapes (256 rows on 64 images): 62 vs 68 us forward, 132 vs 147 us backward in isolation, but -3 % on the whole
 // step (64 KB workgroups co-reside worse with the other streams' kernels), so off by default;
-// bit 12 (4096) / bit 13 (8192): strip-walking resident forward / dQ kernels (the default; see their header)
+// bit 12 (4096) / bit 13 (8192): strip-walking resident forward / dQ kernels (the default; see their header);
+// bit 14 (16384): bias kernels on the plain 3-D grid instead of the XCD-aware 1-D order (attn_block)
 // x2_tune(8, v) (gemm.hip) overrides the environment at run time: tests and probes A/B variants inside one process
 int x2_attn_variant_override = -1;
 static int attn_variant() {
@@ -1020,6 +1047,23 @@ static int attn_variant() {
   // 128.1 -> 118.8 us, profiles/r03a_attn_walk_ab.txt)
   if (v < 0) { const char* e = getenv("X2_ATTN_VARIANT"); v = e ? atoi(e) : (4096 | 8192); }
   return v;
+}
+
+// Launch `kernel` over the logical grid (nx tiles, ny heads, nz batches): as a 3-D grid, or - xmap, the kernels that read a
+// relative-position bias - as the 1-D XCD-aware grid attn_block() decodes (x2_tune(8) bit 14 = 16384 switches it off).
+template <typename Kern>
+static void attn_launch(Kern kernel, AttnArgs a, int nx, int ny, int nz, int threads, bool xmap, hipStream_t st) {
+  a.grid_nx = nx; a.grid_ny = ny; a.grid_nz = nz; a.grid_map = 0;
+  if (xmap && !(attn_variant() & 16384)) {
+    int C = 1;
+    while (C < 8 && (ny * C) % 8 != 0) C *= 2;        // batch chunks per head: (head, chunk) units divide evenly over 8 XCDs
+    if (C > nz) C = 1;
+    a.grid_map = C;
+    const int zc = (nz + C - 1) / C, units = ny * C;
+    hipLaunchKernelGGL(kernel, dim3(8 * ((units + 7) / 8) * zc * nx), dim3(threads), 0, st, a);
+    return;
+  }
+  hipLaunchKernelGGL(kernel, dim3(nx, ny, nz), dim3(threads), 0, st, a);
 }
 
 static int check_common(const AttnArgs& a, const char* who) {
@@ -1032,8 +1076,10 @@ static int check_common(const AttnArgs& a, const char* who) {
 }
 
 extern "C" int x2_attn_fwd(const AttnArgs* pa, void* stream) {
-  const AttnArgs a = *pa;
+  AttnArgs a = *pa;
+  a.grid_nx = a.grid_ny = a.grid_nz = a.grid_map = 0;
   if (int e = check_common(a, "x2_attn_fwd")) return e;
+  const bool xm = a.bias != nullptr && !a.kv_idx;        // XCD-aware block order for the kernels that read a [H][Lq][Lk] bias
   X2_REQUIRE(a.Q && a.K && a.V && a.Out && a.LSE, "x2_attn_fwd: null tensor");
   X2_REQUIRE((a.o_rs % 4 | a.o_bs % 4) == 0, "x2_attn_fwd: output strides");
   const hipStream_t st = (hipStream_t)stream;
@@ -1049,18 +1095,20 @@ extern "C" int x2_attn_fwd(const AttnArgs* pa, void* stream) {
   else if (a.Lk > 256 && a.Lq > 64 && (attn_variant() & 1024))
     hipLaunchKernelGGL((attn_fwd_kernel<4, 2, false>), dim3((a.Lq + 127) / 128, a.H, a.B), dim3(256), 0, st, a);
   else if (a.Lk > 256 && a.Lq > 64 && !(attn_variant() & 32))      // long sequences (X2VLM-large, N = 577): 8 waves share each streamed K/V tile (285 -> 254 us)
-    hipLaunchKernelGGL((attn_fwd_kernel<8, 1, false>), dim3((a.Lq + 127) / 128, a.H, a.B), dim3(512), 0, st, a);
+    attn_launch(attn_fwd_kernel<8, 1, false>, a, (a.Lq + 127) / 128, a.H, a.B, 512, xm, st);
   else if (a.Lq <= 64 || a.Lk > 256) hipLaunchKernelGGL((attn_fwd_kernel<4, 1, false>), dim3((a.Lq + 63) / 64, a.H, a.B), dim3(256), 0, st, a);
   else if (attn_variant() & 4) hipLaunchKernelGGL((attn_fwd_kernel<4, 2, true>), dim3((a.Lq + 127) / 128, a.H, a.B), dim3(256), 0, st, a);
   else if ((attn_variant() & 4096) && !a.kv_idx && a.Lk <= WALK_ROWS)      // staged: one strip-walking workgroup per (sequence, head)
-    hipLaunchKernelGGL((attn_fwd_walk_kernel<4>), dim3(1, a.H, a.B), dim3(256), 0, st, a);
-  else hipLaunchKernelGGL((attn_fwd_kernel<8, 1, true>), dim3((a.Lq + 127) / 128, a.H, a.B), dim3(512), 0, st, a);
+    attn_launch(attn_fwd_walk_kernel<4>, a, 1, a.H, a.B, 256, xm, st);
+  else attn_launch(attn_fwd_kernel<8, 1, true>, a, (a.Lq + 127) / 128, a.H, a.B, 512, xm, st);
   return x2_check_launch("x2_attn_fwd");
 }
 
 extern "C" int x2_attn_bwd(const AttnArgs* pa, void* stream) {
-  const AttnArgs a = *pa;
+  AttnArgs a = *pa;
+  a.grid_nx = a.grid_ny = a.grid_nz = a.grid_map = 0;
   if (int e = check_common(a, "x2_attn_bwd")) return e;
+  const bool xm = a.bias != nullptr && !a.kv_idx, xmT = a.biasT != nullptr && !a.seq_off;
   X2_REQUIRE(a.Q && a.K && a.V && a.O && a.dO && a.dQ && a.dK && a.dV && a.LSE && a.Delta, "x2_attn_bwd: null tensor");
   X2_REQUIRE(!a.bias || (a.biasT && a.biasT_ld % 64 == 0 && a.biasT_ld >= a.Lq), "x2_attn_bwd: biasT [H][Lk][ld%%64==0] required with bias");
   X2_REQUIRE(!a.dS || (a.ds_ld % 64 == 0 && a.ds_ld >= a.Lk), "x2_attn_bwd: ds_ld must be a multiple of 64 covering Lk");
@@ -1076,12 +1124,12 @@ extern "C" int x2_attn_bwd(const AttnArgs* pa, void* stream) {
   else if (a.Lk > 256 && a.Lq > 64 && (attn_variant() & 2048))
     hipLaunchKernelGGL((attn_bwd_dq_kernel<4, 2, false>), dim3((a.Lq + 127) / 128, a.H, a.B), dim3(256), 0, st, a);
   else if (a.Lk > 256 && a.Lq > 64 && !(attn_variant() & 64))      // N = 577: dQ + dK/dV 810 -> 652 us with 8-wave workgroups
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<8, 1, false>), dim3((a.Lq + 127) / 128, a.H, a.B), dim3(512), 0, st, a);
+    attn_launch(attn_bwd_dq_kernel<8, 1, false>, a, (a.Lq + 127) / 128, a.H, a.B, 512, xm, st);
   else if (a.Lq <= 64 || a.Lk > 256) hipLaunchKernelGGL((attn_bwd_dq_kernel<4, 1, false>), dim3((a.Lq + 63) / 64, a.H, a.B), dim3(256), 0, st, a);
   else if (attn_variant() & 2) hipLaunchKernelGGL((attn_bwd_dq_kernel<4, 2, true>), dim3((a.Lq + 127) / 128, a.H, a.B), dim3(256), 0, st, a);
   else if ((attn_variant() & 8192) && !a.kv_idx && a.Lk <= WALK_ROWS)
-    hipLaunchKernelGGL((attn_bwd_dq_walk_kernel<4>), dim3(1, a.H, a.B), dim3(256), 0, st, a);
-  else hipLaunchKernelGGL((attn_bwd_dq_kernel<8, 1, true>), dim3((a.Lq + 127) / 128, a.H, a.B), dim3(512), 0, st, a);
+    attn_launch(attn_bwd_dq_walk_kernel<4>, a, 1, a.H, a.B, 256, xm, st);
+  else attn_launch(attn_bwd_dq_kernel<8, 1, true>, a, (a.Lq + 127) / 128, a.H, a.B, 512, xm, st);
   if (int e = x2_check_launch("x2_attn_bwd(dq)")) return e;
   const bool res = !a.seq_off && a.Lq > 64 && a.Lq <= 256;   // one sequence per K/V batch, 2..4 query tiles: resident Q/dO
   if (a.Lk <= 32 && !a.seq_off && a.Lq <= 64) {          // text self-attention: one sequence, one query tile, 17 KB of LDS
@@ -1091,11 +1139,11 @@ extern "C" int x2_attn_bwd(const AttnArgs* pa, void* stream) {
   } else if (res && !(attn_variant() & 1)) {
     // 8 waves (128 keys) share the resident Q / dO image (133 KB: one workgroup per CU either way): 206 -> 189 us per
     // vision layer against 4-wave workgroups, which left 4 waves on a CU (probes/bench_attn.py)
-    hipLaunchKernelGGL((attn_bwd_dkv_kernel<8, 1, true>), dim3((a.Lk + 127) / 128, a.H, a.Bkv), dim3(512), 0, st, a);
+    attn_launch(attn_bwd_dkv_kernel<8, 1, true>, a, (a.Lk + 127) / 128, a.H, a.Bkv, 512, xmT, st);
   } else if (res) {
     hipLaunchKernelGGL((attn_bwd_dkv_kernel<4, 1, true>), dim3((a.Lk + 63) / 64, a.H, a.Bkv), dim3(256), 0, st, a);
   } else if (a.Lk > 256 && !a.seq_off && !(attn_variant() & 128)) {
-    hipLaunchKernelGGL((attn_bwd_dkv_kernel<8, 1, false>), dim3((a.Lk + 127) / 128, a.H, a.Bkv), dim3(512), 0, st, a);
+    attn_launch(attn_bwd_dkv_kernel<8, 1, false>, a, (a.Lk + 127) / 128, a.H, a.Bkv, 512, xmT, st);
   } else {
     hipLaunchKernelGGL((attn_bwd_dkv_kernel<4, 1, false>), dim3((a.Lk + 63) / 64, a.H, a.Bkv), dim3(256), 0, st, a);
   }

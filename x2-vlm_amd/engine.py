@@ -312,24 +312,30 @@ class _LayerPairs:
 
     def __init__(self):
         self.pending = []
+        self.extra = []
 
-    def add(self, G, tn):
+    def add(self, G, tn, param_only=()):
+        """param_only: closures of further parameter-gradient-only kernels of this layer (bias column sums, the bias-table
+        gradient), handed over only while WGRAD_QUEUE collects: they then run with the deferred work, off the input-gradient
+        chain's stream.  They must write through aliases (Tensor.detach()) of the arena views, see _launch."""
         deferred, K.DEFERRED = K.DEFERRED, None
         if len(tn) > 4 or not self.enabled:
             self.flush()
-            self._launch([(G, tn, deferred)])
+            self._launch([(G, tn, deferred)], list(param_only))
             return
         self.pending.append((G, tn, deferred))
+        self.extra += list(param_only)
         if len(self.pending) == 2:
             self.flush()
 
     def flush(self):
         if self.pending:
             entries, self.pending = self.pending, []
-            self._launch(entries)
+            extra, self.extra = self.extra, []
+            self._launch(entries, extra)
 
     @staticmethod
-    def _launch(entries):
+    def _launch(entries, extra=()):
         deferred = [d for _, _, ds in entries for d in (ds or ())]
         tn = [pr for _, t, _ in entries for pr in t]
 
@@ -346,7 +352,11 @@ class _LayerPairs:
             def_a = [(ws, nblk, nk, width, tuple(None if o is None else o.detach() for o in outs)) for ws, nblk, nk, width, outs in deferred]
             pubs = [(G.flat, G.key, list(G.params)) for G, _, _ in entries]
 
+            extra = list(extra)
+
             def later():
+                for fn in extra:
+                    fn()
                 if def_a:
                     K.reduce_partials_multi(def_a)
                 K.gemm_tn_grouped(tn_a)
@@ -355,10 +365,21 @@ class _LayerPairs:
                         GRAD_READY_HOOK(flat, key, None, params)
             WGRAD_QUEUE.append(later)
             return
+        assert not extra, "param_only closures are only collected while WGRAD_QUEUE is set"
         keep = [t for pr in tn for t in pr[:2]] + [G.flat for G, _, _ in entries] + [d[0] for d in deferred]
         done = SIDE.launch(work, keep)
         for G, _, _ in entries:
             G.publish(done)
+
+
+def _param_only(po, fn, src, dst):
+    """A kernel that only produces a parameter gradient (fn(src, dst), dst a view of the layer's arena): now, or - while
+    WGRAD_QUEUE collects - with the layer's deferred work (through an alias of dst, see _LayerPairs._launch)."""
+    if WGRAD_QUEUE is not None:
+        dst_a = dst.detach()
+        po.append(lambda: fn(src, dst_a))
+    else:
+        fn(src, dst)
 
 
 def _finish_layer_backward(G, tn):
@@ -567,11 +588,20 @@ class VisionEncoderFn(torch.autograd.Function):
             datt = K.gemm_nt(dy1, wprojT)
             dqkv = torch.empty_like(qkv)
             delta = torch.empty_like(lse)
+            # parameter-only gradients of the block (bias table, q / v bias): with the deferred weight-gradient work when a queue
+            # collects (then the dS stream needs a buffer of its own per block), in line otherwise
+            po = []
+            dS_i = torch.empty_like(dS) if WGRAD_QUEUE is not None else dS
             K.attn_bwd(K.view3(qkv, B, T, 0), K.view3(qkv, B, T, D), K.view3(qkv, B, T, 2 * D), K.view3(att, B, T),
                        K.view3(datt, B, T), B, B, H, T, T, scale, lse, delta, K.view3(dqkv, B, T, 0), K.view3(dqkv, B, T, D),
-                       K.view3(dqkv, B, T, 2 * D), dS=dS, bias=bias, biasT=biasT)
-            K.relpos_bias_bwd(dS, meta["rel_index"], G["attn.relative_position_bias_table"])
-            K.colsum_bf16(dqkv, G["qkv_bias"])
+                       K.view3(dqkv, B, T, 2 * D), dS=dS_i, bias=bias, biasT=biasT)
+            if WGRAD_QUEUE is not None:
+                tbl_a, qb_a = G["attn.relative_position_bias_table"].detach(), G["qkv_bias"].detach()
+                po.append(lambda dS_i=dS_i, tbl_a=tbl_a: K.relpos_bias_bwd(dS_i, meta["rel_index"], tbl_a))
+                po.append(lambda dqkv=dqkv, qb_a=qb_a: K.colsum_bf16(dqkv, qb_a))
+            else:
+                K.relpos_bias_bwd(dS_i, meta["rel_index"], G["attn.relative_position_bias_table"])
+                K.colsum_bf16(dqkv, G["qkv_bias"])
             G.alias("attn.q_bias", G["qkv_bias"][:D])
             G.alias("attn.v_bias", G["qkv_bias"][2 * D:])
             dh1 = K.gemm_nt(dqkv, wqkvT)
@@ -587,7 +617,7 @@ class VisionEncoderFn(torch.autograd.Function):
                 dxn, _ = K.layernorm_bwd(dh1, x, mean1, rstd1, p[b + "norm1.weight"], G["norm1.weight"], G["norm1.bias"], dres=dx1)
             tn = [(dy2, act, G["mlp.fc2.weight"]), (dpre, h2, G["mlp.fc1.weight"]),
                   (dy1, att, G["attn.proj.weight"]), (dqkv, h1, G["attn.qkv.weight"])]
-            pairs.add(G, tn)
+            pairs.add(G, tn, po)
             for n in names:
                 if n.startswith(b):
                     out[n] = G.g[n[len(b):]]
@@ -760,7 +790,7 @@ class BertLayersFn(torch.autograd.Function):
                          ("crossattention.output.LayerNorm.bias", (Hd,), True), ("crossattention.self.query.weight", (Hd, Hd), False),
                          ("c.kv_weight", (2 * Hd, Dv), False), ("crossattention.output.dense.weight", (Hd, Hd), False)]
             G = Grads(dev, spec, key=("bert", id(p[a + "self.query.weight"])), params=[p[n] for n in names if n.startswith(b)])
-            tn = []
+            tn, po = [], []
             _begin_layer_backward()
             ds3, ds3b = K.layernorm_bwd(dh, s3, m3, r3, p[b + "output.LayerNorm.weight"], G["output.LayerNorm.weight"],
                                         G["output.LayerNorm.bias"], dcol=G["output.dense.bias"], want_bf16=True,
@@ -789,8 +819,8 @@ class BertLayersFn(torch.autograd.Function):
                            S, Bi, H, L, T, scale, lse2, delta2, K.view3(dq2, S, L), K.view3(dkv, Bi, T, 0), K.view3(dkv, Bi, T, Hd),
                            mask=meta["enc_mask"], kv_idx=meta["kv_idx"], seq_off=meta["seq_off"], seq_ids=meta["seq_ids"],
                            drop=BertLayersFn._drop(meta, i, 2))
-                K.colsum_bf16(dq2, G["crossattention.self.query.bias"])
-                K.colsum_bf16(dkv, G["c.kv_bias"])
+                _param_only(po, K.colsum_bf16, dq2, G["crossattention.self.query.bias"])
+                _param_only(po, K.colsum_bf16, dkv, G["c.kv_bias"])
                 G.alias("crossattention.self.key.bias", G["c.kv_bias"][:Hd])
                 G.alias("crossattention.self.value.bias", G["c.kv_bias"][Hd:])
                 G.alias("crossattention.self.key.weight", G["c.kv_weight"][:Hd])
@@ -814,14 +844,14 @@ class BertLayersFn(torch.autograd.Function):
             K.attn_bwd(K.view3(qkv, S, L, 0), K.view3(qkv, S, L, Hd), K.view3(qkv, S, L, 2 * Hd), K.view3(att, S, L), K.view3(datt, S, L),
                        S, S, H, L, L, scale, lse, delta, K.view3(dqkv, S, L, 0), K.view3(dqkv, S, L, Hd), K.view3(dqkv, S, L, 2 * Hd),
                        mask=meta["self_mask"], drop=BertLayersFn._drop(meta, i, 0))
-            K.colsum_bf16(dqkv, G["a.qkv_bias"])
+            _param_only(po, K.colsum_bf16, dqkv, G["a.qkv_bias"])
             for k3, nm in enumerate(("query", "key", "value")):
                 G.alias("attention.self.%s.bias" % nm, G["a.qkv_bias"][k3 * Hd:(k3 + 1) * Hd])
                 G.alias("attention.self.%s.weight" % nm, G["a.qkv_weight"][k3 * Hd:(k3 + 1) * Hd])
             _, wqkvT = BANK.linear(p[a + "self.query.weight"], p[a + "self.key.weight"], p[a + "self.value.weight"])
             dh = K.gemm_nt(dqkv, wqkvT, resid=ds1, out_dtype=F32)
             tn += [(ds1b, att, G["attention.output.dense.weight"]), (dqkv, hb, G["a.qkv_weight"])]
-            pairs.add(G, tn)
+            pairs.add(G, tn, po)
             for n in names:
                 if n.startswith(b):
                     out[n] = G.g[n[len(b):]]

@@ -232,7 +232,8 @@ class SegmentedStep:
                 g = torch.cuda.CUDAGraph()
                 before = self._grad_ids()
                 self._cur_seg = name
-                with torch.cuda.graph(g, pool=pool, stream=stream):
+                # thread_local: a process group's watchdog thread (RCCL) keeps polling its events while this thread captures
+                with torch.cuda.graph(g, pool=pool, stream=stream, capture_error_mode="thread_local"):
                     fn()
                 self.graphs[name] = g
                 after = self._grad_ids()
