@@ -53,7 +53,7 @@ for name, B, H, N in (("vision large N=577", 32, 16, 577), ("vision base N=197",
     fwd, bwd = case(B, H, N, N, True, False)
     for rnd in range(2):
         row = []
-        for bits, tag in ((4096 | 8192, "xcd-order"), (4096 | 8192 | 16384, "3-D grid ")):
+        for bits, tag in ((4096 | 8192, "default  "), (4096 | 8192 | 32768, "2waves/SIMD")):
             LIB.x2_tune(8, bits)
             row.append("%s fwd %6.1f bwd %6.1f" % (tag, timeit(fwd), timeit(bwd)))
         print("%s round %d: " % (name, rnd) + "   ".join(row))

@@ -18,6 +18,12 @@
 #define NEG_BIG (-1.0e30f)
 #define LOG2E 1.4426950408889634f
 #define LN2 0.6931471805599453f
+#include <type_traits>
+// v_exp_f32 as is: libm's exp2f wraps it in a denormal-range fix-up (compare, select, ldexp, multiply: five more VALU
+// instructions per element in kernels whose inner loops are VALU-bound); arguments here are score - running max <= 0, and
+// results below 2^-126 may flush to zero
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+using FullTile = std::true_type; using PartTile = std::false_type;
 
 struct AttnArgs {
   const bf16_t *Q, *K, *V, *O, *dO;
@@ -118,8 +124,14 @@ __device__ __forceinline__ f32x4 add_bias_mask(f32x4 s, const AttnArgs& a, int h
 
 // the same with the bias / mask values already in registers (loaded at the top of the key tile, so that their L2
 // latency is covered by the QK^T MFMAs instead of sitting between them and the softmax)
+template <bool FULL = false>
 __device__ __forceinline__ f32x4 apply_bias_mask(f32x4 s, float4 bb, float4 mm, int key0, int Lk, float sc2) {
   f32x4 o;
+  if constexpr (FULL) {       // every key of the tile exists: no index select
+    o[0] = s[0] * sc2 + (bb.x + mm.x) * LOG2E; o[1] = s[1] * sc2 + (bb.y + mm.y) * LOG2E;
+    o[2] = s[2] * sc2 + (bb.z + mm.z) * LOG2E; o[3] = s[3] * sc2 + (bb.w + mm.w) * LOG2E;
+    return o;
+  }
   o[0] = key0 + 0 < Lk ? s[0] * sc2 + (bb.x + mm.x) * LOG2E : NEG_BIG;
   o[1] = key0 + 1 < Lk ? s[1] * sc2 + (bb.y + mm.y) * LOG2E : NEG_BIG;
   o[2] = key0 + 2 < Lk ? s[2] * sc2 + (bb.z + mm.z) * LOG2E : NEG_BIG;
@@ -156,8 +168,8 @@ __device__ __forceinline__ void load_bias_mask(const AttnArgs& a, int h, int b, 
 // NS: LDS slots.  Resident form: one per key tile (4 covers Lk <= 256; 1 for Lk <= 64, the 30-token text sequences: 16 KB
 // per workgroup instead of 32-64 KB lets 10 of the 2-wave workgroups share a CU instead of 5, and these launches are a
 // serial load -> multiply -> store chain per workgroup whose only latency hiding is other workgroups).
-template <int QW, int QG, bool RES, int NS = (RES ? 4 : 2)>
-__global__ __launch_bounds__(64 * QW, QG > 1 ? 2 : 4) void attn_fwd_kernel(AttnArgs a) {
+template <int QW, int QG, bool RES, int NS = (RES ? 4 : 2), int WPS = (QG > 1 ? 2 : 4)>     // WPS: waves per SIMD the registers must allow
+__global__ __launch_bounds__(64 * QW, WPS) void attn_fwd_kernel(AttnArgs a) {
   const DropSpec drop_ = drop_at_epoch(a.drop, a.drop_epoch);
   constexpr int NT = 64 * QW;
   __shared__ __attribute__((aligned(16))) char smem[NS][2 * KT * 128];   // {K tile, V tile} per slot
@@ -211,13 +223,18 @@ __global__ __launch_bounds__(64 * QW, QG > 1 ? 2 : 4) void attn_fwd_kernel(AttnA
   // barrier follows in the resident form), and 16-key sub-tiles past Lk are skipped instead of multiplied and masked
   const bool idle = (bx_ * QW * QG + wave * QG) * 16 >= a.Lq;
   if (RES && idle) return;
-  for (int kt = 0; kt < nkt; ++kt) {
+  // One key tile.  FULL (compile time): all 64 keys exist and this wave has queries - the 16-key sub-tile tests and the
+  // key-index selects fold away and the tile is straight-line code (the tests used to put every MFMA in a basic block of its
+  // own: nothing could be scheduled across them, and these loops are VALU-bound); only the last tile of a sequence, and
+  // waves without queries, take the general form.
+  auto tile = [&](int kt, auto full_) {
+    constexpr bool FULL = decltype(full_)::value;
     const uint32_t ktile = lds_addr(smem[RES ? kt : (kt & 1)]), vtile = ktile + KT * 128;
     if (!RES && kt + 1 < nkt) {             // next tile's HBM loads fly under this tile's MFMAs
       tile_load<NT>(rk, Kp, a.k_rs, (kt + 1) * KT, a.Lk, tid);
       tile_load<NT>(rv, Vp, a.v_rs, (kt + 1) * KT, a.Lk, tid);
     }
-    const int nsub = idle ? 0 : min(4, (a.Lk - kt * KT + 15) >> 4);      // valid 16-key sub-tiles of this tile (wave-uniform)
+    const int nsub = FULL ? 4 : (idle ? 0 : min(4, (a.Lk - kt * KT + 15) >> 4));      // valid 16-key sub-tiles of this tile (wave-uniform)
     float4 bbv[QG][4], mmv[4];
     load_bias_mask<QG>(a, h, b, q, kt * KT, g, nsub, bbv, mmv);
     f32x4 st[QG][4];
@@ -241,18 +258,18 @@ __global__ __launch_bounds__(64 * QW, QG > 1 ? 2 : 4) void attn_fwd_kernel(AttnA
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) {
         if (nt >= nsub) continue;
-        st[gq][nt] = apply_bias_mask(st[gq][nt], bbv[gq][nt], mmv[nt], kt * KT + nt * 16 + g * 4, a.Lk, sc2);
+        st[gq][nt] = apply_bias_mask<FULL>(st[gq][nt], bbv[gq][nt], mmv[nt], kt * KT + nt * 16 + g * 4, a.Lk, sc2);
         mx = fmaxf(fmaxf(mx, fmaxf(st[gq][nt][0], st[gq][nt][1])), fmaxf(st[gq][nt][2], st[gq][nt][3]));
       }
       mx = group_max(mx);
       const float m_new = fmaxf(m_i[gq], mx);
-      const float alpha = exp2f(m_i[gq] - m_new);
+      const float alpha = fast_exp2(m_i[gq] - m_new);
       float rs = 0.f;
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) {
         if (nt >= nsub) continue;           // skipped sub-tiles keep P = 0 (st was zero-initialised)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { st[gq][nt][r] = (a.dbg & 2) ? (st[gq][nt][r] - m_new) * 0.001f : exp2f(st[gq][nt][r] - m_new); rs += st[gq][nt][r]; }
+        for (int r = 0; r < 4; ++r) { st[gq][nt][r] = (a.dbg & 2) ? (st[gq][nt][r] - m_new) * 0.001f : fast_exp2(st[gq][nt][r] - m_new); rs += st[gq][nt][r]; }
       }
       l_i[gq] = l_i[gq] * alpha + group_sum(rs);
       m_i[gq] = m_new;
@@ -287,6 +304,10 @@ __global__ __launch_bounds__(64 * QW, QG > 1 ? 2 : 4) void attn_fwd_kernel(AttnA
       }
       __syncthreads();
     }
+  };
+  for (int kt = 0; kt < nkt; ++kt) {
+    if (!idle && (kt + 1) * KT <= a.Lk) tile(kt, FullTile{});
+    else tile(kt, PartTile{});
   }
 #pragma unroll
   for (int gq = 0; gq < QG; ++gq) {
@@ -301,8 +322,8 @@ __global__ __launch_bounds__(64 * QW, QG > 1 ? 2 : 4) void attn_fwd_kernel(AttnA
 }
 
 // ------------------------------------------------------------------------------------------ backward: dQ (+ dS)
-template <int QW, int QG, bool RES, int NS = (RES ? 4 : 2)>
-__global__ __launch_bounds__(64 * QW, QG > 1 ? 2 : 4) void attn_bwd_dq_kernel(AttnArgs a) {
+template <int QW, int QG, bool RES, int NS = (RES ? 4 : 2), int WPS = (QG > 1 ? 2 : 4)>
+__global__ __launch_bounds__(64 * QW, WPS) void attn_bwd_dq_kernel(AttnArgs a) {
   const DropSpec drop_ = drop_at_epoch(a.drop, a.drop_epoch);
   constexpr int NT = 64 * QW;
   __shared__ __attribute__((aligned(16))) char smem[NS][2 * KT * 128];
@@ -362,13 +383,14 @@ __global__ __launch_bounds__(64 * QW, QG > 1 ? 2 : 4) void attn_bwd_dq_kernel(At
   __syncthreads();
   const bool idle = (bx_ * QW * QG + wave * QG) * 16 >= a.Lq;       // see attn_fwd_kernel
   if (RES && idle) return;
-  for (int kt = 0; kt < nkt; ++kt) {
+  auto tile = [&](int kt, auto full_) {          // FULL: see attn_fwd_kernel
+    constexpr bool FULL = decltype(full_)::value;
     const uint32_t ktile = lds_addr(smem[RES ? kt : (kt & 1)]), vtile = ktile + KT * 128;
     if (!RES && kt + 1 < nkt) {
       tile_load<NT>(rk, Kp, a.k_rs, (kt + 1) * KT, a.Lk, tid);
       tile_load<NT>(rv, Vp, a.v_rs, (kt + 1) * KT, a.Lk, tid);
     }
-    const int nsub = idle ? 0 : min(4, (a.Lk - kt * KT + 15) >> 4);
+    const int nsub = FULL ? 4 : (idle ? 0 : min(4, (a.Lk - kt * KT + 15) >> 4));
     float4 bbv[QG][4], mmv[4];
     load_bias_mask<QG>(a, h, b, q, kt * KT, g, nsub, bbv, mmv);
     f32x4 ds[QG][4];
@@ -394,14 +416,14 @@ __global__ __launch_bounds__(64 * QW, QG > 1 ? 2 : 4) void attn_bwd_dq_kernel(At
       const int key0 = kt * KT + nt * 16 + g * 4;
 #pragma unroll
       for (int gq = 0; gq < QG; ++gq) {
-        s[gq] = apply_bias_mask(s[gq], bbv[gq][nt], mmv[nt], key0, a.Lk, sc2);
+        s[gq] = apply_bias_mask<FULL>(s[gq], bbv[gq][nt], mmv[nt], key0, a.Lk, sc2);
         if (drop_.thr16) {
           float dm[4];
           drop_mul4(drop_, (uint32_t)(((long)b * a.H + h) * a.Lq + q[gq]) * (uint32_t)lkp + (uint32_t)key0, dm);
           dp[gq][0] *= dm[0]; dp[gq][1] *= dm[1]; dp[gq][2] *= dm[2]; dp[gq][3] *= dm[3];
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) ds[gq][nt][r] = exp2f(s[gq][r] - lse[gq]) * (dp[gq][r] - delta[gq]);
+        for (int r = 0; r < 4; ++r) ds[gq][nt][r] = fast_exp2(s[gq][r] - lse[gq]) * (dp[gq][r] - delta[gq]);
         if (a.dS && qok[gq] && key0 < a.ds_ld)
           *reinterpret_cast<u32x2*>(a.dS + (((long)b * a.H + h) * a.Lq + q[gq]) * a.ds_ld + key0) =
               u32x2{pack_bf16(ds[gq][nt][0], ds[gq][nt][1]), pack_bf16(ds[gq][nt][2], ds[gq][nt][3])};
@@ -427,7 +449,10 @@ __global__ __launch_bounds__(64 * QW, QG > 1 ? 2 : 4) void attn_bwd_dq_kernel(At
       }
       __syncthreads();
     }
-  }
+  };
+  // (the straight-line FULL form of the forward kernels costs registers here: under this kernel's 128-VGPR bound it spills, and
+  // at 256 VGPRs the lost occupancy outweighs it - measured 639 -> 1492 / 667 us for dQ + dK/dV at N = 577; general form only)
+  for (int kt = 0; kt < nkt; ++kt) tile(kt, PartTile{});
 #pragma unroll
   for (int gq = 0; gq < QG; ++gq) {
     if (!qok[gq]) continue;
@@ -508,13 +533,13 @@ __global__ __launch_bounds__(64 * QW) void attn_fwd_grouped_kernel(AttnArgs a) {
         mx = fmaxf(fmaxf(mx, fmaxf(st[nt][0], st[nt][1])), fmaxf(st[nt][2], st[nt][3]));
       }
       mx = group_max(mx);
-      const float m_new = fmaxf(m_i, mx), alpha = exp2f(m_i - m_new);
+      const float m_new = fmaxf(m_i, mx), alpha = fast_exp2(m_i - m_new);
       float rs = 0.f;
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) {
         if (nt >= nsub) continue;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { st[nt][r] = exp2f(st[nt][r] - m_new); rs += st[nt][r]; }
+        for (int r = 0; r < 4; ++r) { st[nt][r] = fast_exp2(st[nt][r] - m_new); rs += st[nt][r]; }
       }
       l_i = l_i * alpha + group_sum(rs);
       m_i = m_new;
@@ -621,7 +646,7 @@ __global__ __launch_bounds__(64 * QW, 32 / QW) void attn_bwd_dq_grouped_kernel(A
           dp[0] *= dm[0]; dp[1] *= dm[1]; dp[2] *= dm[2]; dp[3] *= dm[3];
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) ds[nt][r] = exp2f(s[r] - lse) * (dp[r] - delta);
+        for (int r = 0; r < 4; ++r) ds[nt][r] = fast_exp2(s[r] - lse) * (dp[r] - delta);
       }
       const bf16x8 dsf[2] = {pack8(ds[0], ds[1]), pack8(ds[2], ds[3])};
 #pragma unroll
@@ -704,9 +729,10 @@ __global__ __launch_bounds__(64 * QW, 3) void attn_fwd_walk_kernel(AttnArgs a) {
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
     float m_i = NEG_BIG, l_i = 0.f;
-    for (int kt = 0; kt < nkt; ++kt) {
+    auto tile = [&](int kt, auto full_) {          // FULL: see attn_fwd_kernel
+      constexpr bool FULL = decltype(full_)::value;
       const uint32_t ktile = kbase + kt * KT * 128, vtile = vbase + kt * KT * 128;
-      const int nsub = min(4, (a.Lk - kt * KT + 15) >> 4);
+      const int nsub = FULL ? 4 : min(4, (a.Lk - kt * KT + 15) >> 4);
       float4 bbv[1][4], mmv[4];
       load_bias_mask<1>(a, h, b, q1, kt * KT, g, nsub, bbv, mmv);
       f32x4 st[4];
@@ -723,17 +749,17 @@ __global__ __launch_bounds__(64 * QW, 3) void attn_fwd_walk_kernel(AttnArgs a) {
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) {
         if (nt >= nsub) continue;
-        st[nt] = apply_bias_mask(st[nt], bbv[0][nt], mmv[nt], kt * KT + nt * 16 + g * 4, a.Lk, sc2);
+        st[nt] = apply_bias_mask<FULL>(st[nt], bbv[0][nt], mmv[nt], kt * KT + nt * 16 + g * 4, a.Lk, sc2);
         mx = fmaxf(fmaxf(mx, fmaxf(st[nt][0], st[nt][1])), fmaxf(st[nt][2], st[nt][3]));
       }
       mx = group_max(mx);
-      const float m_new = fmaxf(m_i, mx), alpha = exp2f(m_i - m_new);
+      const float m_new = fmaxf(m_i, mx), alpha = fast_exp2(m_i - m_new);
       float rs = 0.f;
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) {
         if (nt >= nsub) continue;               // skipped sub-tiles keep P = 0
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { st[nt][r] = exp2f(st[nt][r] - m_new); rs += st[nt][r]; }
+        for (int r = 0; r < 4; ++r) { st[nt][r] = fast_exp2(st[nt][r] - m_new); rs += st[nt][r]; }
       }
       l_i = l_i * alpha + group_sum(rs);
       m_i = m_new;
@@ -757,6 +783,10 @@ __global__ __launch_bounds__(64 * QW, 3) void attn_fwd_walk_kernel(AttnArgs a) {
           if (2 * s2 >= nsub) continue;
           o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_cols(vtile, s2, dt, lane), pf[s2], o[dt], 0, 0, 0);
         }
+    };
+    for (int kt = 0; kt < nkt; ++kt) {
+      if ((kt + 1) * KT <= a.Lk) tile(kt, FullTile{});
+      else tile(kt, PartTile{});
     }
     if (qok) {
       const float inv = 1.0f / l_i;
@@ -804,9 +834,10 @@ __global__ __launch_bounds__(64 * QW, 3) void attn_bwd_dq_walk_kernel(AttnArgs a
     f32x4 dq[4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int kt = 0; kt < nkt; ++kt) {
+    auto tile = [&](int kt, auto full_) {          // FULL: see attn_fwd_kernel
+      constexpr bool FULL = decltype(full_)::value;
       const uint32_t ktile = kbase + kt * KT * 128, vtile = vbase + kt * KT * 128;
-      const int nsub = min(4, (a.Lk - kt * KT + 15) >> 4);
+      const int nsub = FULL ? 4 : min(4, (a.Lk - kt * KT + 15) >> 4);
       float4 bbv[1][4], mmv[4];
       load_bias_mask<1>(a, h, b, q1, kt * KT, g, nsub, bbv, mmv);
       f32x4 ds[4];
@@ -820,14 +851,14 @@ __global__ __launch_bounds__(64 * QW, 3) void attn_bwd_dq_walk_kernel(AttnArgs a
           dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(vtile, nt * 16 + fi, ks * 4 + g), dof[ks], dp, 0, 0, 0);
         }
         const int key0 = kt * KT + nt * 16 + g * 4;
-        s = apply_bias_mask(s, bbv[0][nt], mmv[nt], key0, a.Lk, sc2);
+        s = apply_bias_mask<FULL>(s, bbv[0][nt], mmv[nt], key0, a.Lk, sc2);
         if (drop_.thr16) {
           float dm[4];
           drop_mul4(drop_, (uint32_t)(((long)b * a.H + h) * a.Lq + q) * (uint32_t)lkp + (uint32_t)key0, dm);
           dp[0] *= dm[0]; dp[1] *= dm[1]; dp[2] *= dm[2]; dp[3] *= dm[3];
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) ds[nt][r] = exp2f(s[r] - lse) * (dp[r] - delta);
+        for (int r = 0; r < 4; ++r) ds[nt][r] = fast_exp2(s[r] - lse) * (dp[r] - delta);
         if (a.dS && qok && key0 < a.ds_ld)
           *reinterpret_cast<u32x2*>(a.dS + (((long)b * a.H + h) * a.Lq + q) * a.ds_ld + key0) =
               u32x2{pack_bf16(ds[nt][0], ds[nt][1]), pack_bf16(ds[nt][2], ds[nt][3])};
@@ -840,7 +871,8 @@ __global__ __launch_bounds__(64 * QW, 3) void attn_bwd_dq_walk_kernel(AttnArgs a
           if (2 * s2 >= nsub) continue;
           dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_cols(ktile, s2, dt, lane), dsf[s2], dq[dt], 0, 0, 0);
         }
-    }
+    };
+    for (int kt = 0; kt < nkt; ++kt) tile(kt, PartTile{});          // general form only: see attn_bwd_dq_kernel
     if (qok) {
       bf16_t* op = a.dQ + b * a.dq_bs + (long)q * a.dq_rs + h * HD + g * 4;
 #pragma unroll
@@ -853,11 +885,11 @@ __global__ __launch_bounds__(64 * QW, 3) void attn_bwd_dq_walk_kernel(AttnArgs a
 
 // ------------------------------------------------------------------------------------------ backward: dK, dV
 // KW waves, KG groups of 16 keys per wave; the workgroup walks every (sequence using this K/V batch, 64-query tile).
-template <int KW, int KG, bool RES, int NS = (RES ? 4 : 2)>
+template <int KW, int KG, bool RES, int NS = (RES ? 4 : 2), int WPS = ((KW == 4 && !RES) ? 3 : 4)>
 // (second launch bound = waves per SIMD the register allocation must allow: these kernels hide their load -> MFMA -> exp
 // chains only behind other waves, and left alone hipcc spends 170-230 VGPRs on the short-sequence forms (2 waves per SIMD);
 // capped at 128 they run 1.3-1.5x faster.  The streamed 4-wave form needs more than 128: 35 spills under the cap.)
-__global__ __launch_bounds__(64 * KW, (KW == 4 && !RES) ? 3 : 4) void attn_bwd_dkv_kernel(AttnArgs a) {
+__global__ __launch_bounds__(64 * KW, WPS) void attn_bwd_dkv_kernel(AttnArgs a) {
   const DropSpec drop_ = drop_at_epoch(a.drop, a.drop_epoch);
   constexpr int NT = 64 * KW;
   __shared__ __attribute__((aligned(16))) char smem[NS][2 * KT * 128 + 2 * KT * 4];   // {Q tile, dO tile, LSE[64], Delta[64]} per slot
@@ -927,9 +959,13 @@ __global__ __launch_bounds__(64 * KW, (KW == 4 && !RES) ? 3 : 4) void attn_bwd_d
     __syncthreads();
     const bool idle = (bx_ * KW * KG + wave * KG) * 16 >= a.Lk;      // all keys of this wave are padding
     if (RES && idle) return;
-    for (int it = 0; it < nit; ++it) {
+    // FULL (compile time): all 64 queries of the tile and all keys of this wave exist - the sub-tile tests and the validity
+    // selects fold away and the tile is straight-line code (see attn_fwd_kernel)
+    const bool keys_full = (bx_ * KW * KG + wave * KG + KG) * 16 <= a.Lk;
+    auto tile = [&](int it, auto full_) {
+      constexpr bool FULL = decltype(full_)::value;
       const int si = sb + it / nqt, qt = it % nqt;
-      const int nsub = idle ? 0 : min(4, (a.Lq - qt * KT + 15) >> 4);      // valid 16-query sub-tiles of this tile
+      const int nsub = FULL ? 4 : (idle ? 0 : min(4, (a.Lq - qt * KT + 15) >> 4));      // valid 16-query sub-tiles of this tile
       const int b = a.seq_ids ? a.seq_ids[si] : si;
       char* buf = smem[RES ? it : (it & 1)];
       const uint32_t qtile = lds_addr(buf), dotile = qtile + KT * 128;
@@ -982,8 +1018,8 @@ __global__ __launch_bounds__(64 * KW, (KW == 4 && !RES) ? 3 : 4) void attn_bwd_d
           const float bbv[4] = {bb.x, bb.y, bb.z, bb.w};
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const bool ok = kok[gk] && (qq0 + r < a.Lq);
-            const float pv = ok ? exp2f(s[gk][r] * sc2 + bbv[r] * LOG2E + mk[gk] - lsv[r]) : 0.f;
+            const bool ok = FULL || (kok[gk] && (qq0 + r < a.Lq));
+            const float pv = ok ? fast_exp2(s[gk][r] * sc2 + bbv[r] * LOG2E + mk[gk] - lsv[r]) : 0.f;
             float dm = 1.f;
             if (drop_.thr16)
               dm = drop_mul(drop_, (uint32_t)(((long)b * a.H + h) * a.Lq + min(qq0 + r, a.Lq - 1)) * (uint32_t)lkp + (uint32_t)key[gk]);
@@ -1012,7 +1048,9 @@ __global__ __launch_bounds__(64 * KW, (KW == 4 && !RES) ? 3 : 4) void attn_bwd_d
         if (it + 1 < nit) commit((it + 1) & 1);
         __syncthreads();
       }
-    }
+    };
+    (void)keys_full;
+    for (int it = 0; it < nit; ++it) tile(it, PartTile{});            // general form only: see attn_bwd_dq_kernel
   }
 #pragma unroll
   for (int gk = 0; gk < KG; ++gk) {
@@ -1037,7 +1075,8 @@ __global__ __launch_bounds__(64 * KW, (KW == 4 && !RES) ? 3 : 4) void attn_bwd_d
 // fusion shapes (256 rows on 64 images): 62 vs 68 us forward, 132 vs 147 us backward in isolation, but -3 % on the whole
 // step (64 KB workgroups co-reside worse with the other streams' kernels), so off by default;
 // bit 12 (4096) / bit 13 (8192): strip-walking resident forward / dQ kernels (the default; see their header);
-// bit 14 (16384): bias kernels on the plain 3-D grid instead of the XCD-aware 1-D order (attn_block)
+// bit 14 (16384): bias kernels on the plain 3-D grid instead of the XCD-aware 1-D order (attn_block);
+// bit 15 (32768): the 8-wave streaming / resident-dK/dV kernels compiled for 2 waves per SIMD (256 VGPRs) instead of 4 (128)
 // x2_tune(8, v) (gemm.hip) overrides the environment at run time: tests and probes A/B variants inside one process
 int x2_attn_variant_override = -1;
 static int attn_variant() {
@@ -1095,7 +1134,8 @@ extern "C" int x2_attn_fwd(const AttnArgs* pa, void* stream) {
   else if (a.Lk > 256 && a.Lq > 64 && (attn_variant() & 1024))
     hipLaunchKernelGGL((attn_fwd_kernel<4, 2, false>), dim3((a.Lq + 127) / 128, a.H, a.B), dim3(256), 0, st, a);
   else if (a.Lk > 256 && a.Lq > 64 && !(attn_variant() & 32))      // long sequences (X2VLM-large, N = 577): 8 waves share each streamed K/V tile (285 -> 254 us)
-    attn_launch(attn_fwd_kernel<8, 1, false>, a, (a.Lq + 127) / 128, a.H, a.B, 512, xm, st);
+    { if (attn_variant() & 32768) attn_launch(attn_fwd_kernel<8, 1, false, 2, 2>, a, (a.Lq + 127) / 128, a.H, a.B, 512, xm, st);
+      else attn_launch(attn_fwd_kernel<8, 1, false>, a, (a.Lq + 127) / 128, a.H, a.B, 512, xm, st); }
   else if (a.Lq <= 64 || a.Lk > 256) hipLaunchKernelGGL((attn_fwd_kernel<4, 1, false>), dim3((a.Lq + 63) / 64, a.H, a.B), dim3(256), 0, st, a);
   else if (attn_variant() & 4) hipLaunchKernelGGL((attn_fwd_kernel<4, 2, true>), dim3((a.Lq + 127) / 128, a.H, a.B), dim3(256), 0, st, a);
   else if ((attn_variant() & 4096) && !a.kv_idx && a.Lk <= WALK_ROWS)      // staged: one strip-walking workgroup per (sequence, head)
@@ -1124,7 +1164,8 @@ extern "C" int x2_attn_bwd(const AttnArgs* pa, void* stream) {
   else if (a.Lk > 256 && a.Lq > 64 && (attn_variant() & 2048))
     hipLaunchKernelGGL((attn_bwd_dq_kernel<4, 2, false>), dim3((a.Lq + 127) / 128, a.H, a.B), dim3(256), 0, st, a);
   else if (a.Lk > 256 && a.Lq > 64 && !(attn_variant() & 64))      // N = 577: dQ + dK/dV 810 -> 652 us with 8-wave workgroups
-    attn_launch(attn_bwd_dq_kernel<8, 1, false>, a, (a.Lq + 127) / 128, a.H, a.B, 512, xm, st);
+    { if (attn_variant() & 32768) attn_launch(attn_bwd_dq_kernel<8, 1, false, 2, 2>, a, (a.Lq + 127) / 128, a.H, a.B, 512, xm, st);
+      else attn_launch(attn_bwd_dq_kernel<8, 1, false>, a, (a.Lq + 127) / 128, a.H, a.B, 512, xm, st); }
   else if (a.Lq <= 64 || a.Lk > 256) hipLaunchKernelGGL((attn_bwd_dq_kernel<4, 1, false>), dim3((a.Lq + 63) / 64, a.H, a.B), dim3(256), 0, st, a);
   else if (attn_variant() & 2) hipLaunchKernelGGL((attn_bwd_dq_kernel<4, 2, true>), dim3((a.Lq + 127) / 128, a.H, a.B), dim3(256), 0, st, a);
   else if ((attn_variant() & 8192) && !a.kv_idx && a.Lk <= WALK_ROWS)
@@ -1139,11 +1180,13 @@ extern "C" int x2_attn_bwd(const AttnArgs* pa, void* stream) {
   } else if (res && !(attn_variant() & 1)) {
     // 8 waves (128 keys) share the resident Q / dO image (133 KB: one workgroup per CU either way): 206 -> 189 us per
     // vision layer against 4-wave workgroups, which left 4 waves on a CU (probes/bench_attn.py)
-    attn_launch(attn_bwd_dkv_kernel<8, 1, true>, a, (a.Lk + 127) / 128, a.H, a.Bkv, 512, xmT, st);
+    if (attn_variant() & 32768) attn_launch(attn_bwd_dkv_kernel<8, 1, true, 4, 2>, a, (a.Lk + 127) / 128, a.H, a.Bkv, 512, xmT, st);
+    else attn_launch(attn_bwd_dkv_kernel<8, 1, true>, a, (a.Lk + 127) / 128, a.H, a.Bkv, 512, xmT, st);
   } else if (res) {
     hipLaunchKernelGGL((attn_bwd_dkv_kernel<4, 1, true>), dim3((a.Lk + 63) / 64, a.H, a.Bkv), dim3(256), 0, st, a);
   } else if (a.Lk > 256 && !a.seq_off && !(attn_variant() & 128)) {
-    attn_launch(attn_bwd_dkv_kernel<8, 1, false>, a, (a.Lk + 127) / 128, a.H, a.Bkv, 512, xmT, st);
+    if (attn_variant() & 32768) attn_launch(attn_bwd_dkv_kernel<8, 1, false, 2, 2>, a, (a.Lk + 127) / 128, a.H, a.Bkv, 512, xmT, st);
+    else attn_launch(attn_bwd_dkv_kernel<8, 1, false>, a, (a.Lk + 127) / 128, a.H, a.Bkv, 512, xmT, st);
   } else {
     hipLaunchKernelGGL((attn_bwd_dkv_kernel<4, 1, false>), dim3((a.Lk + 63) / 64, a.H, a.Bkv), dim3(256), 0, st, a);
   }
