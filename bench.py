@@ -344,6 +344,8 @@ def main():
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t)
+    if rank == 0 and getattr(runner, "times", None):
+        print("segment times (ms): " + json.dumps({k: round(v, 3) for k, v in runner.segment_times().items()}), file=sys.stderr, flush=True)
     pairs_s = world * args.batch * args.steps / dt
     per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
 

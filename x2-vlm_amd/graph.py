@@ -172,6 +172,7 @@ class SegmentedStep:
         self.vcuts = sorted(c for c in vision_cuts if 0 < c < depth)
         self.defer_vision_wgrad = os.environ.get("X2_SEG_VISION_WGRAD", "1") == "1"
         self._vq = {}
+        self.times = {} if os.environ.get("X2_SEG_TIMES") == "1" else None
         self._held = []
         self._rorder = []                       # segment names in the order their reductions are issued (recorded at capture)
         self.total_loss = total_loss or (lambda losses: sum(losses.values()))
@@ -227,6 +228,13 @@ class SegmentedStep:
     def _seg(self, mode, name, stream, fn, pool):
         with torch.cuda.stream(stream):
             if mode == "replay":
+                if self.times is not None:            # X2_SEG_TIMES=1: HIP events around every segment replay (diagnostics)
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    self.graphs[name].replay()
+                    e1.record()
+                    self.times.setdefault(name, []).append((e0, e1))
+                    return
                 self.graphs[name].replay()
             elif mode == "capture":
                 g = torch.cuda.CUDAGraph()
@@ -499,6 +507,21 @@ class SegmentedStep:
         self._all_reduce(flat)
         for p, v in zip([p for p in self.params if p.grad is not None], views):
             p.grad = v
+
+    def segment_times(self):
+        """{segment: mean ms} over the replays timed so far (X2_SEG_TIMES=1), plus start offsets relative to the first segment."""
+        torch.cuda.synchronize()
+        out = {}
+        first = None
+        for name, evs in (self.times or {}).items():
+            evs = evs[len(evs) // 2:]                  # later half: warm
+            out[name] = sum(a.elapsed_time(b) for a, b in evs) / len(evs)
+        if self.times:
+            base = self.times.get("T") or next(iter(self.times.values()))
+            for name, evs in self.times.items():
+                k = len(evs) // 2
+                out["start:" + name] = sum(base[i][0].elapsed_time(evs[i][0]) for i in range(k, len(evs))) / (len(evs) - k)
+        return out
 
     def reattach_grads(self):
         """p.grad back to the static tensors the segments write (after an optimizer.zero_grad(set_to_none=True))."""
