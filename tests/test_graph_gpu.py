@@ -124,7 +124,7 @@ def test_segmented_replay_is_the_eager_step(synthetic):
     step = graph.SegmentedStep(model, static, clamp_temp=False, vision_cuts=[1])
     assert step.mode == "hipgraph-segments", step.error
     # towers | features | tail + its backward | vision backward in two stages, text backward, deferred weight gradients
-    assert sorted(step.graphs) == ["F1", "F2", "Fw", "T", "Tb", "V", "Vb", "Vb1", "Vw"]
+    assert sorted(step.graphs) == ["F1", "F2", "Fw", "P", "T", "Tb", "V", "Vb", "Vb1", "Vw"]
     captured = [p.grad for p in params]                      # static tensors the segments write on every replay
     seen = []
     for i, b in enumerate(data):

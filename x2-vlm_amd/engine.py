@@ -671,6 +671,25 @@ class BertLayersFn(torch.autograd.Function):
                3 cross out, 4 ffn out}, element index))."""
 
     @staticmethod
+    def prepare_weights(p, lo, hi, fusion_at, cross):
+        """bf16 (W, W^T) copies and stacked bias vectors of layers [lo, hi) in two multi-tensor launches (no-ops for what is
+        fresh).  Also called ahead of time, on another stream, by graph.SegmentedStep (the fusion layers' casts run under the
+        vision tower's forward instead of at the head of the tail segment)."""
+        groups, vecs = [], []
+        for i in range(lo, hi):
+            b = "layer.%d." % i
+            a, c = b + "attention.", b + "crossattention."
+            groups += [(p[a + "self.query.weight"], p[a + "self.key.weight"], p[a + "self.value.weight"]),
+                       (p[a + "output.dense.weight"],), (p[b + "intermediate.dense.weight"],), (p[b + "output.dense.weight"],)]
+            vecs.append((p[a + "self.query.bias"], p[a + "self.key.bias"], p[a + "self.value.bias"]))
+            if cross and i >= fusion_at:
+                groups += [(p[c + "self.query.weight"],), (p[c + "self.key.weight"], p[c + "self.value.weight"]),
+                           (p[c + "output.dense.weight"],)]
+                vecs.append((p[c + "self.key.bias"], p[c + "self.value.bias"]))
+        BANK.prepare(groups)
+        BANK.prepare_vectors(vecs)
+
+    @staticmethod
     def _drop(meta, layer, kind):
         d = meta.get("drop")
         if not d:
@@ -694,23 +713,7 @@ class BertLayersFn(torch.autograd.Function):
         if cross:
             Bi, T, Dv = enc.shape
             encb = K.cast_bf16(enc.contiguous().view(Bi * T, Dv))
-        groups = []
-        for i in range(meta["lo"], meta["hi"]):
-            b = "layer.%d." % i
-            a, c = b + "attention.", b + "crossattention."
-            groups += [(p[a + "self.query.weight"], p[a + "self.key.weight"], p[a + "self.value.weight"]),
-                       (p[a + "output.dense.weight"],), (p[b + "intermediate.dense.weight"],), (p[b + "output.dense.weight"],)]
-            if cross and i >= meta["fusion_at"]:
-                groups += [(p[c + "self.query.weight"],), (p[c + "self.key.weight"], p[c + "self.value.weight"]),
-                           (p[c + "output.dense.weight"],)]
-        BANK.prepare(groups)
-        vecs = []
-        for i in range(meta["lo"], meta["hi"]):
-            a, c = "layer.%d.attention." % i, "layer.%d.crossattention." % i
-            vecs.append((p[a + "self.query.bias"], p[a + "self.key.bias"], p[a + "self.value.bias"]))
-            if cross and i >= meta["fusion_at"]:
-                vecs.append((p[c + "self.key.bias"], p[c + "self.value.bias"]))
-        BANK.prepare_vectors(vecs)
+        BertLayersFn.prepare_weights(p, meta["lo"], meta["hi"], meta["fusion_at"], cross)
         saved = []
         for i in range(meta["lo"], meta["hi"]):
             b = "layer.%d." % i

@@ -171,6 +171,7 @@ class SegmentedStep:
             vision_cuts = [int(c) for c in env.split(",") if c] if env is not None else [depth // 3, 2 * depth // 3]
         self.vcuts = sorted(c for c in vision_cuts if 0 < c < depth)
         self.defer_vision_wgrad = os.environ.get("X2_SEG_VISION_WGRAD", "1") == "1"
+        self.prefetch_casts = os.environ.get("X2_SEG_PREFETCH_CASTS", "1") == "1" and recast_weights
         self._vq = {}
         self.times = {} if os.environ.get("X2_SEG_TIMES") == "1" else None
         self._held = []
@@ -263,6 +264,21 @@ class SegmentedStep:
         leaf = x.detach().requires_grad_()
         self.t["vmid"].append((x, leaf))
         return leaf
+
+    def _s_prefetch(self):
+        """Stream B, behind the text tower and under the vision tower's forward: the bf16 weight copies the tail segment would
+        otherwise cast at its head, on the critical stream (fusion layers, MLM head dense, the padded vocabulary)."""
+        eng = self.engine
+        bert = self.model._bert
+        cfg = bert.config
+        lo, hi = cfg.fusion_layer, cfg.num_hidden_layers
+        names = eng.bert_layer_param_names(lo, hi, cfg.fusion_layer, True)
+        sd = dict(bert.encoder.named_parameters())
+        eng.BertLayersFn.prepare_weights({n: sd[n] for n in names}, lo, hi, cfg.fusion_layer, True)
+        te = self.model.text_encoder
+        if hasattr(te, "cls"):
+            eng.BANK.linear(te.cls.predictions.transform.dense.weight)
+            eng.BANK.vocab(bert.embeddings.word_embeddings.weight)
 
     def _s_vision(self):
         b = self.batch
@@ -368,6 +384,8 @@ class SegmentedStep:
             K.DROP_EPOCH.add_(1)
         Bs.wait_stream(A)
         self._seg(mode, "T", Bs, self._s_text, pb)
+        if self.prefetch_casts:
+            self._seg(mode, "P", Bs, self._s_prefetch, pb)
         self._seg(mode, "V", A, self._s_vision, pa)
         A.wait_stream(Bs)
         self._seg(mode, "F1", A, self._s_feat, pa)
