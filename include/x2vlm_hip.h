@@ -155,9 +155,11 @@ int x2_assemble_tokens(const float* patch, const float* cls, float* x, int B, in
 int x2_assemble_tokens_bwd(const float* dx, void* dpatch_bf16, float* dcls, int B, int P, int D, void* stream);
 /* token 0 <- (weighted) mean of patch tokens: avgpool beit2.py:413-416, region pooling beit2.py:430-436 */
 int x2_pool_tokens(float* x, const float* w, int B, int P, int D, int bwd, void* stream);
-/* relative_position_bias_table[relative_position_index] -> [H][N][ld] (+ transposed), beit2.py:138-144 */
+/* relative_position_bias_table[relative_position_index] x scale -> [H][N][ld] (+ transposed), beit2.py:138-144.  scale = 1, or
+ * log2(e) for a bias in the unit the attention kernels' softmax works in: set bit 4 (16) of X2AttnArgs.dbg with such a bias
+ * (no mask) and a score costs one fma instead of four VALU operations */
 int x2_relpos_bias(const float* table, const long* index, const long* indexT /* index^T or NULL */, float* bias, float* biasT, int N, int H, int ld, int ldT,
-                   void* stream);
+                   float scale, void* stream);
 /* dtable[index[i][j]][h] += sum_b dS[b][h][i][j] (dS bf16 [B][H][N][ld]); the index arrives as its CSR inverse
  * (inv_off [T+1], inv_pos = i*ld + j); ws: slices*H*N*ld floats (batch-slice sums, then a gather: no atomics) */
 int x2_relpos_bias_bwd(const void* dS, const int* inv_off, const int* inv_pos, float* dtable, int B, int N, int H, int ld,

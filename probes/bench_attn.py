@@ -24,6 +24,7 @@ def case(B, H, Lq, Lk, bias, mask):
     kw = {}
     if bias:
         kw["bias"] = torch.randn(H, Lq, K.round_up(Lk, 64), device=dev); kw["biasT"] = torch.randn(H, Lk, K.round_up(Lq, 64), device=dev)
+        kw["bias_log2"] = os.environ.get("X2_BENCH_BIAS_LOG2", "1") == "1"      # as the engine hands the bias over (one-fma score path)
     if mask:
         kw["mask"] = torch.zeros(B, K.round_up(Lk, 64), device=dev)
     HD = H * d
@@ -31,7 +32,7 @@ def case(B, H, Lq, Lk, bias, mask):
     dS = torch.empty(B, H, Lq, K.round_up(Lk, 64), device=dev, dtype=torch.bfloat16) if bias else None
     def fwd(dbg=0):
         a = K._attn_args(q3, k3, v3, B, B, H, Lq, Lk, d ** -0.5, **{k_: v_ for k_, v_ in kw.items() if k_ != "biasT"})
-        a.Out, a.o_bs, a.o_rs = K.view3(out, B, Lq); a.LSE = lse.data_ptr(); a.dbg = dbg
+        a.Out, a.o_bs, a.o_rs = K.view3(out, B, Lq); a.LSE = lse.data_ptr(); a.dbg |= dbg
         K.call("x2_attn_fwd", K.C.byref(a))
     def bwd():
         K.attn_bwd(q3, k3, v3, K.view3(out, B, Lq), K.view3(dout, B, Lq), B, B, H, Lq, Lk, d ** -0.5, lse, delta,

@@ -339,7 +339,7 @@ def attn_ref(q, k, v, scale, add):
     return O.attention_core(q, k, v, scale, add)
 
 
-def run_attention(K, B, Bkv, H, Lq, Lk, use_bias, use_mask, kv_map, seed):
+def run_attention(K, B, Bkv, H, Lq, Lk, use_bias, use_mask, kv_map, seed, bias_log2=False):
     d = 64
     qh = bf(rnd(B, Lq, H * d, seed=seed)); kh = bf(rnd(Bkv, Lk, H * d, seed=seed + 1)); vh = bf(rnd(Bkv, Lk, H * d, seed=seed + 2))
     doh = bf(rnd(B, Lq, H * d, seed=seed + 3))
@@ -370,6 +370,9 @@ def run_attention(K, B, Bkv, H, Lq, Lk, use_bias, use_mask, kv_map, seed):
     if use_bias:
         bp = torch.zeros(H, Lq, Lkp); bp[:, :, :Lk] = bias
         bT = torch.zeros(H, Lk, Lqp); bT[:, :, :Lq] = bias.transpose(1, 2)
+        if bias_log2:         # the bias in log2 units, as kernels.relpos_bias(log2=True) hands it over: the one-fma score path
+            bp, bT = bp * K.LOG2E, bT * K.LOG2E
+            kw["bias_log2"] = True
         kw.update(bias=bp.to(dev), biasT=bT.to(dev))
     if use_mask:
         mp = torch.zeros(B, Lkp); mp[:, :Lk] = mask
@@ -426,8 +429,10 @@ def test_attention_vision_bias_strip_walking_variants(K, bits):
     _attn_variant(K, bits)
     try:
         run_attention(K, B=3, Bkv=3, H=12, Lq=197, Lk=197, use_bias=True, use_mask=False, kv_map=None, seed=100)
+        run_attention(K, B=3, Bkv=3, H=12, Lq=197, Lk=197, use_bias=True, use_mask=False, kv_map=None, seed=100, bias_log2=True)
         run_attention(K, B=2, Bkv=2, H=3, Lq=70, Lk=70, use_bias=True, use_mask=True, kv_map=None, seed=110)
         run_attention(K, B=2, Bkv=2, H=2, Lq=208, Lk=208, use_bias=True, use_mask=False, kv_map=None, seed=120)
+        run_attention(K, B=2, Bkv=2, H=2, Lq=208, Lk=208, use_bias=True, use_mask=False, kv_map=None, seed=120, bias_log2=True)
     finally:
         _attn_variant(K, -1)
 
@@ -449,6 +454,7 @@ def test_attention_cross_shared_kv(K, bits):
 def test_attention_long_keys(K):
     """N = 577 (384 px) exercises many key tiles of the online softmax."""
     run_attention(K, B=1, Bkv=1, H=2, Lq=577, Lk=577, use_bias=True, use_mask=False, kv_map=None, seed=400)
+    run_attention(K, B=2, Bkv=2, H=4, Lq=577, Lk=577, use_bias=True, use_mask=False, kv_map=None, seed=410, bias_log2=True)
 
 
 @pytest.mark.parametrize("rows,D,period", [(37, 768, 0), (788, 768, 0), (4 * 196, 768, 196), (50, 128, 0), (9, 1536, 0)])

@@ -51,7 +51,7 @@ _SIGS = {
     "x2_assemble_tokens": [P, P, P, I, I, I, P],
     "x2_assemble_tokens_bwd": [P, P, P, I, I, I, P],
     "x2_pool_tokens": [P, P, I, I, I, I, P],
-    "x2_relpos_bias": [P, P, P, P, P, I, I, I, I, P],
+    "x2_relpos_bias": [P, P, P, P, P, I, I, I, I, F, P],
     "x2_relpos_bias_bwd": [P, P, P, P, I, I, I, I, I, P, I, P],
     "x2_embed_fwd": [P, P, P, P, P, I, I, I, P],
     "x2_embed_bwd": [P, P, P, P, P, I, I, I, P],

@@ -41,7 +41,8 @@ struct AttnArgs {
   int ds_ld;                           // dS: [B][H][Lq][ds_ld]
   DropSpec drop;                       // dropout on the attention probabilities (xbert.py:399), element index
                                        // ((b*H + h)*Lq + q) * round_up(Lk,64) + key
-  int dbg;                             // ablation (probes/bench_attn.py): 1 no bias/mask loads, 2 no exp2, 4 no PV MFMAs, 8 no QK MFMAs
+  int dbg;                             // ablation (probes/bench_attn.py): 1 no bias/mask loads, 2 no exp2, 4 no PV MFMAs, 8 no QK MFMAs;
+                                       // 16 (not an ablation): bias / biasT hold bias x log2(e) (x2_relpos_bias with that scale)
   int head_dim;                        // the caller's head dimension: must be 64 (the only one these kernels are built for)
   const uint32_t* drop_epoch;          // device step counter mixed into drop.seed (x2_common.h drop_at_epoch), or NULL
   // filled by the entry points (callers pass zeros): logical grid (x = query / key tiles, y = heads, z = batches) and, when
@@ -124,9 +125,19 @@ __device__ __forceinline__ f32x4 add_bias_mask(f32x4 s, const AttnArgs& a, int h
 
 // the same with the bias / mask values already in registers (loaded at the top of the key tile, so that their L2
 // latency is covered by the QK^T MFMAs instead of sitting between them and the softmax)
-template <bool FULL = false>
+// BL2: the bias is already in log2 units (x log2 e, x2_relpos_bias with scale = log2 e) and there is no mask: one fma per
+// score instead of add + two multiplies + add (these loops are VALU-bound: ISA of the forward kernel)
+template <bool FULL = false, bool BL2 = false>
 __device__ __forceinline__ f32x4 apply_bias_mask(f32x4 s, float4 bb, float4 mm, int key0, int Lk, float sc2) {
   f32x4 o;
+  if constexpr (BL2) {
+    o[0] = fmaf(s[0], sc2, bb.x); o[1] = fmaf(s[1], sc2, bb.y); o[2] = fmaf(s[2], sc2, bb.z); o[3] = fmaf(s[3], sc2, bb.w);
+    if constexpr (!FULL) {
+      o[0] = key0 + 0 < Lk ? o[0] : NEG_BIG; o[1] = key0 + 1 < Lk ? o[1] : NEG_BIG;
+      o[2] = key0 + 2 < Lk ? o[2] : NEG_BIG; o[3] = key0 + 3 < Lk ? o[3] : NEG_BIG;
+    }
+    return o;
+  }
   if constexpr (FULL) {       // every key of the tile exists: no index select
     o[0] = s[0] * sc2 + (bb.x + mm.x) * LOG2E; o[1] = s[1] * sc2 + (bb.y + mm.y) * LOG2E;
     o[2] = s[2] * sc2 + (bb.z + mm.z) * LOG2E; o[3] = s[3] * sc2 + (bb.w + mm.w) * LOG2E;
@@ -138,7 +149,7 @@ __device__ __forceinline__ f32x4 apply_bias_mask(f32x4 s, float4 bb, float4 mm, 
   o[3] = key0 + 3 < Lk ? s[3] * sc2 + (bb.w + mm.w) * LOG2E : NEG_BIG;
   return o;
 }
-template <int QG>
+template <int QG, bool BL2 = false>
 __device__ __forceinline__ void load_bias_mask(const AttnArgs& a, int h, int b, const int (&q)[QG], int key_base, int g, int nsub,
                                                float4 (&bb)[QG][4], float4 (&mm)[4]) {
 #pragma unroll
@@ -153,6 +164,14 @@ __device__ __forceinline__ void load_bias_mask(const AttnArgs& a, int h, int b, 
 #pragma unroll
       for (int gq = 0; gq < QG; ++gq)
         if (nt < nsub) bb[gq][nt] = *reinterpret_cast<const float4*>(a.bias + ((long)h * a.Lq + q[gq]) * a.bias_ld + key_base + nt * 16 + g * 4);
+    // a bias in log2 units (dbg bit 4) reaching a kernel that has no one-fma form (the callers of this function multiply by
+    // log2 e themselves): back to natural units here, a wave-uniform branch outside the per-score arithmetic
+    if (!BL2 && (a.dbg & 16)) {
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int gq = 0; gq < QG; ++gq) { bb[gq][nt].x *= LN2; bb[gq][nt].y *= LN2; bb[gq][nt].z *= LN2; bb[gq][nt].w *= LN2; }
+    }
   }
   if (a.mask && !(a.dbg & 1)) {
 #pragma unroll
@@ -168,7 +187,7 @@ __device__ __forceinline__ void load_bias_mask(const AttnArgs& a, int h, int b, 
 // NS: LDS slots.  Resident form: one per key tile (4 covers Lk <= 256; 1 for Lk <= 64, the 30-token text sequences: 16 KB
 // per workgroup instead of 32-64 KB lets 10 of the 2-wave workgroups share a CU instead of 5, and these launches are a
 // serial load -> multiply -> store chain per workgroup whose only latency hiding is other workgroups).
-template <int QW, int QG, bool RES, int NS = (RES ? 4 : 2), int WPS = (QG > 1 ? 2 : 4)>     // WPS: waves per SIMD the registers must allow
+template <int QW, int QG, bool RES, int NS = (RES ? 4 : 2), int WPS = (QG > 1 ? 2 : 4), bool BL2 = false>     // WPS: waves per SIMD the registers must allow
 __global__ __launch_bounds__(64 * QW, WPS) void attn_fwd_kernel(AttnArgs a) {
   const DropSpec drop_ = drop_at_epoch(a.drop, a.drop_epoch);
   constexpr int NT = 64 * QW;
@@ -236,7 +255,7 @@ __global__ __launch_bounds__(64 * QW, WPS) void attn_fwd_kernel(AttnArgs a) {
     }
     const int nsub = FULL ? 4 : (idle ? 0 : min(4, (a.Lk - kt * KT + 15) >> 4));      // valid 16-key sub-tiles of this tile (wave-uniform)
     float4 bbv[QG][4], mmv[4];
-    load_bias_mask<QG>(a, h, b, q, kt * KT, g, nsub, bbv, mmv);
+    load_bias_mask<QG, BL2>(a, h, b, q, kt * KT, g, nsub, bbv, mmv);
     f32x4 st[QG][4];
 #pragma unroll
     for (int gq = 0; gq < QG; ++gq)
@@ -258,7 +277,7 @@ __global__ __launch_bounds__(64 * QW, WPS) void attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) {
         if (nt >= nsub) continue;
-        st[gq][nt] = apply_bias_mask<FULL>(st[gq][nt], bbv[gq][nt], mmv[nt], kt * KT + nt * 16 + g * 4, a.Lk, sc2);
+        st[gq][nt] = apply_bias_mask<FULL, BL2>(st[gq][nt], bbv[gq][nt], mmv[nt], kt * KT + nt * 16 + g * 4, a.Lk, sc2);
         mx = fmaxf(fmaxf(mx, fmaxf(st[gq][nt][0], st[gq][nt][1])), fmaxf(st[gq][nt][2], st[gq][nt][3]));
       }
       mx = group_max(mx);
@@ -322,7 +341,7 @@ __global__ __launch_bounds__(64 * QW, WPS) void attn_fwd_kernel(AttnArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------ backward: dQ (+ dS)
-template <int QW, int QG, bool RES, int NS = (RES ? 4 : 2), int WPS = (QG > 1 ? 2 : 4)>
+template <int QW, int QG, bool RES, int NS = (RES ? 4 : 2), int WPS = (QG > 1 ? 2 : 4), bool BL2 = false>
 __global__ __launch_bounds__(64 * QW, WPS) void attn_bwd_dq_kernel(AttnArgs a) {
   const DropSpec drop_ = drop_at_epoch(a.drop, a.drop_epoch);
   constexpr int NT = 64 * QW;
@@ -392,7 +411,7 @@ __global__ __launch_bounds__(64 * QW, WPS) void attn_bwd_dq_kernel(AttnArgs a) {
     }
     const int nsub = FULL ? 4 : (idle ? 0 : min(4, (a.Lk - kt * KT + 15) >> 4));
     float4 bbv[QG][4], mmv[4];
-    load_bias_mask<QG>(a, h, b, q, kt * KT, g, nsub, bbv, mmv);
+    load_bias_mask<QG, BL2>(a, h, b, q, kt * KT, g, nsub, bbv, mmv);
     f32x4 ds[QG][4];
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
@@ -416,7 +435,7 @@ __global__ __launch_bounds__(64 * QW, WPS) void attn_bwd_dq_kernel(AttnArgs a) {
       const int key0 = kt * KT + nt * 16 + g * 4;
 #pragma unroll
       for (int gq = 0; gq < QG; ++gq) {
-        s[gq] = apply_bias_mask<FULL>(s[gq], bbv[gq][nt], mmv[nt], key0, a.Lk, sc2);
+        s[gq] = apply_bias_mask<FULL, BL2>(s[gq], bbv[gq][nt], mmv[nt], key0, a.Lk, sc2);
         if (drop_.thr16) {
           float dm[4];
           drop_mul4(drop_, (uint32_t)(((long)b * a.H + h) * a.Lq + q[gq]) * (uint32_t)lkp + (uint32_t)key0, dm);
@@ -702,7 +721,7 @@ __device__ __forceinline__ void walk_load_kv(const AttnArgs& a, const bf16_t* Kp
     if (kt < nkt) { tile_store_bounded<NT>(rva[kt], vreg, kt * KT, tid); tile_store_bounded<NT>(rka[kt], kreg, kt * KT, tid); }
 }
 
-template <int QW>
+template <int QW, bool BL2 = false>
 __global__ __launch_bounds__(64 * QW, 3) void attn_fwd_walk_kernel(AttnArgs a) {
   const DropSpec drop_ = drop_at_epoch(a.drop, a.drop_epoch);
   constexpr int NT = 64 * QW;
@@ -734,7 +753,7 @@ __global__ __launch_bounds__(64 * QW, 3) void attn_fwd_walk_kernel(AttnArgs a) {
       const uint32_t ktile = kbase + kt * KT * 128, vtile = vbase + kt * KT * 128;
       const int nsub = FULL ? 4 : min(4, (a.Lk - kt * KT + 15) >> 4);
       float4 bbv[1][4], mmv[4];
-      load_bias_mask<1>(a, h, b, q1, kt * KT, g, nsub, bbv, mmv);
+      load_bias_mask<1, BL2>(a, h, b, q1, kt * KT, g, nsub, bbv, mmv);
       f32x4 st[4];
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) st[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -749,7 +768,7 @@ __global__ __launch_bounds__(64 * QW, 3) void attn_fwd_walk_kernel(AttnArgs a) {
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) {
         if (nt >= nsub) continue;
-        st[nt] = apply_bias_mask<FULL>(st[nt], bbv[0][nt], mmv[nt], kt * KT + nt * 16 + g * 4, a.Lk, sc2);
+        st[nt] = apply_bias_mask<FULL, BL2>(st[nt], bbv[0][nt], mmv[nt], kt * KT + nt * 16 + g * 4, a.Lk, sc2);
         mx = fmaxf(fmaxf(mx, fmaxf(st[nt][0], st[nt][1])), fmaxf(st[nt][2], st[nt][3]));
       }
       mx = group_max(mx);
@@ -799,7 +818,7 @@ __global__ __launch_bounds__(64 * QW, 3) void attn_fwd_walk_kernel(AttnArgs a) {
   }
 }
 
-template <int QW>
+template <int QW, bool BL2 = false>
 __global__ __launch_bounds__(64 * QW, 3) void attn_bwd_dq_walk_kernel(AttnArgs a) {
   const DropSpec drop_ = drop_at_epoch(a.drop, a.drop_epoch);
   constexpr int NT = 64 * QW;
@@ -839,7 +858,7 @@ __global__ __launch_bounds__(64 * QW, 3) void attn_bwd_dq_walk_kernel(AttnArgs a
       const uint32_t ktile = kbase + kt * KT * 128, vtile = vbase + kt * KT * 128;
       const int nsub = FULL ? 4 : min(4, (a.Lk - kt * KT + 15) >> 4);
       float4 bbv[1][4], mmv[4];
-      load_bias_mask<1>(a, h, b, q1, kt * KT, g, nsub, bbv, mmv);
+      load_bias_mask<1, BL2>(a, h, b, q1, kt * KT, g, nsub, bbv, mmv);
       f32x4 ds[4];
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) {
@@ -851,7 +870,7 @@ __global__ __launch_bounds__(64 * QW, 3) void attn_bwd_dq_walk_kernel(AttnArgs a
           dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(vtile, nt * 16 + fi, ks * 4 + g), dof[ks], dp, 0, 0, 0);
         }
         const int key0 = kt * KT + nt * 16 + g * 4;
-        s = apply_bias_mask<FULL>(s, bbv[0][nt], mmv[nt], key0, a.Lk, sc2);
+        s = apply_bias_mask<FULL, BL2>(s, bbv[0][nt], mmv[nt], key0, a.Lk, sc2);
         if (drop_.thr16) {
           float dm[4];
           drop_mul4(drop_, (uint32_t)(((long)b * a.H + h) * a.Lq + q) * (uint32_t)lkp + (uint32_t)key0, dm);
@@ -885,7 +904,7 @@ __global__ __launch_bounds__(64 * QW, 3) void attn_bwd_dq_walk_kernel(AttnArgs a
 
 // ------------------------------------------------------------------------------------------ backward: dK, dV
 // KW waves, KG groups of 16 keys per wave; the workgroup walks every (sequence using this K/V batch, 64-query tile).
-template <int KW, int KG, bool RES, int NS = (RES ? 4 : 2), int WPS = ((KW == 4 && !RES) ? 3 : 4)>
+template <int KW, int KG, bool RES, int NS = (RES ? 4 : 2), int WPS = ((KW == 4 && !RES) ? 3 : 4), bool BL2 = false>
 // (second launch bound = waves per SIMD the register allocation must allow: these kernels hide their load -> MFMA -> exp
 // chains only behind other waves, and left alone hipcc spends 170-230 VGPRs on the short-sequence forms (2 waves per SIMD);
 // capped at 128 they run 1.3-1.5x faster.  The streamed 4-wave form needs more than 128: 35 spills under the cap.)
@@ -986,6 +1005,12 @@ __global__ __launch_bounds__(64 * KW, WPS) void attn_bwd_dkv_kernel(AttnArgs a) 
 #pragma unroll
           for (int gk = 0; gk < KG; ++gk)
             if (t < nsub) btv[gk][t] = *reinterpret_cast<const float4*>(a.biasT + ((long)h * a.Lk + key[gk]) * a.biasT_ld + qt * KT + t * 16 + g * 4);
+        if (!BL2 && (a.dbg & 16)) {      // log2-unit bias in a kernel without the one-fma form: see load_bias_mask
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int gk = 0; gk < KG; ++gk) { btv[gk][t].x *= LN2; btv[gk][t].y *= LN2; btv[gk][t].z *= LN2; btv[gk][t].w *= LN2; }
+        }
       }
       f32x4 p[KG][4], ds[KG][4];
 #pragma unroll
@@ -1019,7 +1044,7 @@ __global__ __launch_bounds__(64 * KW, WPS) void attn_bwd_dkv_kernel(AttnArgs a) 
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const bool ok = FULL || (kok[gk] && (qq0 + r < a.Lq));
-            const float pv = ok ? fast_exp2(s[gk][r] * sc2 + bbv[r] * LOG2E + mk[gk] - lsv[r]) : 0.f;
+            const float pv = ok ? fast_exp2(BL2 ? fmaf(s[gk][r], sc2, bbv[r]) - lsv[r] : s[gk][r] * sc2 + bbv[r] * LOG2E + mk[gk] - lsv[r]) : 0.f;
             float dm = 1.f;
             if (drop_.thr16)
               dm = drop_mul(drop_, (uint32_t)(((long)b * a.H + h) * a.Lq + min(qq0 + r, a.Lq - 1)) * (uint32_t)lkp + (uint32_t)key[gk]);
@@ -1119,6 +1144,7 @@ extern "C" int x2_attn_fwd(const AttnArgs* pa, void* stream) {
   a.grid_nx = a.grid_ny = a.grid_nz = a.grid_map = 0;
   if (int e = check_common(a, "x2_attn_fwd")) return e;
   const bool xm = a.bias != nullptr && !a.kv_idx;        // XCD-aware block order for the kernels that read a [H][Lq][Lk] bias
+  const bool bl2 = (a.dbg & 16) && a.bias && !a.mask;   // bias handed over in log2 units (kernels.relpos_bias(log2=True)), no mask
   X2_REQUIRE(a.Q && a.K && a.V && a.Out && a.LSE, "x2_attn_fwd: null tensor");
   X2_REQUIRE((a.o_rs % 4 | a.o_bs % 4) == 0, "x2_attn_fwd: output strides");
   const hipStream_t st = (hipStream_t)stream;
@@ -1135,11 +1161,13 @@ extern "C" int x2_attn_fwd(const AttnArgs* pa, void* stream) {
     hipLaunchKernelGGL((attn_fwd_kernel<4, 2, false>), dim3((a.Lq + 127) / 128, a.H, a.B), dim3(256), 0, st, a);
   else if (a.Lk > 256 && a.Lq > 64 && !(attn_variant() & 32))      // long sequences (X2VLM-large, N = 577): 8 waves share each streamed K/V tile (285 -> 254 us)
     { if (attn_variant() & 32768) attn_launch(attn_fwd_kernel<8, 1, false, 2, 2>, a, (a.Lq + 127) / 128, a.H, a.B, 512, xm, st);
+      else if (bl2) attn_launch(attn_fwd_kernel<8, 1, false, 2, 4, true>, a, (a.Lq + 127) / 128, a.H, a.B, 512, xm, st);
       else attn_launch(attn_fwd_kernel<8, 1, false>, a, (a.Lq + 127) / 128, a.H, a.B, 512, xm, st); }
   else if (a.Lq <= 64 || a.Lk > 256) hipLaunchKernelGGL((attn_fwd_kernel<4, 1, false>), dim3((a.Lq + 63) / 64, a.H, a.B), dim3(256), 0, st, a);
   else if (attn_variant() & 4) hipLaunchKernelGGL((attn_fwd_kernel<4, 2, true>), dim3((a.Lq + 127) / 128, a.H, a.B), dim3(256), 0, st, a);
   else if ((attn_variant() & 4096) && !a.kv_idx && a.Lk <= WALK_ROWS)      // staged: one strip-walking workgroup per (sequence, head)
-    attn_launch(attn_fwd_walk_kernel<4>, a, 1, a.H, a.B, 256, xm, st);
+    { if (bl2) attn_launch(attn_fwd_walk_kernel<4, true>, a, 1, a.H, a.B, 256, xm, st);
+      else attn_launch(attn_fwd_walk_kernel<4>, a, 1, a.H, a.B, 256, xm, st); }
   else attn_launch(attn_fwd_kernel<8, 1, true>, a, (a.Lq + 127) / 128, a.H, a.B, 512, xm, st);
   return x2_check_launch("x2_attn_fwd");
 }
@@ -1149,6 +1177,7 @@ extern "C" int x2_attn_bwd(const AttnArgs* pa, void* stream) {
   a.grid_nx = a.grid_ny = a.grid_nz = a.grid_map = 0;
   if (int e = check_common(a, "x2_attn_bwd")) return e;
   const bool xm = a.bias != nullptr && !a.kv_idx, xmT = a.biasT != nullptr && !a.seq_off;
+  const bool bl2 = (a.dbg & 16) && a.bias && a.biasT && !a.mask;
   X2_REQUIRE(a.Q && a.K && a.V && a.O && a.dO && a.dQ && a.dK && a.dV && a.LSE && a.Delta, "x2_attn_bwd: null tensor");
   X2_REQUIRE(!a.bias || (a.biasT && a.biasT_ld % 64 == 0 && a.biasT_ld >= a.Lq), "x2_attn_bwd: biasT [H][Lk][ld%%64==0] required with bias");
   X2_REQUIRE(!a.dS || (a.ds_ld % 64 == 0 && a.ds_ld >= a.Lk), "x2_attn_bwd: ds_ld must be a multiple of 64 covering Lk");
@@ -1165,11 +1194,13 @@ extern "C" int x2_attn_bwd(const AttnArgs* pa, void* stream) {
     hipLaunchKernelGGL((attn_bwd_dq_kernel<4, 2, false>), dim3((a.Lq + 127) / 128, a.H, a.B), dim3(256), 0, st, a);
   else if (a.Lk > 256 && a.Lq > 64 && !(attn_variant() & 64))      // N = 577: dQ + dK/dV 810 -> 652 us with 8-wave workgroups
     { if (attn_variant() & 32768) attn_launch(attn_bwd_dq_kernel<8, 1, false, 2, 2>, a, (a.Lq + 127) / 128, a.H, a.B, 512, xm, st);
+      else if (bl2) attn_launch(attn_bwd_dq_kernel<8, 1, false, 2, 4, true>, a, (a.Lq + 127) / 128, a.H, a.B, 512, xm, st);
       else attn_launch(attn_bwd_dq_kernel<8, 1, false>, a, (a.Lq + 127) / 128, a.H, a.B, 512, xm, st); }
   else if (a.Lq <= 64 || a.Lk > 256) hipLaunchKernelGGL((attn_bwd_dq_kernel<4, 1, false>), dim3((a.Lq + 63) / 64, a.H, a.B), dim3(256), 0, st, a);
   else if (attn_variant() & 2) hipLaunchKernelGGL((attn_bwd_dq_kernel<4, 2, true>), dim3((a.Lq + 127) / 128, a.H, a.B), dim3(256), 0, st, a);
   else if ((attn_variant() & 8192) && !a.kv_idx && a.Lk <= WALK_ROWS)
-    attn_launch(attn_bwd_dq_walk_kernel<4>, a, 1, a.H, a.B, 256, xm, st);
+    { if (bl2) attn_launch(attn_bwd_dq_walk_kernel<4, true>, a, 1, a.H, a.B, 256, xm, st);
+      else attn_launch(attn_bwd_dq_walk_kernel<4>, a, 1, a.H, a.B, 256, xm, st); }
   else attn_launch(attn_bwd_dq_kernel<8, 1, true>, a, (a.Lq + 127) / 128, a.H, a.B, 512, xm, st);
   if (int e = x2_check_launch("x2_attn_bwd(dq)")) return e;
   const bool res = !a.seq_off && a.Lq > 64 && a.Lq <= 256;   // one sequence per K/V batch, 2..4 query tiles: resident Q/dO
@@ -1181,11 +1212,13 @@ extern "C" int x2_attn_bwd(const AttnArgs* pa, void* stream) {
     // 8 waves (128 keys) share the resident Q / dO image (133 KB: one workgroup per CU either way): 206 -> 189 us per
     // vision layer against 4-wave workgroups, which left 4 waves on a CU (probes/bench_attn.py)
     if (attn_variant() & 32768) attn_launch(attn_bwd_dkv_kernel<8, 1, true, 4, 2>, a, (a.Lk + 127) / 128, a.H, a.Bkv, 512, xmT, st);
+    else if (bl2) attn_launch(attn_bwd_dkv_kernel<8, 1, true, 4, 4, true>, a, (a.Lk + 127) / 128, a.H, a.Bkv, 512, xmT, st);
     else attn_launch(attn_bwd_dkv_kernel<8, 1, true>, a, (a.Lk + 127) / 128, a.H, a.Bkv, 512, xmT, st);
   } else if (res) {
     hipLaunchKernelGGL((attn_bwd_dkv_kernel<4, 1, true>), dim3((a.Lk + 63) / 64, a.H, a.Bkv), dim3(256), 0, st, a);
   } else if (a.Lk > 256 && !a.seq_off && !(attn_variant() & 128)) {
     if (attn_variant() & 32768) attn_launch(attn_bwd_dkv_kernel<8, 1, false, 2, 2>, a, (a.Lk + 127) / 128, a.H, a.Bkv, 512, xmT, st);
+    else if (bl2) attn_launch(attn_bwd_dkv_kernel<8, 1, false, 2, 4, true>, a, (a.Lk + 127) / 128, a.H, a.Bkv, 512, xmT, st);
     else attn_launch(attn_bwd_dkv_kernel<8, 1, false>, a, (a.Lk + 127) / 128, a.H, a.Bkv, 512, xmT, st);
   } else {
     hipLaunchKernelGGL((attn_bwd_dkv_kernel<4, 1, false>), dim3((a.Lk + 63) / 64, a.H, a.Bkv), dim3(256), 0, st, a);

@@ -728,7 +728,7 @@ extern "C" int x2_pool_tokens(float* x, const float* w, int B, int P, int D, int
 // 57 us per X2VLM-large block).
 __global__ __launch_bounds__(256) void relpos_bias_kernel(const float* __restrict__ table, const long* __restrict__ index,
                                                           const long* __restrict__ indexT, float* bias, float* biasT, int N, int H,
-                                                          int ld, int ldT) {
+                                                          int ld, int ldT, float scale) {
   const long total = (long)N * N;
   long e = blockIdx.x * 256L + threadIdx.x;
   if (e >= total) return;
@@ -737,22 +737,22 @@ __global__ __launch_bounds__(256) void relpos_bias_kernel(const float* __restric
   if (indexT && biasT) {
     const long idt = indexT[e];
     for (int h = 0; h < H; ++h) {
-      bias[((long)h * N + i) * ld + j] = table[idx * H + h];
-      biasT[((long)h * N + i) * ldT + j] = table[idt * H + h];
+      bias[((long)h * N + i) * ld + j] = table[idx * H + h] * scale;
+      biasT[((long)h * N + i) * ldT + j] = table[idt * H + h] * scale;
     }
     return;
   }
   for (int h = 0; h < H; ++h) {
-    const float v = table[idx * H + h];
+    const float v = table[idx * H + h] * scale;
     bias[((long)h * N + i) * ld + j] = v;
     if (biasT) biasT[((long)h * N + j) * ldT + i] = v;
   }
 }
 extern "C" int x2_relpos_bias(const float* table, const long* index, const long* indexT, float* bias, float* biasT, int N, int H, int ld,
-                              int ldT, void* stream) {
+                              int ldT, float scale, void* stream) {
   X2_REQUIRE(N > 0 && H > 0 && ld >= N && (!biasT || ldT >= N), "x2_relpos_bias: N=%d H=%d ld=%d ldT=%d", N, H, ld, ldT);
   hipLaunchKernelGGL(relpos_bias_kernel, dim3((int)(((long)N * N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, table, index, indexT,
-                     bias, biasT, N, H, ld, ldT);
+                     bias, biasT, N, H, ld, ldT, scale);
   return x2_check_launch("x2_relpos_bias");
 }
 // dtable[index[i][j]][h] += sum_b dS[b][h][i][j]   (dS bf16 [B][H][N][ld], ld % 8 == 0), without atomics:

@@ -482,11 +482,11 @@ class VisionEncoderFn(torch.autograd.Function):
             wqkv, _ = BANK.linear(p[b + "attn.qkv.weight"])
             qkv_bias = BANK.vector(p[b + "attn.q_bias"], D, p[b + "attn.v_bias"])          # no k bias: beit2.py:129
             qkv = K.gemm_nt(h1, wqkv, bias=qkv_bias)
-            bias, biasT = K.relpos_bias(p[b + "attn.relative_position_bias_table"].detach(), meta["rel_index"])
+            bias, biasT = K.relpos_bias(p[b + "attn.relative_position_bias_table"].detach(), meta["rel_index"], log2=True)
             att = torch.empty(M, D, device=x.device, dtype=BF16)
             lse = torch.empty(B * H * T, device=x.device, dtype=F32)
             K.attn_fwd(K.view3(qkv, B, T, 0), K.view3(qkv, B, T, D), K.view3(qkv, B, T, 2 * D), B, B, H, T, T, scale,
-                       K.view3(att, B, T), lse, bias=bias)
+                       K.view3(att, B, T), lse, bias=bias, bias_log2=True)
             wproj, _ = BANK.linear(p[b + "attn.proj.weight"])
             aux1 = torch.empty(M, D, device=x.device, dtype=BF16)
             x1 = K.gemm_nt(att, wproj, bias=p[b + "attn.proj.bias"], gamma=p[b + "gamma_1"], resid=x, aux=aux1, out_dtype=F32,
@@ -594,7 +594,7 @@ class VisionEncoderFn(torch.autograd.Function):
             dS_i = torch.empty_like(dS) if WGRAD_QUEUE is not None else dS
             K.attn_bwd(K.view3(qkv, B, T, 0), K.view3(qkv, B, T, D), K.view3(qkv, B, T, 2 * D), K.view3(att, B, T),
                        K.view3(datt, B, T), B, B, H, T, T, scale, lse, delta, K.view3(dqkv, B, T, 0), K.view3(dqkv, B, T, D),
-                       K.view3(dqkv, B, T, 2 * D), dS=dS_i, bias=bias, biasT=biasT)
+                       K.view3(dqkv, B, T, 2 * D), dS=dS_i, bias=bias, biasT=biasT, bias_log2=True)
             if WGRAD_QUEUE is not None:
                 tbl_a, qb_a = G["attn.relative_position_bias_table"].detach(), G["qkv_bias"].detach()
                 po.append(lambda dS_i=dS_i, tbl_a=tbl_a: K.relpos_bias_bwd(dS_i, meta["rel_index"], tbl_a))

@@ -224,7 +224,7 @@ def gemm_tn_grouped(problems, accumulate=False, split=0):
 # ----------------------------------------------------------------------------- attention
 
 def _attn_args(q, k, v, B, Bkv, H, Lq, Lk, scale, bias=None, biasT=None, mask=None, kv_idx=None, seq_off=None,
-               seq_ids=None, drop=NO_DROP, head_dim=64):
+               seq_ids=None, drop=NO_DROP, head_dim=64, bias_log2=False):
     """q/k/v: (tensor, batch_stride, row_stride) views in elements; data pointer already at head 0."""
     a = AttnArgs()
     a.Q, a.q_bs, a.q_rs = q
@@ -232,6 +232,7 @@ def _attn_args(q, k, v, B, Bkv, H, Lq, Lk, scale, bias=None, biasT=None, mask=No
     a.V, a.v_bs, a.v_rs = v
     a.B, a.Bkv, a.H, a.Lq, a.Lk, a.scale = B, Bkv, H, Lq, Lk, scale
     a.head_dim = head_dim
+    a.dbg = 16 if bias_log2 else 0
     a.drop_thr16, a.drop_seed, a.drop_scale = drop[:3]
     a.drop_epoch = ptr(drop[3])
     if bias is not None:
@@ -412,14 +413,20 @@ def pool_tokens(x, w=None, bwd=False):
     return x
 
 
-def relpos_bias(table, index, want_T=True):
+LOG2E = 1.4426950408889634
+
+
+def relpos_bias(table, index, want_T=True, log2=False):
+    """log2: the gathered bias times log2(e) - the unit the attention kernels' softmax works in; pass bias_log2=True to
+    attn_fwd / attn_bwd with it (one fma per score instead of four VALU operations)."""
     N = index.shape[0]
     H = table.shape[1]
     ld = round_up(N, 64)
     # pad columns stay undefined: the attention kernels select on key < Lk / query < Lq before using a bias value
     bias = torch.empty(H, N, ld, device=table.device, dtype=F32)
     biasT = torch.empty(H, N, ld, device=table.device, dtype=F32) if want_T else None
-    call("x2_relpos_bias", ptr(table), ptr(index), ptr(_relpos_index_t(index)) if want_T else None, ptr(bias), ptr(biasT), N, H, ld, ld)
+    call("x2_relpos_bias", ptr(table), ptr(index), ptr(_relpos_index_t(index)) if want_T else None, ptr(bias), ptr(biasT), N, H, ld, ld,
+         LOG2E if log2 else 1.0)
     return bias, biasT
 
 
