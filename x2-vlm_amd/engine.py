@@ -185,7 +185,8 @@ FUSE_DGELU_COLSUM = os.environ.get("X2_FUSE_DGELU_COLSUM", "1") == "1"       # f
 # layer-scale backward inside the LayerNorm backward that feeds it (x2_layernorm_bwd_layerscale).  Measured in the step (same
 # box, profiles/r03c_ab_switches.txt): 25.16 ms with it, 24.92 without - the fused kernel needs 156 VGPRs (3 waves per SIMD
 # instead of 4) and the HBM-bound LayerNorm backward loses more to the lower occupancy than the saved 38.7 MB read and
-# launch give back.  Off by default; the kernel stays (parity-tested) for a register-leaner rewrite.
+# launch give back.  A register-leaner form (the two extra column sums as ds_add_f32 into LDS: 128 VGPRs, no spill) was worse:
+# 25.22 vs 23.58 ms - the LDS atomics of four waves on the same columns serialise.  Off by default; the kernel stays, parity-tested.
 FUSE_LAYERSCALE_BWD = os.environ.get("X2_FUSE_LAYERSCALE_BWD", "0") == "1"
 KEEP_MLM_LOGITS = False     # tests: also materialise the MLM logits (inspection only; the loss still comes from the fused path)
 # Tied decoder / word-embedding gradient in ONE buffer (graph.SegmentedStep switches it on for its passes): the MLM head's
