@@ -7,7 +7,9 @@ import re
 import sys
 
 FLOPS = {   # TFLOP per step: (NT algorithmic, TN algorithmic, attention)
-    "base": (7.556, 3.786, 0.399), "large": (28.2, 13.9, 5.62), "video": (4.84, 2.42, 0.40),
+    # NT / TN: launches x GFLOP per launch of bench.py's accounting (profiles/r03k_bench_*.json); attention: 3.5 x the forward's
+    # 4*B*H*Lq*Lk*64 over vision (+ text / fusion self- and cross-attention for base)
+    "base": (7.556, 3.786, 0.399), "large": (25.825, 12.927, 5.62), "video": (4.706, 2.360, 0.40),
 }
 
 
@@ -49,7 +51,9 @@ def table(path, ncols):
     return rows
 
 
-stats, fetch, write = table(sys.argv[1], 6), table(sys.argv[2], 4), table(sys.argv[3], 4)
+stats = table(sys.argv[1], 6)
+have_pmc = sys.argv[2] != "-"
+fetch, write = (table(sys.argv[2], 4), table(sys.argv[3], 4)) if have_pmc else ([], [])
 steps_t, steps_p, cfg = int(sys.argv[4]), int(sys.argv[5]), sys.argv[6]
 fam = {}
 for n, calls, total_us in stats:
@@ -68,7 +72,8 @@ for name, f in sorted(fam.items(), key=lambda kv: -kv[1]["us"]):
     ms = f["us"] / steps_t / 1e3
     gb = (f["rd"] + f["wr"]) / steps_p / 1e9
     tf = fl.get(name)
-    print("| %s | %.0f | %.2f | %.1f %% | %s | %s | %s | %.2f | %.2f | %.0f %% (%.0f %%) |" % (
+    mem = "%.2f | %.2f | %.0f %% (%.0f %%)" % (gb, gb / ms, 100 * gb / ms / 8.0, 100 * gb / ms / 6.3) if have_pmc else "- | - | -"
+    print("| %s | %.0f | %.2f | %.1f %% | %s | %s | %s | %s |" % (
         name, f["calls"] / steps_t, ms, 100 * f["us"] / tot, "%.2f" % tf if tf else "-", "%.0f" % (tf / ms * 1e3) if tf else "-",
-        "%.1f %%" % (100 * tf / ms * 1e3 / 2500) if tf else "-", gb, gb / ms, 100 * gb / ms / 8.0, 100 * gb / ms / 6.3))
+        "%.1f %%" % (100 * tf / ms * 1e3 / 2500) if tf else "-", mem))
 print("| **all kernels, serialized** | %.0f | **%.2f** | | | | | | | |" % (sum(f["calls"] for f in fam.values()) / steps_t, tot / steps_t / 1e3))
