@@ -41,25 +41,50 @@ class X2Comm:
         _check(lib().x2_comm_unique_id(buf), "x2_comm_unique_id")
         return buf.raw
 
+    _SEQ = 0          # communicators this process has created through from_store (every rank counts the same way)
+
     @classmethod
     def from_store(cls, store, rank, world, key="x2_comm_id"):
-        """store: torch.distributed Store (set/get), or a file path shared by all ranks."""
+        """store: torch.distributed Store (set/get), or a file path shared by all ranks.  Every communicator gets a key of
+        its own (`key` + a per-process sequence number: all ranks create their communicators in the same order), so a second
+        communicator - or an id left behind by an earlier run in a file store - can never be picked up for this one; with a
+        path the launch id (MASTER_PORT / TORCHELASTIC_RUN_ID) is part of the file name, and rank 0 removes the file once every
+        rank has read it (ranks acknowledge through marker files)."""
+        cls._SEQ += 1
+        key = "%s.%d" % (key, cls._SEQ)
         if isinstance(store, str):
+            launch = os.environ.get("TORCHELASTIC_RUN_ID") or os.environ.get("MASTER_PORT") or "0"
+            path = "%s.%s.%s" % (store, launch, key)
             if rank == 0:
-                with open(store + ".tmp", "wb") as f:
+                with open(path + ".tmp", "wb") as f:
                     f.write(cls.unique_id())
-                os.replace(store + ".tmp", store)
+                os.replace(path + ".tmp", path)
             t0 = time.time()
-            while not os.path.exists(store):
+            while not os.path.exists(path):
                 if time.time() - t0 > 120:
-                    raise X2HipError("x2_comm: rank 0 never published the RCCL id at %s" % store)
+                    raise X2HipError("x2_comm: rank 0 never published the RCCL id at %s" % path)
                 time.sleep(0.05)
-            with open(store, "rb") as f:
+            with open(path, "rb") as f:
                 ident = f.read()
-        else:
+            comm = cls(ident, rank, world)        # x2_comm_init returns once every rank has joined: all have read the id
+            open("%s.ack%d" % (path, rank), "w").close()
             if rank == 0:
-                store.set(key, cls.unique_id())
-            ident = bytes(store.get(key))
+                t0 = time.time()
+                while not all(os.path.exists("%s.ack%d" % (path, r)) for r in range(world)) and time.time() - t0 < 120:
+                    time.sleep(0.05)
+                for r in range(world):
+                    try:
+                        os.remove("%s.ack%d" % (path, r))
+                    except OSError:
+                        pass
+                try:
+                    os.remove(path)
+                except OSError:
+                    pass
+            return comm
+        if rank == 0:
+            store.set(key, cls.unique_id())
+        ident = bytes(store.get(key))         # blocks until rank 0 has set THIS communicator's key
         return cls(ident, rank, world)
 
     def info(self):

@@ -168,7 +168,9 @@ class SegmentedStep:
         env = os.environ.get("X2_SEG_VISION_CUT")
         if vision_cuts is None:
             # default: thirds (same box, base: no cut 25.07 ms, one cut 24.88, two cuts 24.72 - profiles/r03f_ab_segments.txt)
-            vision_cuts = [int(c) for c in env.split(",") if c] if env is not None else [depth // 3, 2 * depth // 3]
+            # (world > 1: quarters - the last stage's arenas are the only all-reduce that nothing can overlap)
+            parts = 4 if world > 1 else 3
+            vision_cuts = [int(c) for c in env.split(",") if c] if env is not None else [depth * i // parts for i in range(1, parts)]
         self.vcuts = sorted(c for c in vision_cuts if 0 < c < depth)
         self.defer_vision_wgrad = os.environ.get("X2_SEG_VISION_WGRAD", "1") == "1"
         self.prefetch_casts = os.environ.get("X2_SEG_PREFETCH_CASTS", "1") == "1" and recast_weights
