@@ -14,7 +14,7 @@ def timeit(fn, iters=20):
     b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b) / iters * 1e3
 
-def case(B, H, Lq, Lk, bias, mask):
+def case(B, H, Lq, Lk, bias, mask, drop=None):
     d = 64
     qkv = torch.randn(B * Lq, 3 * H * d, device=dev).bfloat16()
     kv = qkv if Lq == Lk else torch.randn(B * Lk, 3 * H * d, device=dev).bfloat16()
@@ -36,7 +36,8 @@ def case(B, H, Lq, Lk, bias, mask):
         K.call("x2_attn_fwd", K.C.byref(a))
     def bwd():
         K.attn_bwd(q3, k3, v3, K.view3(out, B, Lq), K.view3(dout, B, Lq), B, B, H, Lq, Lk, d ** -0.5, lse, delta,
-                   K.view3(dqkv, B, Lq, 0), K.view3(dkv, B, Lk, HD), K.view3(dkv, B, Lk, 2 * HD), dS=dS, **kw)
+                   K.view3(dqkv, B, Lq, 0), K.view3(dkv, B, Lk, HD), K.view3(dkv, B, Lk, 2 * HD), dS=dS,
+                   **({"drop": drop} if drop else {}), **kw)
     return fwd, bwd
 
 LIB = importlib.import_module("x2-vlm_amd._lib").lib()
@@ -71,8 +72,14 @@ for name, B, H, Lq, Lk, bias, mask in [("vision large", 32, 16, 577, 577, True, 
     if name == "vision":
         print("   fwd ablation: " + "  ".join("d%d %.1fus" % (g, timeit(lambda g=g: fwd(g))) for g in (0, 1, 2, 3, 4, 8, 12, 15)))
 
+# backward with probability dropout 0.1 on (as in the training step)
+DROP = K.dropout_spec(0.1, 1234, 7)
+for name, B, H, N in (("vision base N=197", 64, 12, 197), ("vision large N=577", 32, 16, 577)):
+    _, bwd = case(B, H, N, N, True, False, drop=DROP)
+    print("%s bwd with dropout 0.1: %6.1f us" % (name, min(timeit(bwd) for _ in range(3))))
+
 # cross-attention of the fusion stack: 256 text rows on 64 images (the 4-pass batch: positives, MLM, 2 x hard negatives)
-def cross_case(S=256, Bi=64, H=12, L=30, T=197):
+def cross_case(S=256, Bi=64, H=12, L=30, T=197, drop=None):
     d = 64
     g = torch.Generator().manual_seed(0)
     ar = torch.arange(Bi)
@@ -88,8 +95,10 @@ def cross_case(S=256, Bi=64, H=12, L=30, T=197):
     q3, k3, v3 = K.view3(q, S, L), K.view3(kvt, Bi, T, 0), K.view3(kvt, Bi, T, HD)
     fwd = lambda: K.attn_fwd(q3, k3, v3, S, Bi, H, L, T, d ** -0.5, K.view3(out, S, L), lse, **kw)
     bwd = lambda: K.attn_bwd(q3, k3, v3, K.view3(out, S, L), K.view3(dout, S, L), S, Bi, H, L, T, d ** -0.5, lse, delta,
-                             K.view3(dq, S, L), K.view3(dkv, Bi, T, 0), K.view3(dkv, Bi, T, HD), **kw)
+                             K.view3(dq, S, L), K.view3(dkv, Bi, T, 0), K.view3(dkv, Bi, T, HD), **({"drop": drop} if drop else {}), **kw)
     return fwd, bwd
 
 fwd, bwd = cross_case()
 print("cross (256 rows on 64 images)  fwd %6.1fus   bwd(dq+dkv) %6.1fus   [X2_ATTN_VARIANT=%s]" % (timeit(fwd), timeit(bwd), os.environ.get("X2_ATTN_VARIANT", "0")))
+_, bwd = cross_case(drop=DROP)
+print("cross bwd with dropout 0.1: %6.1f us" % min(timeit(bwd) for _ in range(3)))

@@ -918,6 +918,11 @@ __global__ __launch_bounds__(64 * KW, WPS) void attn_bwd_dkv_kernel(AttnArgs a) 
   if (!attn_block(a, bx_, h, bk)) return;
   const float sc2 = a.scale * LOG2E;
   const int lkp = (a.Lk + 63) & ~63;
+  // LEAN: score arithmetic without validity selects, dropout a compile-time property of the tile (see the tile).  Only the
+  // 8-wave resident form (vision, N = 197) takes it: measured r03v, the straight-line code costs the streaming kernels
+  // registers they do not have (N = 577: 41 scratch accesses inside the loop, 516 -> 712 us) and the two-wave text kernels
+  // their latency hiding (30 -> 35 us).
+  constexpr bool LEAN = RES && KW == 8;
 
   int key[KG]; bool kok[KG];
   bf16x8 kf[KG][2], vf[KG][2];
@@ -948,9 +953,12 @@ __global__ __launch_bounds__(64 * KW, WPS) void attn_bwd_dkv_kernel(AttnArgs a) 
       tile_load<NT>(rq, a.Q + bb * a.q_bs + h * HD, a.q_rs, qt * KT, a.Lq, tid);
       tile_load<NT>(rdo, a.dO + bb * a.do_bs + h * HD, a.do_rs, qt * KT, a.Lq, tid);
       if (tid < KT) {
+        // queries past Lq: LSE = +1e30 makes their P (and dS) exactly 0 in the tile arithmetic below, which therefore needs
+        // no per-score validity select (the rows of Q / dO they multiply are clamped copies: finite)
         const int qq = min(qt * KT + tid, a.Lq - 1);
-        rl = a.LSE[((long)bb * a.H + h) * a.Lq + qq];
-        rd = a.Delta[((long)bb * a.H + h) * a.Lq + qq];
+        const bool qv = qt * KT + tid < a.Lq;
+        rl = qv ? a.LSE[((long)bb * a.H + h) * a.Lq + qq] : 1e30f;
+        rd = qv ? a.Delta[((long)bb * a.H + h) * a.Lq + qq] : 0.f;
       }
     };
     auto commit = [&](int buf) {
@@ -986,8 +994,9 @@ __global__ __launch_bounds__(64 * KW, WPS) void attn_bwd_dkv_kernel(AttnArgs a) 
     // FULL (compile time): all 64 queries of the tile and all keys of this wave exist - the sub-tile tests and the validity
     // selects fold away and the tile is straight-line code (see attn_fwd_kernel)
     const bool keys_full = (bx_ * KW * KG + wave * KG + KG) * 16 <= a.Lk;
-    auto tile = [&](int it, auto full_) {
+    auto tile = [&](int it, auto full_, auto drop_tag) {
       constexpr bool FULL = decltype(full_)::value;
+      constexpr bool DROP = decltype(drop_tag)::value;          // LEAN only: probability dropout on, compile-time inside the tile
       const int si = sb + it / nqt, qt = it % nqt;
       const int nsub = FULL ? 4 : (idle ? 0 : min(4, (a.Lq - qt * KT + 15) >> 4));      // valid 16-query sub-tiles of this tile
       const int b = a.seq_ids ? a.seq_ids[si] : si;
@@ -1046,15 +1055,30 @@ __global__ __launch_bounds__(64 * KW, WPS) void attn_bwd_dkv_kernel(AttnArgs a) 
         for (int gk = 0; gk < KG; ++gk) {
           const float4 bb = btv[gk][t];
           const float bbv[4] = {bb.x, bb.y, bb.z, bb.w};
+          if constexpr (LEAN) {
+            // Branch-free: a key past Lk needs no masking here - column `key` of P / dS reaches only row `key` of dK / dV,
+            // which is not stored - and a query past Lq has LSE = +1e30 (P = dS = 0).  The min keeps whatever sits in the
+            // pad columns of the bias (undefined, possibly NaN: v_min returns the other operand) from reaching the exponent.
+            const uint32_t e0 = (uint32_t)(((long)b * a.H + h) * a.Lq + qq0) * (uint32_t)lkp + (uint32_t)key[gk];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const bool ok = FULL || (kok[gk] && (qq0 + r < a.Lq));
-            const float pv = ok ? fast_exp2(BL2 ? fmaf(s[gk][r], sc2, bbv[r]) - lsv[r] : s[gk][r] * sc2 + bbv[r] * LOG2E + mk[gk] - lsv[r]) : 0.f;
-            float dm = 1.f;
-            if (drop_.thr16)
-              dm = drop_mul(drop_, (uint32_t)(((long)b * a.H + h) * a.Lq + min(qq0 + r, a.Lq - 1)) * (uint32_t)lkp + (uint32_t)key[gk]);
-            p[gk][t][r] = pv * dm;
-            ds[gk][t][r] = pv * (dp[gk][r] * dm - dlv[r]);
+            for (int r = 0; r < 4; ++r) {
+              const float x = BL2 ? fmaf(s[gk][r], sc2, bbv[r]) : fmaf(s[gk][r], sc2, fmaf(bbv[r], LOG2E, mk[gk]));
+              const float pv = fast_exp2(fminf(x, 1e29f) - lsv[r]);
+              const float dm = DROP ? drop_mul(drop_, e0 + (uint32_t)r * (uint32_t)lkp) : 1.f;
+              p[gk][t][r] = DROP ? pv * dm : pv;
+              ds[gk][t][r] = pv * ((DROP ? dp[gk][r] * dm : dp[gk][r]) - dlv[r]);
+            }
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const bool ok = FULL || (kok[gk] && (qq0 + r < a.Lq));
+              const float pv = ok ? fast_exp2(BL2 ? fmaf(s[gk][r], sc2, bbv[r]) - lsv[r] : s[gk][r] * sc2 + bbv[r] * LOG2E + mk[gk] - lsv[r]) : 0.f;
+              float dm = 1.f;
+              if (drop_.thr16)
+                dm = drop_mul(drop_, (uint32_t)(((long)b * a.H + h) * a.Lq + min(qq0 + r, a.Lq - 1)) * (uint32_t)lkp + (uint32_t)key[gk]);
+              p[gk][t][r] = pv * dm;
+              ds[gk][t][r] = pv * (dp[gk][r] * dm - dlv[r]);
+            }
           }
         }
       }
@@ -1080,14 +1104,18 @@ __global__ __launch_bounds__(64 * KW, WPS) void attn_bwd_dkv_kernel(AttnArgs a) 
       }
     };
     (void)keys_full;
+    auto run = [&](int it) {                   // general (PartTile) form only: see attn_bwd_dq_kernel
+      if (!LEAN || drop_.thr16) tile(it, PartTile{}, std::true_type{});
+      else tile(it, PartTile{}, std::false_type{});
+    };
     if (RES) {
       for (int base = 0; base < nit; base += NS) {
         load_round(base);
         if (idle && nit <= NS) return;         // single round: no barrier follows, a wave without keys is done
-        for (int it = base; it < min(nit, base + NS); ++it) tile(it, PartTile{});
+        for (int it = base; it < min(nit, base + NS); ++it) run(it);
       }
     } else {
-      for (int it = 0; it < nit; ++it) tile(it, PartTile{});          // general form only: see attn_bwd_dq_kernel
+      for (int it = 0; it < nit; ++it) run(it);
     }
   }
 #pragma unroll

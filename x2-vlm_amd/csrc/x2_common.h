@@ -88,7 +88,6 @@ __device__ __forceinline__ void drop_mul4(const DropSpec& d, uint32_t e0, float 
   m[2] = (h1 & 0xffffu) >= d.thr16 ? d.scale : 0.f;
   m[3] = (h1 >> 16) >= d.thr16 ? d.scale : 0.f;
 }
-
 // ---- wave64 reductions ----
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
