@@ -388,7 +388,15 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNT p) {
   // The two workgroups of a CU are dispatched together and take equally long, so they stay in phase for the whole
   // kernel: both in the L2-bound main loop, then both in the HBM-write-bound epilogue.  Delaying the second-slot
   // workgroups of the FIRST round once (workgroups 256..511) de-phases every later round.
-  if (p.stagger && blockIdx.x >= 256 && blockIdx.x < 512)
+  // stagger & 256: "spread" form, unit 0.43 us: the first 512 workgroups start in eight phases - the two slots of a CU half
+  // a period apart, neighbouring CUs of an XCD a quarter - so that the chip's main loops (L2 reads) and epilogues (HBM
+  // writes) are spread over time from the first round on.
+  if (p.stagger & 256) {
+    if (blockIdx.x < 512) {
+      const int n = ((((int)blockIdx.x >> 3) & 3) * 2 + (((int)blockIdx.x >> 8) & 1) * 4) * (p.stagger & 255);
+      for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(16);
+    }
+  } else if (p.stagger && blockIdx.x >= 256 && blockIdx.x < 512)
     for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(127);
   // Software pipeline (one barrier per K-step, placed in the MIDDLE of the step):
   //   fragments of k-half 1 are requested before the MFMAs of k-half 0 are issued, and the fragments of the NEXT
@@ -682,7 +690,7 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmNT p) {
 // knobs for A/B measurements and for the tests that pin a kernel variant (0 = automatic everywhere); [7] 1: no 160x128 NT tiles
 //   [0] GROUP_M of the NT tile raster            [1] 0: automatic, 1: 128-column kernels only, 2: the 8-wave 256x128 kernel, 3: always the 256-column kernel
 //   [2] NT ablation bits (4 no epilogue, 16 sc1 stores, 64 row-contiguous fp32 stores)          [6] 1: always the generic (run-time flags) NT epilogue
-//   [3] NT tile: 1 = 128x128, 2 = 192x128, 3 = 64x128, 4 = 160x128; 5..8 = rows / 32 of the 256-column kernel        [4] NT start stagger (x 4 us)
+//   [3] NT tile: 1 = 128x128, 2 = 192x128, 3 = 64x128, 4 = 160x128; 5..8 = rows / 32 of the 256-column kernel        [4] NT start stagger (x 4 us; | 256: eight start phases, x 0.43 us)
 //   [5] TN: 1 = always 128x128 tiles, 2 = 256x256 tiles whenever the contraction lengths allow
 //   [8] attention kernel variant bits (attention.hip attn_variant(); -1 = back to the X2_ATTN_VARIANT environment value)
 //   [9] percent of perfect CU fill the 256-column NT kernel's plan must reach to be chosen when [1] = 4 (0 = 80)
