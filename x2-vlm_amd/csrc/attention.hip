@@ -969,28 +969,23 @@ __global__ __launch_bounds__(64 * KW, WPS) void attn_bwd_dkv_kernel(AttnArgs a) 
         reinterpret_cast<float*>(smem[buf] + 2 * KT * 128)[KT + tid] = rd;
       }
     };
-    // RES: rounds of NS (sequence, query tile) iterations, all tiles of a round requested before the first LDS write - one
-    // exposed load latency per round instead of one per tile.  The vision shapes (one sequence, <= 4 query tiles) are a single
-    // round; the cross-attention of the fusion layers (30-token text rows sharing an image: 3 + Poisson(1) rows of ONE tile
-    // each) used to stream tile by tile - ~5 us per iteration for 16 MFMAs, all of it load latency - and now takes 1-2 rounds.
-    auto load_round = [&](int base) {
+    if (RES) {
+      // (<= 4 query tiles) all requested before the first LDS write, as in the forward kernel
       TileRegs<NT> rqa[NS], rdoa[NS];
       float rla[NS], rda[NS];
 #pragma unroll
-      for (int i = 0; i < NS; ++i)
-        if (base + i < nit) { fetch(base + i); rqa[i] = rq; rdoa[i] = rdo; rla[i] = rl; rda[i] = rd; }
-      if (base > 0) __syncthreads();           // every wave is done with the previous round's slots (loads already in flight)
+      for (int it = 0; it < NS; ++it)
+        if (it < nit) { fetch(it); rqa[it] = rq; rdoa[it] = rdo; rla[it] = rl; rda[it] = rd; }
 #pragma unroll
-      for (int i = 0; i < NS; ++i)
-        if (base + i < nit) { rq = rqa[i]; rdo = rdoa[i]; rl = rla[i]; rd = rda[i]; commit(i); }
-      __syncthreads();
-    };
-    if (!RES) {
+      for (int it = 0; it < NS; ++it)
+        if (it < nit) { rq = rqa[it]; rdo = rdoa[it]; rl = rla[it]; rd = rda[it]; commit(it); }
+    } else {
       fetch(0);
       commit(0);
-      __syncthreads();
     }
+    __syncthreads();
     const bool idle = (bx_ * KW * KG + wave * KG) * 16 >= a.Lk;      // all keys of this wave are padding
+    if (RES && idle) return;
     // FULL (compile time): all 64 queries of the tile and all keys of this wave exist - the sub-tile tests and the validity
     // selects fold away and the tile is straight-line code (see attn_fwd_kernel)
     const bool keys_full = (bx_ * KW * KG + wave * KG + KG) * 16 <= a.Lk;
@@ -1000,7 +995,7 @@ __global__ __launch_bounds__(64 * KW, WPS) void attn_bwd_dkv_kernel(AttnArgs a) 
       const int si = sb + it / nqt, qt = it % nqt;
       const int nsub = FULL ? 4 : (idle ? 0 : min(4, (a.Lq - qt * KT + 15) >> 4));      // valid 16-query sub-tiles of this tile
       const int b = a.seq_ids ? a.seq_ids[si] : si;
-      char* buf = smem[RES ? it % NS : (it & 1)];
+      char* buf = smem[RES ? it : (it & 1)];
       const uint32_t qtile = lds_addr(buf), dotile = qtile + KT * 128;
       const float* lse_s = reinterpret_cast<const float*>(buf + 2 * KT * 128);
       const float* del_s = lse_s + KT;
@@ -1104,18 +1099,9 @@ __global__ __launch_bounds__(64 * KW, WPS) void attn_bwd_dkv_kernel(AttnArgs a) 
       }
     };
     (void)keys_full;
-    auto run = [&](int it) {                   // general (PartTile) form only: see attn_bwd_dq_kernel
+    for (int it = 0; it < nit; ++it) {         // general (PartTile) form only: see attn_bwd_dq_kernel
       if (!LEAN || drop_.thr16) tile(it, PartTile{}, std::true_type{});
       else tile(it, PartTile{}, std::false_type{});
-    };
-    if (RES) {
-      for (int base = 0; base < nit; base += NS) {
-        load_round(base);
-        if (idle && nit <= NS) return;         // single round: no barrier follows, a wave without keys is done
-        for (int it = base; it < min(nit, base + NS); ++it) run(it);
-      }
-    } else {
-      for (int it = 0; it < nit; ++it) run(it);
     }
   }
 #pragma unroll
@@ -1142,8 +1128,7 @@ __global__ __launch_bounds__(64 * KW, WPS) void attn_bwd_dkv_kernel(AttnArgs a) 
 // step (64 KB workgroups co-reside worse with the other streams' kernels), so off by default;
 // bit 12 (4096) / bit 13 (8192): strip-walking resident forward / dQ kernels (the default; see their header);
 // bit 14 (16384): bias kernels on the plain 3-D grid instead of the XCD-aware 1-D order (attn_block);
-// bit 15 (32768): the 8-wave streaming / resident-dK/dV kernels compiled for 2 waves per SIMD (256 VGPRs) instead of 4 (128);
-// bit 16 (65536): cross-attention dK/dV in rounds of 4 resident query tiles instead of the 2-slot streaming kernel
+// bit 15 (32768): the 8-wave streaming / resident-dK/dV kernels compiled for 2 waves per SIMD (256 VGPRs) instead of 4 (128)
 // x2_tune(8, v) (gemm.hip) overrides the environment at run time: tests and probes A/B variants inside one process
 int x2_attn_variant_override = -1;
 static int attn_variant() {
@@ -1262,11 +1247,6 @@ extern "C" int x2_attn_bwd(const AttnArgs* pa, void* stream) {
     if (attn_variant() & 32768) attn_launch(attn_bwd_dkv_kernel<8, 1, false, 2, 2>, a, (a.Lk + 127) / 128, a.H, a.Bkv, 512, xmT, st);
     else if (bl2) attn_launch(attn_bwd_dkv_kernel<8, 1, false, 2, 4, true>, a, (a.Lk + 127) / 128, a.H, a.Bkv, 512, xmT, st);
     else attn_launch(attn_bwd_dkv_kernel<8, 1, false>, a, (a.Lk + 127) / 128, a.H, a.Bkv, 512, xmT, st);
-  } else if (a.seq_off && a.Lq <= 64 && (attn_variant() & 65536)) {
-    // text rows sharing an image's K / V (one query tile each): rounds of 4 resident tiles instead of a 2-slot stream.
-    // Not the default: in the step it measured 25.05 ms against 24.93 (r03t, two runs each) - the 2-slot stream at 3 waves
-    // per SIMD already hides the tile loads behind the other workgroups of the CU, and 67 KB of LDS per block halves those.
-    hipLaunchKernelGGL((attn_bwd_dkv_kernel<4, 1, true>), dim3((a.Lk + 63) / 64, a.H, a.Bkv), dim3(256), 0, st, a);
   } else {
     hipLaunchKernelGGL((attn_bwd_dkv_kernel<4, 1, false>), dim3((a.Lk + 63) / 64, a.H, a.Bkv), dim3(256), 0, st, a);
   }
