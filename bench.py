@@ -43,6 +43,13 @@ CONFIGS = {
                    metric="region-text pairs/sec (fwd+bwd) X2VLM-base 224px, 128 region texts over 26 images/GPU",
                    workload="X2VLM-base region iteration (run_region_iter: 26 images, 128 region texts, masked mean pooling, "
                             "predict_bbox pass) fwd+bwd, ITC+ITM+MLM+bbox(L1+GIoU), 224px"),
+    # Pretrain.run_mixed_iter (Pretrain.py:189-252), the iteration the default pre-training yaml actually runs: one image batch
+    # AND one region batch per optimizer step, their gradients accumulated, one averaging.  Replayed as graph.MixedStep.
+    "mixed": dict(size="base", res=224, batch=64, region_batch=128, images=26, frames=0, f_min=None, unit="pairs/s",
+                  metric="(image-text + region-text) pairs/sec (fwd+bwd) X2VLM-base 224px mixed iteration: 64 image pairs + 128 region "
+                         "texts over 26 images per GPU",
+                  workload="X2VLM-base mixed iteration (run_mixed_iter: image batch 64 + region batch 26 images / 128 texts, gradients "
+                           "accumulated, one reduction) fwd+bwd, ITC+ITM+MLM (+bbox L1+GIoU on the region part), 224px"),
     "video": dict(size="base", res=224, batch=8, frames=8, f_min=921.1, unit="clips/s",
                   metric="video-text clips/sec (fwd+bwd) X2VLM-base 8x8-frame 224px clips/GPU",
                   workload="X2VLM-base video path (avgpool over 8 frames + frame position embedding) pre-training step "
@@ -89,6 +96,7 @@ def cpu_baseline(conf, seconds=20.0):
     else:
         cfg = O.OracleConfig(image_res=conf["res"], frames=conf["frames"])
     sd = O.make_params(cfg, 0, synthetic.synth_tensor)
+    mixed = "region_batch" in conf
     B = 4 if conf is CONFIGS["base"] else 8 if "images" in conf else 2
     kw = {}
     if "images" in conf:        # 8 region texts over 2 images: the same ~4.9 texts per image as the benchmark batch
@@ -97,13 +105,18 @@ def cpu_baseline(conf, seconds=20.0):
     else:
         b = synthetic_batch(0, B, 30, conf["res"], frames=conf["frames"])
     neg = synthetic.synth_negatives(0, B)
+    bi, negi = (synthetic_batch(0, 4, 30, conf["res"]), synthetic.synth_negatives(0, 4)) if mixed else (None, None)
     n, t0, first = 0, time.time(), None
     while True:
         for t in sd.values():
             t.grad = None
         ts = time.time()
         losses, _ = O.xvlm_forward(sd, cfg, b, neg, **kw)
-        sum(losses.values()).backward()
+        total = sum(losses.values())
+        if mixed:               # + the image part of the mixed iteration (4 pairs), gradients accumulated by one backward
+            li, _ = O.xvlm_forward(sd, cfg, bi, negi)
+            total = total + sum(li.values())
+        total.backward()
         if first is None:
             first = time.time() - ts          # warm-up iteration, not counted
             t0 = time.time()
@@ -112,9 +125,11 @@ def cpu_baseline(conf, seconds=20.0):
         if time.time() - t0 > seconds or n >= 8:
             break
     dt = time.time() - t0
-    return {"value": round(B * n / dt, 3), "unit": conf["unit"], "cores": threads, "kind": "port",
-            "sample": "oracle fp32, %s, B=%d, %d timed steps after 1 warm-up (%.1fs), %d torch threads"
-                      % (conf["workload"].split(" pre-training")[0], B, n, dt, threads)}
+    units = B + (4 if mixed else 0)
+    return {"value": round(units * n / dt, 3), "unit": conf["unit"], "cores": threads, "kind": "port",
+            "sample": "oracle fp32, %s, %s, %d timed steps after 1 warm-up (%.1fs), %d torch threads"
+                      % (conf["workload"].split(" pre-training")[0], "4 image pairs + 8 region texts over 2 images" if mixed else "B=%d" % B,
+                         n, dt, threads)}
 
 
 def other_configs(args):
@@ -123,7 +138,7 @@ def other_configs(args):
     pools and graphs) - same timing contract, own cpu_baseline."""
     import subprocess
     res = {}
-    for name, steps in (("large", 10), ("video", 15), ("region", 15)):
+    for name, steps in (("large", 10), ("video", 15), ("region", 15), ("mixed", 10)):
         cmd = [sys.executable, os.path.abspath(__file__), "--config", name, "--steps", str(steps), "--warmup", "3", "--graph", args.graph]
         if args.no_cpu_baseline:
             cmd.append("--no-cpu-baseline")
@@ -205,7 +220,8 @@ def main():
         model.overlap_towers = False
         importlib.import_module("x2-vlm_amd.engine").SIDE.enabled = False
     ddp = acc.GradientBuckets(model, world) if world > 1 else None
-    region = "images" in conf
+    mixed = "region_batch" in conf
+    region = "images" in conf and not mixed
     if region:
         synth = importlib.import_module("x2-vlm_amd.synthetic")
         batch = {k: v.to(dev) for k, v in synth.synth_region_batch(1234 + rank, conf["images"], args.batch, args.seq_len, conf["res"], 16,
@@ -214,6 +230,12 @@ def main():
         batch = {k: v.to(dev) for k, v in synthetic_batch(rank, args.batch, args.seq_len, conf["res"], frames=conf["frames"]).items()}
     region_kw = dict(image_atts=batch["image_atts"], idx_to_group_img=batch["idx_to_group_img"], target_bbox=batch["target_bbox"],
                      is_image=batch["is_image"], ret_bbox_loss=True) if region else {}
+    rbatch, units = None, args.batch                      # units of the metric one rank processes per step
+    if mixed:
+        synth = importlib.import_module("x2-vlm_amd.synthetic")
+        rbatch = {k: v.to(dev) for k, v in synth.synth_region_batch(4321 + rank, conf["images"], conf["region_batch"], args.seq_len, conf["res"],
+                                                                    16, 30522, 12).items()}
+        units = args.batch + conf["region_batch"]
 
     eng = importlib.import_module("x2-vlm_amd.engine")
 
@@ -233,6 +255,13 @@ def main():
         loss = model(batch["image"], batch["text_ids"], batch["text_atts"], text_ids_masked=batch["text_ids_masked"],
                      masked_pos=batch["masked_pos"], masked_ids=batch["masked_ids"], **region_kw)
         total = sum(loss.values())              # Pretrain.py:67-68 / 98-100: the plain sum of the returned losses
+        if mixed:                               # Pretrain.py:206-251: the region forward's losses join the same backward_step
+            rl = model(rbatch["image"], rbatch["text_ids"], rbatch["text_atts"], text_ids_masked=rbatch["text_ids_masked"],
+                       masked_pos=rbatch["masked_pos"], masked_ids=rbatch["masked_ids"], image_atts=rbatch["image_atts"],
+                       idx_to_group_img=rbatch["idx_to_group_img"], target_bbox=rbatch["target_bbox"], is_image=rbatch["is_image"],
+                       ret_bbox_loss=True)
+            total = total + sum(rl.values())
+            loss = dict(loss, **{"region_" + k: v for k, v in rl.items()})
         total.backward()
         if ddp is not None:
             ddp.finish()
@@ -315,8 +344,12 @@ def main():
         if ddp is not None:
             ddp.close()
             ddp = None
-        runner = graph.SegmentedStep(model, batch, world=world, rank=rank, warmup=1, enabled=use_graph, verbose=(rank == 0),
-                                     ret_bbox_loss=region)
+        if mixed:
+            runner = graph.MixedStep(model, [dict(batch=batch), dict(batch=rbatch, ret_bbox_loss=True)], world=world, rank=rank, warmup=1,
+                                     enabled=use_graph, verbose=(rank == 0))
+        else:
+            runner = graph.SegmentedStep(model, batch, world=world, rank=rank, warmup=1, enabled=use_graph, verbose=(rank == 0),
+                                         ret_bbox_loss=region)
     else:
         # N = 1: the whole step as ONE multi-stream hipGraph (fork / join edges: ~15 us of host time per node).
         # N > 1 on this path: eager launches with bucketed all-reduces overlapped on a side stream (accelerator.GradientBuckets).
@@ -325,6 +358,8 @@ def main():
 
     def step():
         loss = runner()
+        if isinstance(loss, list):              # MixedStep: one loss dict per part
+            loss = dict(loss[0], **{"region_" + k: v for k, v in loss[1].items()})
         optimizer_part()
         return loss
 
@@ -346,7 +381,7 @@ def main():
         dt = float(t)
     if rank == 0 and getattr(runner, "times", None):
         print("segment times (ms): " + json.dumps({k: round(v, 3) for k, v in runner.segment_times().items()}), file=sys.stderr, flush=True)
-    pairs_s = world * args.batch * args.steps / dt
+    pairs_s = world * units * args.steps / dt
     per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
 
     roof = None
@@ -355,7 +390,7 @@ def main():
         # executed GEMM FLOPs of one step (NT + TN launches of the instrumented eager steps; the MLM head's recomputed decoder
         # GEMM is not counted), per unit of the metric
         gf = sum(fl for name, (ms, fl, n) in stat_iso.items() if name in ("gemm_nt", "gemm_tn")) / 2 if rank == 0 else 0.0
-        f_min = gf / 1e9 / args.batch
+        f_min = gf / 1e9 / units
         f_note = "measured: 2MNK of the GEMM launches of one step / units per step (attention and row kernels not counted)"
     if rank == 0:
         def summary(stat, name):
@@ -391,7 +426,8 @@ def main():
                "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
                "config": {"workload": conf["workload"] + ", %d-token captions, 12 masks" % args.seq_len, "name": args.config,
-                          "per_gpu_batch": args.batch, "global_batch": args.batch * world,
+                          "per_gpu_batch": args.batch if not mixed else "%d image pairs + %d region texts" % (args.batch, conf["region_batch"]),
+                          "global_batch": units * world,
                           "parallelism": "dp%d" % world, "streams": "single (--serialize)" if args.serialize else "concurrent",
                           "optimizer_in_step": bool(args.with_optimizer), "mode": "eval (dropout/DropPath off)" if args.eval_mode else
                           "train (BERT dropout 0.1, attention dropout 0.1, DropPath 0..0.1)",

@@ -39,6 +39,11 @@ CASES = {
     "large_full": dict(image_res=384, vision_layers=24, vision_width=1024, hidden=1024, heads=16, ffn=4096, vocab=30522,
                        max_pos=512, text_layers=18, fusion_at=12, embed_dim=256, batch=2, seq_len=30,
                        max_masks=12, ragged=True, region=False, frames=0, wseed=71, bseed=72),
+    # BASELINE.json configs[3] at ITS OWN per-GPU batch 32: the losses of X2VLM-large are held to north_star's 1e-3 here
+    # (the B = 2 case above averages the same per-sample bf16 noise over 16x fewer samples); one-off ~1 h CPU run of the reference
+    "large_full_b32": dict(image_res=384, vision_layers=24, vision_width=1024, hidden=1024, heads=16, ffn=4096, vocab=30522,
+                           max_pos=512, text_layers=18, fusion_at=12, embed_dim=256, batch=32, seq_len=30,
+                           max_masks=12, ragged=True, region=False, frames=0, wseed=73, bseed=74, checkpoint_blocks=True),
     # the region / bbox iteration (Pretrain.run_region_iter, Pretrain.py:79-111) at the REAL geometry: full X2VLM-base, 224 px,
     # 8 region texts over 4 images, image_atts with masked-out patches (masked mean pooling over 197 tokens, beit2.py:426-436),
     # the 5th fusion pass of predict_bbox at base width, L1 + GIoU (xvlm.py:688-698, 910-957)

@@ -37,6 +37,13 @@ def run_case(name):
     model = XVLM(config=cfg, load_vision_params=False, load_text_params=False, pretraining=True)
     synthetic.synth_state_dict(model, c["wseed"])
     model.eval()
+    if c.get("checkpoint_blocks"):
+        # memory only (the B = 32 X2VLM-large case keeps ~70 GB of fp32 activations otherwise): every vision block of the
+        # reference runs under torch.utils.checkpoint - the same modules, the same arithmetic (eval mode: deterministic),
+        # their internals recomputed in the backward instead of stored
+        from torch.utils.checkpoint import checkpoint
+        for blk in model.vision_encoder.blocks:
+            blk.forward = (lambda *a, _f=blk.forward, **k: checkpoint(_f, *a, use_reentrant=False, **k))
 
     if c["region"]:
         batch = synthetic.synth_region_batch(c["bseed"], c["n_images"], c["batch"], c["seq_len"],

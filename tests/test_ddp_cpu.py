@@ -208,3 +208,50 @@ def test_itc_loss_gradient_is_local_slice_of_global():
         assert abs(o[4] - float(loss)) < 1e-6
         assert torch.allclose(o[2], FI.grad[4 * r: 4 * r + 4], atol=1e-6)
         assert torch.allclose(o[3], FT.grad[4 * r: 4 * r + 4], atol=1e-6)
+
+
+def test_file_rendezvous_ignores_leftovers_of_a_crashed_launch(tmp_path):
+    """comm.X2Comm._from_file (the path form of from_store): a launch that crashed before rank 0's clean-up leaves the id file
+    (and announcements) of the SAME name behind; the next launch must not pick them up - every rank ends with the id rank 0
+    published in THIS launch, files are gone afterwards, and a rank 0 that never shows up is a time-out error, not a hang."""
+    import threading
+    import time
+    comm = importlib.import_module("x2-vlm_amd.comm")
+    lib_mod = importlib.import_module("x2-vlm_amd._lib")
+
+    class Fake(comm.X2Comm):
+        made = []
+
+        def __init__(self, ident, rank, world):          # no device: only the rendezvous is under test
+            self.ident, self.rank, self.world, self.h = ident, rank, world, None
+
+        @staticmethod
+        def unique_id():
+            b = os.urandom(128)
+            Fake.made.append(b)
+            return b
+
+    path = str(tmp_path / "x2id.29500.x2_comm_id.1")
+    stale = b"\x01" * 128
+    with open(path, "wb") as f:
+        f.write(stale)
+    open(path + ".hello1", "w").close()
+    open(path + ".ack2", "w").close()
+    world, got, errs = 3, {}, []
+
+    def run(rank, delay):
+        try:
+            time.sleep(delay)
+            got[rank] = Fake._from_file(path, rank, world, timeout=20.0).ident
+        except Exception as e:      # noqa: BLE001
+            errs.append((rank, e))
+    th = [threading.Thread(target=run, args=(r, d)) for r, d in ((1, 0.0), (0, 0.3), (2, 0.6))]     # a reader polls before rank 0 starts
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(40)
+    assert not errs, errs
+    assert len(Fake.made) == 1 and all(got[r] == Fake.made[0] for r in range(world)) and got[0] != stale
+    assert not [f for f in os.listdir(tmp_path) if f.startswith("x2id")], os.listdir(tmp_path)
+    with pytest.raises(lib_mod.X2HipError):
+        Fake._from_file(str(tmp_path / "never"), 1, 2, timeout=0.3)

@@ -215,6 +215,230 @@ def test_two_ranks_replayed_segments_match_oracle_ddp_semantics(case, synthetic)
         assert torch.allclose(out[0]["g2"][n], out[1]["g2"][n], rtol=1e-5, atol=1e-7), n
 
 
+@pytest.mark.parametrize("world", [4, 8])
+def test_many_ranks_replayed_segments_match_oracle_ddp_semantics(world, synthetic):
+    """BASELINE.json configs[2] is 8 ranks: the replayed step at 4 and 8 ranks sharing this GPU over gloo (RCCL refuses two ranks
+    on one device).  Every rank derives its reduction plan from its own capture - SegmentedStep compares the plans' digests at
+    set-up and raises on a mismatch instead of hanging; here: mode, message count equal on all ranks, losses and averaged
+    gradients equal to the oracle's W-rank semantics (global ITC loss over W * B gathered pairs, local rows attached)."""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_two_rank_segmented_worker, args=(world, _free_port(), "tiny", ret), nprocs=world, join=True)
+    out = [ret[r] for r in range(world)]
+    c = CASES["tiny"]
+    g_a, loss_a = _oracle_ddp(synthetic, c, world, 0)
+    g_b, _ = _oracle_ddp(synthetic, c, world, 1000)
+    assert len(set(o["messages"] for o in out)) == 1
+    for r in range(world):
+        assert out[r]["mode"] == "hipgraph-segments", out[r]["error"]
+        for k, v in loss_a[r].items():
+            assert abs(out[r]["loss1"][k] - v) <= 5e-3 * max(abs(v), 1e-6), (r, k, out[r]["loss1"][k], v)
+        _compare(out[r]["g1"], g_a, "rank %d of %d, first replay" % (r, world))
+        _compare(out[r]["g2"], g_b, "rank %d of %d, second replay (new data)" % (r, world))
+    for r in range(1, world):
+        for n in out[0]["g2"]:
+            assert torch.allclose(out[0]["g2"][n], out[r]["g2"][n], rtol=1e-5, atol=1e-7), (r, n)
+
+
+def _plan_mismatch_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), X2_DIST_BACKEND="gloo")
+    synthetic = importlib.import_module("x2-vlm_amd.synthetic")
+    mp_ = importlib.import_module("x2-vlm_amd.model_pretrain")
+    acc = importlib.import_module("x2-vlm_amd.accelerator")
+    graph = importlib.import_module("x2-vlm_amd.graph")
+    c = CASES["tiny"]
+    model = mp_.XVLM(config=model_config("tiny", tempfile.mkdtemp()), load_vision_params=False, load_text_params=False, pretraining=True)
+    synthetic.synth_state_dict(model, c["wseed"])
+    model.eval()
+    a = acc.RocmDDPAccelerator(dict(RNG_SEED=7), None)
+    ddp, _, _ = a.set_up(model, None, None, local_rank=0, world_size=world, rank=rank)
+    try:
+        b1, n1 = _rank_batch(synthetic, c, rank)
+        static = {k: v.cuda() for k, v in b1.items()}
+        model.injected_negatives = tuple(torch.tensor(n, dtype=torch.int32, device="cuda") for n in n1)
+        if rank == 1:       # this rank's plan gets one more message than the others'
+            orig = graph.SegmentedStep._plan_digest
+            graph.SegmentedStep._plan_digest = lambda self: (orig(self)[0] ^ 1, orig(self)[1] + 1)
+        try:
+            a.segmented_step(ddp, static, clamp_temp=False)
+            ret[rank] = "no error"
+        except RuntimeError as e:
+            ret[rank] = str(e)
+    finally:
+        a.buckets.close()
+        dist.destroy_process_group()
+
+
+def test_ranks_with_different_reduction_plans_raise_instead_of_hanging():
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_plan_mismatch_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
+    for r in range(2):
+        assert "different gradient-reduction plans" in ret[r], ret[r]
+
+
+def _rccl_segmented_worker(rank, world, port, ret, comm_mode):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), X2_DDP_SINGLE_RANK_COLLECTIVES="1", X2_COMM=comm_mode)
+    os.environ.pop("X2_DIST_BACKEND", None)
+    synthetic = importlib.import_module("x2-vlm_amd.synthetic")
+    mp_ = importlib.import_module("x2-vlm_amd.model_pretrain")
+    acc = importlib.import_module("x2-vlm_amd.accelerator")
+    c = CASES["tiny"]
+    model = mp_.XVLM(config=model_config("tiny", tempfile.mkdtemp()), load_vision_params=False, load_text_params=False, pretraining=True)
+    synthetic.synth_state_dict(model, c["wseed"])
+    model.eval()
+    a = acc.RocmDDPAccelerator(dict(RNG_SEED=7), None)
+    ddp, _, _ = a.set_up(model, None, None, local_rank=0, world_size=1, rank=0)
+    try:
+        assert dist.get_backend() == "nccl" and (a.buckets.comm is not None) == (comm_mode == "rccl")
+        b, n = _rank_batch(synthetic, c, 0)
+        static = {k: v.cuda() for k, v in b.items()}
+        model.injected_negatives = tuple(torch.tensor(x, dtype=torch.int32, device="cuda") for x in n)
+        step = a.segmented_step(ddp, static, clamp_temp=False)
+        loss = step()
+        torch.cuda.synchronize()
+        grads = {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
+        msgs = step.messages
+        # the same step with no collective anywhere
+        a.buckets.close()
+        os.environ["X2_DDP_SINGLE_RANK_COLLECTIVES"] = "0"
+        for p in model.parameters():
+            p.grad = None
+        model.injected_negatives = n
+        _, total = _step(model, static, n)
+        total.backward()
+        torch.cuda.synchronize()
+        worst = max(float((grads[k] - p.grad).abs().max()) / (float(p.grad.abs().max()) + 1e-12)
+                    for k, p in model.named_parameters() if p.grad is not None)
+        ret[0] = dict(mode=step.mode, error=step.error, msgs=msgs, worst=worst, losses={k: float(v) for k, v in loss.items()})
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("comm_mode", ["torch", "rccl"])
+def test_single_rank_rccl_through_replayed_segments(comm_mode):
+    """Both collective back-ends (torch.distributed "nccl" = RCCL, and the C-ABI communicator x2_comm_*) driven by the REPLAYED
+    step: ITC all-gathers between segments, per-segment AVG all-reduces on the collective stream, the plan-digest exchange at
+    set-up.  One rank (the box has one GPU): averaging is the identity, so the gradients must equal the plain eager step's up
+    to the run-to-run noise of the atomics."""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_rccl_segmented_worker, args=(1, _free_port(), ret, comm_mode), nprocs=1, join=True)
+    r = ret[0]
+    assert r["mode"] == "hipgraph-segments", r["error"]
+    assert r["msgs"] >= 2 + 3
+    assert all(np.isfinite(v) for v in r["losses"].values())
+    assert r["worst"] <= 2e-2, r["worst"]
+
+
+def _mixed_rank_data(synthetic, c, rank, shift=0):
+    si = c["bseed"] + 100 * rank + shift
+    sr = si + 7
+    bi = synthetic.synth_batch(si, 4, c["seq_len"], c["image_res"], c["vocab"], c["max_masks"], ragged=True)
+    br = synthetic.synth_region_batch(sr, c["n_images"], c["batch"], c["seq_len"], c["image_res"], 16, c["vocab"], c["max_masks"])
+    return (bi, synthetic.synth_negatives(si, 4)), (br, synthetic.synth_negatives(sr, c["batch"]))
+
+
+def _two_rank_mixed_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), X2_DIST_BACKEND="gloo")
+    synthetic = importlib.import_module("x2-vlm_amd.synthetic")
+    mp_ = importlib.import_module("x2-vlm_amd.model_pretrain")
+    acc = importlib.import_module("x2-vlm_amd.accelerator")
+    c = CASES["tiny_region"]
+    model = mp_.XVLM(config=model_config("tiny_region", tempfile.mkdtemp()), load_vision_params=False, load_text_params=False, pretraining=True)
+    synthetic.synth_state_dict(model, c["wseed"])
+    model.eval()
+    a = acc.RocmDDPAccelerator(dict(RNG_SEED=7), None)
+    ddp, _, _ = a.set_up(model, None, None, local_rank=0, world_size=world, rank=rank)
+    try:
+        out = {}
+        (bi, ni), (br, nr) = _mixed_rank_data(synthetic, c, rank)
+        si, sr = {k: v.cuda() for k, v in bi.items()}, {k: v.cuda() for k, v in br.items()}
+        negi = tuple(torch.tensor(n, dtype=torch.int32, device="cuda") for n in ni)
+        negr = tuple(torch.tensor(n, dtype=torch.int32, device="cuda") for n in nr)
+        step = a.mixed_step(ddp, [dict(batch=si, negatives=negi), dict(batch=sr, negatives=negr, weight=0.5, ret_bbox_loss=True)],
+                            clamp_temp=False)
+        out["mode"], out["error"] = step.mode, step.error
+        for it in range(2):
+            if it:
+                (bi, ni), (br, nr) = _mixed_rank_data(synthetic, c, rank, shift=1000)
+                step.copy_inputs(0, {k: v.cuda() for k, v in bi.items()})
+                step.copy_inputs(1, {k: v.cuda() for k, v in br.items()})
+                for t, n in zip(negi + negr, list(ni) + list(nr)):
+                    t.copy_(torch.tensor(n, dtype=torch.int32))
+                for p in model.parameters():
+                    p.grad = None
+            li, lr = step()
+            torch.cuda.synchronize()
+            out["loss%d" % it] = ({k: float(v) for k, v in li.items()}, {k: float(v) for k, v in lr.items()})
+            out["g%d" % it] = {n: p.grad.detach().cpu() for n, p in model.named_parameters() if p.grad is not None}
+            out["messages%d" % it] = step.messages
+        ret[rank] = out
+    finally:
+        a.buckets.close()
+        dist.destroy_process_group()
+
+
+def _oracle_ddp_mixed(synthetic, c, world, shift):
+    """Averaged accumulated gradients of `world` ranks: image part + 0.5 x region part, each under the reference's DDP semantics
+    (global ITC loss over the gathered features, local rows attached)."""
+    from oracle import x2vlm_oracle as O
+    cfg = O.config_from_case(c)
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    sd = O.make_params(cfg, c["wseed"], synthetic.synth_tensor)
+    data = [_mixed_rank_data(synthetic, c, r, shift) for r in range(world)]
+    avg, losses = {}, []
+    for part, (w, kw) in enumerate(((1.0, {}), (0.5, dict(ret_bbox_loss=True)))):
+        feats = []
+        with torch.no_grad():
+            for d in data:
+                _, ex = O.xvlm_forward(sd, cfg, d[part][0], d[part][1], **kw)
+                feats.append((ex["image_feat"].detach(), ex["text_feat"].detach()))
+        for r, d in enumerate(data):
+            for t in sd.values():
+                t.grad = None
+            calls = []
+
+            def gather(t, r=r, calls=calls, feats=feats):
+                which = len(calls)
+                calls.append(1)
+                return torch.cat([t if q == r else feats[q][which] for q in range(world)])
+            loss, _ = O.xvlm_forward(sd, cfg, d[part][0], d[part][1], gather=gather, **kw)
+            (w * sum(loss.values())).backward()
+            losses.append((part, r, {k: float(v) for k, v in loss.items()}))
+            for k, t in sd.items():
+                if t.grad is not None:
+                    avg[k] = avg.get(k, 0) + t.grad.detach().clone() / world
+    return avg, losses
+
+
+def test_two_ranks_replayed_mixed_iteration_matches_oracle(synthetic):
+    """Pretrain.run_mixed_iter at two ranks as replayed segments (RocmDDPAccelerator.mixed_step -> graph.MixedStep): image part +
+    region part (iter_perc 0.5), gradients accumulated in static buffers, ONE averaging per arena after the second part; two
+    successive iterations through the same graphs against the oracle's accumulated two-rank gradients."""
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_two_rank_mixed_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    out = [ret[r] for r in range(world)]
+    c = CASES["tiny_region"]
+    for it, shift in enumerate((0, 1000)):
+        want, losses = _oracle_ddp_mixed(synthetic, c, world, shift)
+        for part, r, ref in losses:
+            for k, v in ref.items():
+                got = out[r]["loss%d" % it][part][k]
+                assert abs(got - v) <= 5e-3 * max(abs(v), 1.0), (it, part, r, k, got, v)
+        for r in range(world):
+            assert out[r]["mode"] == "hipgraph-segments", out[r]["error"]
+            _compare(out[r]["g%d" % it], want, "rank %d, mixed iteration %d" % (r, it))
+            assert "bbox_head.0.weight" in out[r]["g%d" % it]
+        assert out[0]["messages%d" % it] == out[1]["messages%d" % it]
+        # 2 + 2 feature gathers; the gradient messages of ONE reduction plan (not one per part)
+        assert 4 + 3 <= out[0]["messages%d" % it] <= 4 + 30, out[0]["messages%d" % it]
+        for n in out[0]["g%d" % it]:
+            assert torch.allclose(out[0]["g%d" % it][n], out[1]["g%d" % it][n], rtol=1e-5, atol=1e-7), n
+
+
 def _rccl_worker(rank, world, port, ret, comm_mode):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), X2_DDP_SINGLE_RANK_COLLECTIVES="1", X2_COMM=comm_mode)
     os.environ.pop("X2_DIST_BACKEND", None)

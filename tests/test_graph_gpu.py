@@ -163,3 +163,68 @@ def test_segmented_replays_draw_new_dropout_masks(synthetic):
         seen.append(tuple(round(float(v), 6) for v in loss.values()))
     assert all(all(x == x and abs(x) < 1e4 for x in s) for s in seen)   # finite
     assert len(set(seen)) == 4, seen                                    # same inputs, four different masks
+
+
+def _mixed_parts(synthetic, model, c, shift=0):
+    """An image part and a region part (weight 0.5) for the tiny_region geometry, with their injected negatives (device tensors)."""
+    bi = synthetic.synth_batch(c["bseed"] + shift, 4, c["seq_len"], c["image_res"], c["vocab"], c["max_masks"], ragged=True)
+    br = synthetic.synth_region_batch(c["bseed"] + 7 + shift, c["n_images"], c["batch"], c["seq_len"], c["image_res"], 16, c["vocab"], c["max_masks"])
+    ni, nr = synthetic.synth_negatives(c["bseed"] + shift, 4), synthetic.synth_negatives(c["bseed"] + 7 + shift, c["batch"])
+    return (bi, ni), (br, nr)
+
+
+def test_mixed_iteration_replayed_accumulates_like_the_oracle(synthetic):
+    """graph.MixedStep = Pretrain.run_mixed_iter (Pretrain.py:189-252): an image sub-iteration and a region sub-iteration
+    (iter_perc 0.5) of ONE optimizer step, each a chain of replayed hipGraph segments, the second's gradients ADDED to the first's
+    static buffers.  Against the CPU oracle's accumulated gradients, for two successive iterations through the same graphs (a
+    replay that overwrote instead of accumulating, or accumulated across iterations, fails the second one)."""
+    import tempfile
+    from oracle import x2vlm_oracle as O
+    graph = importlib.import_module("x2-vlm_amd.graph")
+    mp = importlib.import_module("x2-vlm_amd.model_pretrain")
+    c = CASES["tiny_region"]
+    model = mp.XVLM(config=model_config("tiny_region", tempfile.mkdtemp()), load_vision_params=False, load_text_params=False, pretraining=True)
+    synthetic.synth_state_dict(model, c["wseed"])
+    model = model.to(dev).eval()
+    (bi, ni), (br, nr) = _mixed_parts(synthetic, model, c)
+    si, sr = {k: v.to(dev) for k, v in bi.items()}, {k: v.to(dev) for k, v in br.items()}
+    negi = tuple(torch.tensor(n, dtype=torch.int32, device=dev) for n in ni)
+    negr = tuple(torch.tensor(n, dtype=torch.int32, device=dev) for n in nr)
+    step = graph.MixedStep(model, [dict(batch=si, negatives=negi), dict(batch=sr, negatives=negr, weight=0.5, ret_bbox_loss=True)],
+                           clamp_temp=False)
+    assert step.mode == "hipgraph-segments", step.error
+    cfg = O.config_from_case(c)
+    torch.set_num_threads(8)
+    for it in range(2):
+        if it:
+            (bi, ni), (br, nr) = _mixed_parts(synthetic, model, c, shift=100)
+            step.copy_inputs(0, {k: v.to(dev) for k, v in bi.items()})
+            step.copy_inputs(1, {k: v.to(dev) for k, v in br.items()})
+            for t, n in zip(negi + negr, list(ni) + list(nr)):
+                t.copy_(torch.tensor(n, dtype=torch.int32))
+            for p in model.parameters():
+                p.grad = None                                # optimizer.zero_grad(set_to_none=True) between iterations
+        li, lr = step()
+        torch.cuda.synchronize()
+        sd = O.make_params(cfg, c["wseed"], synthetic.synth_tensor)
+        ri, _ = O.xvlm_forward(sd, cfg, bi, ni)
+        sum(ri.values()).backward()
+        rr, _ = O.xvlm_forward(sd, cfg, br, nr, ret_bbox_loss=True)
+        (0.5 * sum(rr.values())).backward()                  # accumulates into the same .grad
+        for got, ref in ((li, ri), (lr, rr)):
+            assert set(got) == set(ref)
+            for k, v in ref.items():
+                assert abs(float(got[k]) - float(v)) <= 5e-3 * max(1.0, abs(float(v))), (it, k, float(got[k]), float(v))
+        total = sum(float(t.grad.double().pow(2).sum()) for t in sd.values() if t.grad is not None) ** 0.5
+        got = dict(model.named_parameters())
+        sq = 0.0
+        for n, t in sd.items():
+            if t.grad is None:
+                continue
+            g = got[n].grad
+            assert g is not None, n
+            gn, rn = float(g.double().norm()), float(t.grad.double().norm())
+            sq += gn * gn
+            assert abs(gn - rn) <= 3e-2 * max(rn, 1e-2 * total), (it, n, gn, rn)
+        assert abs(sq ** 0.5 - total) <= 1.2e-2 * total, (it, sq ** 0.5, total)
+        assert got["bbox_head.0.weight"].grad is not None    # only the region part produces it

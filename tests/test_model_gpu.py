@@ -4,8 +4,8 @@ on identical seeded weights, batches and injected hard negatives.
 
 Tolerances (bf16 GEMM/attention operands, fp32 everything else, vs the reference's fp32 CPU run): each bound is ~1.3-2x the worst
 deviation measured over the ten cases on MI355X (profiles/r03d_parity_worst.txt), so that a regression shows:
-  losses              1e-3 relative at the headline batch (case base_full_b64, BASELINE.json configs[1]: the north-star
-                      tolerance; measured 6e-5); 5e-3 for the 2..8-sample toy batches, whose losses average the same per-sample
+  losses              1e-3 relative at the configurations' own per-GPU batches (cases base_full_b64 = BASELINE.json configs[1] and
+                      large_full_b32 = configs[3]: the north-star tolerance; measured 6e-5 at B = 64); 5e-3 for the 2..8-sample toy batches, whose losses average the same per-sample
                       bf16 operand-rounding noise over 16x fewer samples (measured 4.7e-3, tiny_video)
   activations/logits  pointwise, of the tensor's max-abs (one bf16 rounding is 2^-9 of an element; ~36 GEMMs deep): vision tokens /
                       features 8e-3 (4.7e-3), text tokens / features 1.6e-2 (1.1e-2), ITC / MLM logits 2e-2 (1.4e-2), ITM logits
@@ -65,14 +65,15 @@ def run_case(case, tmpdir, synthetic):
 
 
 @pytest.mark.parametrize("case", ["tiny", "tiny_region", "tiny_video", "base_shallow", "large_shallow", "base_full", "base_full_b64",
-                                  "large_full", "video_full", "base_region"])
+                                  "large_full", "large_full_b32", "video_full", "base_region"])
 def test_step_matches_reference(case, tmp_path, synthetic):
     gold = np.load(os.path.join(GOLD, case + ".npz"))
     model, loss, c = run_case(case, tmp_path, synthetic)
     report = []
     for k, v in loss.items():
         ref = float(gold[k])
-        report.append(("loss " + k, abs(v.item() - ref) / max(abs(ref), 1e-6), 1e-3 if c["batch"] >= 64 else 5e-3))
+        # north_star's 1e-3 at the configurations' own per-GPU batches (base: 64, large: 32); 5e-3 for the toy batches
+        report.append(("loss " + k, abs(v.item() - ref) / max(abs(ref), 1e-6), 1e-3 if c["batch"] >= 32 else 5e-3))
     full = case.startswith("tiny")
     acts = dict(model.last)
     acts["itc_logits"] = acts["image_feat"] @ acts["text_feat"].t() / model.temp.detach()

@@ -215,6 +215,16 @@ class RocmDDPAccelerator(Accelerator):
         comm = self.buckets.comm if self.buckets is not None else None
         return SegmentedStep(module, static_batch, world=getattr(self, "world_size", 1), rank=rank, comm=comm, **kw)
 
+    def mixed_step(self, model, parts, **kw):
+        """Pretrain.run_mixed_iter (Pretrain.py:189-252) - image + region (+ video) sub-iterations of one optimizer step, gradients
+        accumulated, ONE averaging after the last - as replayed hipGraph segments: graph.MixedStep bound to this rank / world size /
+        communicator.  Replaces the forwards and the two backward_step calls of that iteration."""
+        from .graph import MixedStep
+        module = getattr(model, "module", model)
+        rank = dist.get_rank() if dist.is_initialized() else 0
+        comm = self.buckets.comm if self.buckets is not None else None
+        return MixedStep(module, parts, world=getattr(self, "world_size", 1), rank=rank, comm=comm, **kw)
+
     def optimizer_step(self, optimizer, model, grad_norm):
         """Clip to `grad_norm`, return the total norm as a float (one host sync, like the reference's float(...)).
         With optim.FusedAdamW the norm is one multi-tensor launch and the clip coefficient is applied inside

@@ -48,44 +48,82 @@ class X2Comm:
         """store: torch.distributed Store (set/get), or a file path shared by all ranks.  Every communicator gets a key of
         its own (`key` + a per-process sequence number: all ranks create their communicators in the same order), so a second
         communicator - or an id left behind by an earlier run in a file store - can never be picked up for this one; with a
-        path the launch id (MASTER_PORT / TORCHELASTIC_RUN_ID) is part of the file name, and rank 0 removes the file once every
-        rank has read it (ranks acknowledge through marker files)."""
+        path the launch id (MASTER_PORT / TORCHELASTIC_RUN_ID) is part of the file name and the exchange is `_from_file`'s
+        announce / publish / acknowledge protocol."""
         cls._SEQ += 1
         key = "%s.%d" % (key, cls._SEQ)
         if isinstance(store, str):
             launch = os.environ.get("TORCHELASTIC_RUN_ID") or os.environ.get("MASTER_PORT") or "0"
             path = "%s.%s.%s" % (store, launch, key)
-            if rank == 0:
-                with open(path + ".tmp", "wb") as f:
-                    f.write(cls.unique_id())
-                os.replace(path + ".tmp", path)
-            t0 = time.time()
-            while not os.path.exists(path):
-                if time.time() - t0 > 120:
-                    raise X2HipError("x2_comm: rank 0 never published the RCCL id at %s" % path)
-                time.sleep(0.05)
-            with open(path, "rb") as f:
-                ident = f.read()
-            comm = cls(ident, rank, world)        # x2_comm_init returns once every rank has joined: all have read the id
-            open("%s.ack%d" % (path, rank), "w").close()
-            if rank == 0:
-                t0 = time.time()
-                while not all(os.path.exists("%s.ack%d" % (path, r)) for r in range(world)) and time.time() - t0 < 120:
-                    time.sleep(0.05)
-                for r in range(world):
-                    try:
-                        os.remove("%s.ack%d" % (path, r))
-                    except OSError:
-                        pass
-                try:
-                    os.remove(path)
-                except OSError:
-                    pass
-            return comm
+            return cls._from_file(path, rank, world)
         if rank == 0:
             store.set(key, cls.unique_id())
         ident = bytes(store.get(key))         # blocks until rank 0 has set THIS communicator's key
         return cls(ident, rank, world)
+
+    @classmethod
+    def _from_file(cls, path, rank, world, timeout=120.0):
+        """File rendezvous that survives leftovers of a crashed launch with the same name (default port, same sequence number):
+        every rank announces itself (`path.hello<r>`), rank 0 first removes whatever it finds under this name, waits for all
+        announcements and only THEN publishes the id - so the id of this launch is newer than every announcement, and a rank
+        accepts nothing older than its own first announcement.  A rank whose announcement rank 0's clean-up removed writes it
+        again.  Time-outs raise; rank 0 removes the files once every rank has joined and acknowledged."""
+        hello, ack = "%s.hello%d" % (path, rank), "%s.ack%d" % (path, rank)
+
+        def touch(p):
+            with open(p, "w"):
+                pass
+            return os.stat(p).st_mtime_ns
+
+        def wait(cond, what):
+            t0 = time.time()
+            while not cond():
+                if time.time() - t0 > timeout:
+                    raise X2HipError("x2_comm: timed out after %.0f s waiting for %s (%s)" % (timeout, what, path))
+                time.sleep(0.05)
+
+        if rank == 0:
+            for r in range(world):
+                for f in ("%s.hello%d" % (path, r), "%s.ack%d" % (path, r)):
+                    if r != 0 and os.path.exists(f):
+                        os.remove(f)
+            for f in (path, path + ".tmp"):
+                if os.path.exists(f):
+                    os.remove(f)
+            wait(lambda: all(os.path.exists("%s.hello%d" % (path, r)) for r in range(1, world)), "every rank's announcement")
+            with open(path + ".tmp", "wb") as f:
+                f.write(cls.unique_id())
+            os.replace(path + ".tmp", path)
+            with open(path, "rb") as f:
+                ident = f.read()
+        else:
+            first = touch(hello)
+
+            def fresh():
+                if not os.path.exists(hello):
+                    touch(hello)                  # removed by rank 0's clean-up: announce again
+                try:
+                    return os.stat(path).st_mtime_ns >= first
+                except OSError:
+                    return False
+            wait(fresh, "rank 0's RCCL id")
+            with open(path, "rb") as f:
+                ident = f.read()
+        comm = cls(ident, rank, world)            # x2_comm_init returns once every rank has joined: all have read the id
+        touch(ack)
+        if rank == 0:
+            wait(lambda: all(os.path.exists("%s.ack%d" % (path, r)) for r in range(world)), "every rank's acknowledgement")
+            for r in range(world):
+                for f in ("%s.hello%d" % (path, r), "%s.ack%d" % (path, r)):
+                    try:
+                        os.remove(f)
+                    except OSError:
+                        pass
+            try:
+                os.remove(path)
+            except OSError:
+                pass
+        return comm
 
     def info(self):
         r, w = C.c_int(), C.c_int()
@@ -104,6 +142,9 @@ class X2Comm:
 
     def allgather(self, send, recv, stream=None):
         assert send.is_cuda and send.is_contiguous() and recv.is_contiguous() and recv.numel() == send.numel() * self.world
+        if send.dtype not in _DTYPE:              # a byte copy: any 4- / 8-byte element type travels as fp32 words
+            assert send.dtype == recv.dtype and send.element_size() % 4 == 0
+            send, recv = send.view(torch.float32), recv.view(torch.float32)
         _check(lib().x2_comm_allgather(self.h, send.data_ptr(), recv.data_ptr(), send.numel(), _DTYPE[send.dtype], None,
                                        _stream_handle(stream)), "x2_comm_allgather")
         return recv

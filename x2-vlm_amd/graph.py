@@ -46,42 +46,50 @@ class GraphedStep:
         if not enabled or os.environ.get("X2_GRAPH", "1") == "0":
             return
         from . import engine
-        K.DROP_EPOCH = torch.zeros(1, dtype=torch.int32, device="cuda")
+        # The epoch word's ADDRESS is baked into every captured dropout kernel: it is allocated once per process and never
+        # replaced (a second step object - INTEGRATION 1b offers both kinds - must not free the word a live graph reads);
+        # every step object increments the one it captured with.
+        if K.DROP_EPOCH is None:
+            K.DROP_EPOCH = torch.zeros(1, dtype=torch.int32, device="cuda")
+        self._epoch = K.DROP_EPOCH
         side_rule, engine.SIDE.only_from = engine.SIDE.only_from, self.stream.cuda_stream     # see engine.SideStream.only_from
-        gc.collect()                          # autograd graphs of earlier eager steps (their AccumulateGrad nodes remember the
-                                              # stream they were created on) must be gone before the capture stream's own
-        self.stream.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(self.stream):
-            for _ in range(warmup):           # eager, on the capture stream: caches, workspaces, AccumulateGrad streams
-                K.DROP_EPOCH.add_(1)
-                fn()
-        torch.cuda.synchronize()
-        g = torch.cuda.CUDAGraph()
-        trace = os.environ.get("X2_GRAPH_TRACE") == "1"
-        engine.BANK.invalidate()              # the bf16 weight casts must be part of the captured step, whatever warm-up left cached
-        self._grads = []
         try:
-            if trace:
-                print("GraphedStep: warm-up done, capturing", flush=True)
-            with torch.cuda.graph(g, stream=self.stream):
-                K.DROP_EPOCH.add_(1)
-                self.out = fn()
-                if trace:
-                    print("GraphedStep: fn() captured, ending capture", flush=True)
-            if trace:
-                print("GraphedStep: graph instantiated", flush=True)
-            self.graph, self.mode = g, "hipgraph"
-            # the graph writes gradients into the tensors that were .grad when capture ended: remember them, so that a
-            # training loop that calls optimizer.zero_grad(set_to_none=True) between replays gets them back (__call__)
-            params = getattr(fn, "parameters", None)
-            self._grads = [(p_, p_.grad) for p_ in (params() if callable(params) else ()) if p_.grad is not None]
-        except Exception as e:                # noqa: BLE001 - anything that cannot be captured: run eagerly instead
-            K.DROP_EPOCH = None               # eager launches draw their seeds on the host again
-            self.error = "%s: %s" % (type(e).__name__, str(e).splitlines()[0] if str(e) else "")
-            if verbose:
-                print("GraphedStep: capture failed, running eagerly (%s)" % self.error, flush=True)
+            gc.collect()                      # autograd graphs of earlier eager steps (their AccumulateGrad nodes remember the
+                                              # stream they were created on) must be gone before the capture stream's own
+            self.stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.stream):
+                for _ in range(warmup):       # eager, on the capture stream: caches, workspaces, AccumulateGrad streams
+                    self._epoch.add_(1)
+                    fn()
             torch.cuda.synchronize()
-        engine.SIDE.only_from = side_rule
+            g = torch.cuda.CUDAGraph()
+            trace = os.environ.get("X2_GRAPH_TRACE") == "1"
+            engine.BANK.invalidate()          # the bf16 weight casts must be part of the captured step, whatever warm-up left cached
+            self._grads = []
+            try:
+                if trace:
+                    print("GraphedStep: warm-up done, capturing", flush=True)
+                with torch.cuda.graph(g, stream=self.stream):
+                    self._epoch.add_(1)
+                    self.out = fn()
+                    if trace:
+                        print("GraphedStep: fn() captured, ending capture", flush=True)
+                if trace:
+                    print("GraphedStep: graph instantiated", flush=True)
+                self.graph, self.mode = g, "hipgraph"
+                # the graph writes gradients into the tensors that were .grad when capture ended: remember them, so that a
+                # training loop that calls optimizer.zero_grad(set_to_none=True) between replays gets them back (__call__)
+                params = getattr(fn, "parameters", None)
+                self._grads = [(p_, p_.grad) for p_ in (params() if callable(params) else ()) if p_.grad is not None]
+            except Exception as e:            # noqa: BLE001 - anything that cannot be captured: run eagerly instead
+                # the epoch word stays (other step objects may have captured it); eager launches keep mixing it in, __call__
+                # keeps incrementing it
+                self.error = "%s: %s" % (type(e).__name__, str(e).splitlines()[0] if str(e) else "")
+                if verbose:
+                    print("GraphedStep: capture failed, running eagerly (%s)" % self.error, flush=True)
+                torch.cuda.synchronize()
+        finally:
+            engine.SIDE.only_from = side_rule
         torch.cuda.current_stream().wait_stream(self.stream)
 
     def __call__(self):
@@ -94,8 +102,7 @@ class GraphedStep:
                     if p_.grad is not g_:
                         p_.grad = g_
             else:
-                if K.DROP_EPOCH is not None:
-                    K.DROP_EPOCH.add_(1)
+                self._epoch.add_(1)
                 self.out = self.fn()
         cur.wait_stream(self.stream)
         return self.out
@@ -148,15 +155,23 @@ class SegmentedStep:
 
     def __init__(self, model, batch, world=1, rank=0, process_group=None, comm=None, warmup=2, enabled=True, verbose=False,
                  ret_bbox_loss=False, ret_match_loss=True, recast_weights=True, clamp_temp=True, total_loss=None, side_stream=None,
-                 vision_cuts=None):
+                 vision_cuts=None, reduce_grads=True, defer_reduce=False):
         """side_stream: weight-gradient GEMMs of the stream-A segments (tail, vision backward) on engine.SIDE, forked from and
         joined into stream A inside the segment.  Those segments then replay node by node (~15 us of host time each, still
-        well under the GPU time of a step) but keep the 3 % the side stream is worth on one GPU.  Default: X2_SEG_SIDE or off."""
+        well under the GPU time of a step) but keep the 3 % the side stream is worth on one GPU.  Default: X2_SEG_SIDE or off.
+        reduce_grads=False: no gradient averaging at all (the ITC all-gather stays) - a sub-iteration whose gradients a MixedStep
+        adds to another step's before ONE reduction; defer_reduce=True: the reduction plan is built but issued by `reduce_all()`
+        instead of behind the segments (the accumulating step of a MixedStep)."""
         from . import engine
         self.engine = engine
         self.model, self.batch, self.world, self.rank, self.pg, self.comm = model, batch, world, rank, process_group, comm
+        # collectives are issued when there is more than one rank - or when X2_DDP_SINGLE_RANK_COLLECTIVES=1 asks a single rank to
+        # run them anyway (the RCCL call path of the replayed step on a 1-GPU box; AVG over one rank is the identity)
+        self.coll = world > 1 or os.environ.get("X2_DDP_SINGLE_RANK_COLLECTIVES", "0") == "1"
         self.ret_bbox_loss, self.ret_match_loss = ret_bbox_loss, ret_match_loss
         self.recast_weights, self.clamp_temp = recast_weights, clamp_temp
+        self.reduce_grads, self.defer_reduce = reduce_grads, defer_reduce
+        self._home = {}                         # id(param) -> the static tensor the captured segments leave its gradient in
         self.side_stream = (os.environ.get("X2_SEG_SIDE", "0") == "1") if side_stream is None else bool(side_stream)
         # fusion-layer weight gradients as a segment of their own on stream B (engine.WGRAD_QUEUE); X2_SEG_TAIL_WGRAD=0: in line
         self.defer_tail_wgrad = os.environ.get("X2_SEG_TAIL_WGRAD", "1") == "1"
@@ -181,7 +196,8 @@ class SegmentedStep:
         self.total_loss = total_loss or (lambda losses: sum(losses.values()))
         self.sA = torch.cuda.Stream()
         self.sB = self.sA if os.environ.get("X2_SEG_ONE_STREAM", "0") == "1" else torch.cuda.Stream()    # A/B: everything on one stream
-        self.sC = torch.cuda.Stream() if world > 1 else None
+        self.sC = torch.cuda.Stream() if self.coll else None     # gradient all-reduces
+        self.sG = torch.cuda.Stream() if self.coll else None     # ITC all-gathers (see _gather)
         self.t, self.graphs = {}, {}
         self.mode, self.error = "eager", None
         self.messages = 0                       # collectives issued per step (tests / diagnostics)
@@ -196,8 +212,9 @@ class SegmentedStep:
         E = model.embed_dim
         self.t["fi_all"] = torch.zeros(world * B, E, device=dev, requires_grad=True)
         self.t["ft_all"] = torch.zeros(world * B, E, device=dev, requires_grad=True)
-        if K.DROP_EPOCH is None:
+        if K.DROP_EPOCH is None:                  # allocated once per process, never replaced (see GraphedStep)
             K.DROP_EPOCH = torch.zeros(1, dtype=torch.int32, device=dev)
+        self._epoch = K.DROP_EPOCH
         cur = torch.cuda.current_stream()
         self.sA.wait_stream(cur)
         side, tie, hook, rule = engine.SIDE.enabled, engine.TIE_WORD_GRAD, engine.GRAD_READY_HOOK, engine.SIDE.only_from
@@ -210,9 +227,63 @@ class SegmentedStep:
                 self._capture(verbose)
         finally:
             engine.SIDE.enabled, engine.TIE_WORD_GRAD, engine.GRAD_READY_HOOK, engine.SIDE.only_from = side, tie, hook, rule
+            # the warm-up / capture passes counted stage calls; an accelerator's GradientBuckets reads the counters of the NEXT
+            # eager backward_step (a layer that "ran twice" loses its early all-reduce)
+            engine.STAGE_CALLS.clear()
+        if self.coll:
+            self._agree_across_ranks(verbose)
         cur.wait_stream(self.sA)
 
     # ------------------------------------------------------------------ set-up
+    def _plan_digest(self):
+        """What this rank will send, in order: (segment, element count) of every message of a replayed step.  All ranks
+        must have derived the SAME sequence from their own capture - RCCL matches collectives by issue order, a mismatch is a
+        hang, not an error."""
+        import hashlib
+        items = []
+        for seg in self._rorder:
+            inplace, packed = (self._plan or {}).get(seg, ((), None))
+            items.append((seg, tuple(int(t.numel()) for t in inplace), -1 if packed is None else int(packed[0].numel())))
+        return int.from_bytes(hashlib.sha256(repr(items).encode()).digest()[:7], "big"), len(items)
+
+    def _exchange_ints(self, vals):
+        """[world, len(vals)] int64 on the host: every rank's values (one small all-gather through the step's own transport)."""
+        dev = self.batch["text_ids"].device
+        mine = torch.tensor(vals, dtype=torch.int64, device=dev)
+        out = torch.empty(self.world * len(vals), dtype=torch.int64, device=dev)
+        if self.comm is not None:
+            self.comm.allgather(mine, out)
+        else:
+            import torch.distributed as dist
+            dist.all_gather(list(out.chunk(self.world)), mine, group=self.pg)
+        torch.cuda.synchronize()
+        return out.view(self.world, len(vals)).cpu()
+
+    def _agree_across_ranks(self, verbose=False):
+        """world > 1, after capture: (a) the launch mode is a job-wide decision - a rank whose capture failed would issue ONE flat
+        all-reduce per step while the others issue per-segment messages: if any rank fell back, all do; (b) the reduction plans
+        must be identical (message order and sizes), checked through a digest."""
+        ok = 1 if self.graphs else 0
+        digest, nseg = self._plan_digest() if ok else (0, 0)
+        got = self._exchange_ints([ok, digest, nseg])
+        if int(got[:, 0].min()) == 0:
+            if self.graphs:
+                self.error = "capture failed on rank(s) %s: all ranks run the segments eagerly" % [r for r in range(self.world) if int(got[r, 0]) == 0]
+                if verbose:
+                    print("SegmentedStep: " + self.error, flush=True)
+            self._drop_graphs()
+            return
+        if not bool((got[:, 1] == got[0, 1]).all()) or not bool((got[:, 2] == got[0, 2]).all()):
+            raise RuntimeError("SegmentedStep: ranks derived different gradient-reduction plans (rank %d: %d segments, digest %x; all: %s) - "
+                               "the collectives would not match" % (self.rank, nseg, digest, got[:, 1:].tolist()))
+
+    def _drop_graphs(self):
+        """Back to eager segments: forget the graphs and everything derived from the capture (a half-built plan would make
+        the eager fallback all-reduce stale captured arenas as well)."""
+        self.graphs = {}
+        self.mode = "eager"
+        self._plan, self._arenas, self._rorder = None, [], []
+        self._grads = []
     def _pin_accumulators(self):
         """Create (and keep) every parameter's AccumulateGrad node under the stream of the segment that will produce its
         gradient: autograd accumulates on the node's stream, and a node created lazily on another stream would pull that
@@ -304,19 +375,28 @@ class SegmentedStep:
         self.t["feat"] = m.tail_features(self.t["ie"], self.t["both_leaf"])
 
     def _gather(self):
-        """ITC features of all ranks into the static leaves (eager, between two segments; xvlm.py:140-160)."""
+        """ITC features of all ranks into the static leaves (eager, between two segments; xvlm.py:140-160).  The collective is
+        issued from a stream of its own that is never captured: torch.distributed's NCCL (= RCCL) process group records its
+        completion events on the stream the call is made from, its watchdog thread keeps querying them, and ROCm refuses
+        hipEventQuery on an event whose stream has meanwhile started capturing (the next segment's capture follows at once):
+        `operation not permitted on an event last recorded in a capturing stream` took the process down
+        (tests/test_ddp_gpu.py::test_single_rank_rccl_through_replayed_segments)."""
         fi, ft = self.t["feat"]
-        for src, dst in ((fi, self.t["fi_all"]), (ft, self.t["ft_all"])):
-            out = dst.detach()
-            if self.world == 1:
-                out.copy_(src.detach())
-            elif self.comm is not None:
-                self.comm.allgather(src.detach().contiguous(), out)
+        if not self.coll:
+            for src, dst in ((fi, self.t["fi_all"]), (ft, self.t["ft_all"])):
+                dst.detach().copy_(src.detach())
+            return
+        self.sG.wait_stream(self.sA)
+        with torch.cuda.stream(self.sG):
+            for src, dst in ((fi, self.t["fi_all"]), (ft, self.t["ft_all"])):
+                out = dst.detach()
+                if self.comm is not None:
+                    self.comm.allgather(src.detach().contiguous(), out)
+                else:
+                    import torch.distributed as dist
+                    dist.all_gather(list(out.chunk(self.world)), src.detach().contiguous(), group=self.pg)
                 self.messages += 1
-            else:
-                import torch.distributed as dist
-                dist.all_gather(list(out.chunk(self.world)), src.detach().contiguous(), group=self.pg)
-                self.messages += 1
+        self.sA.wait_stream(self.sG)
 
     def _s_loss(self):
         m, b, t = self.model, self.batch, self.t
@@ -380,10 +460,12 @@ class SegmentedStep:
             eng.TIE_WORD_GRAD = True
             if self.recast_weights:
                 eng.BANK.invalidate()         # as after an optimizer step: fp32 master weights are re-cast inside the step
+            else:
+                eng.BANK.backward_seen = False    # a later sub-iteration of the same optimizer step: the copies are current
             for p in self.params:
                 p.grad = None
         with torch.cuda.stream(A):
-            K.DROP_EPOCH.add_(1)
+            self._epoch.add_(1)
         Bs.wait_stream(A)
         self._seg(mode, "T", Bs, self._s_text, pb)
         if self.prefetch_casts:
@@ -437,11 +519,12 @@ class SegmentedStep:
         try:
             self._run("capture")
             self._grads = [(p, p.grad) for p in self.params if p.grad is not None]
+            self._home = {id(p): p.grad for p in self.params if p.grad is not None}
             self._make_plan()
             self.mode = "hipgraph-segments"
         except Exception as e:                # noqa: BLE001 - anything that cannot be captured: run the segments eagerly
             self.error = "%s: %s" % (type(e).__name__, str(e).splitlines()[0] if str(e) else "")
-            self.graphs = {}
+            self._drop_graphs()
             if verbose:
                 print("SegmentedStep: capture failed, running eagerly (%s)" % self.error, flush=True)
             torch.cuda.synchronize()
@@ -453,7 +536,7 @@ class SegmentedStep:
     def _make_plan(self):
         """Per segment: [tensors to all-reduce in place], (flat, views, sources) for the packed remainder."""
         self._plan = {}
-        if self.world == 1:
+        if not self.coll or not self.reduce_grads:
             return
         inside = lambda g, flat: flat.data_ptr() <= g.data_ptr() and g.data_ptr() + g.numel() * 4 <= flat.data_ptr() + flat.numel() * 4
         done = set()
@@ -505,8 +588,19 @@ class SegmentedStep:
     def _reduce(self, seg, stream):
         if self._capturing and seg not in self._rorder:
             self._rorder.append(seg)
-        if self.world == 1 or self._plan is None:        # one rank; or still warming up / capturing
+        if not self.coll or self._plan is None or self.defer_reduce:      # one rank; still warming up / capturing; or reduce_all() does it
             return
+        self._reduce_now(seg, stream)
+
+    def reduce_all(self, stream=None):
+        """defer_reduce=True: every segment's reduction now, in plan order, behind `stream` (default: stream A)."""
+        if not self.coll or not self._plan:
+            return
+        for seg in self._rorder:
+            self._reduce_now(seg, self.sA if stream is None else stream)
+        self.sA.wait_stream(self.sC)
+
+    def _reduce_now(self, seg, stream):
         inplace, packed = self._plan.get(seg, ((), None))
         self.sC.wait_stream(stream)
         with torch.cuda.stream(self.sC):
@@ -562,12 +656,126 @@ class SegmentedStep:
             eng.GRAD_READY_HOOK = None
             try:
                 self._run("eager")
-                if self.world > 1:
+                if self.coll and self.reduce_grads and not self.defer_reduce:
                     with torch.cuda.stream(self.sA):
                         self._reduce_eager_fallback()
             finally:
                 eng.SIDE.enabled, eng.TIE_WORD_GRAD, eng.GRAD_READY_HOOK, eng.SIDE.only_from = side, tie, hook, rule
+                eng.STAGE_CALLS.clear()
         cur.wait_stream(self.sA)
         return self.t["loss"]
 
     copy_inputs = staticmethod(GraphedStep.copy_inputs)
+
+
+class MixedStep:
+    """Pretrain.run_mixed_iter (Pretrain.py:189-252) as replayed hipGraph segments: several sub-iterations of ONE optimizer step -
+    the image batch, the region batch, a video batch - whose gradients accumulate (the reference sums the losses of the image and
+    region forwards into one backward_step and gives the video batch a backward_step of its own, `Pretrain.py:197, 247`; either
+    way the optimizer sees the sum of the sub-iterations' gradients) and are averaged over the ranks ONCE, after the last one.
+
+    Every part is a SegmentedStep of its own (own static inputs, own graphs and gradient buffers; the bf16 weight copies are
+    cast by the first part only and read by the others); after the last part ONE multi-tensor add folds the later parts'
+    gradients into the first part's static buffers, and - more than one rank - the first part's reduction plan runs: one
+    message per layer arena, as for a single iteration.  p.grad of every parameter is a static tensor afterwards.
+
+    parts: list of dict(batch=static device tensors, weight=iter_perc (1.0), ret_bbox_loss=False, ret_match_loss=True,
+                        negatives=None (tests: injected hard negatives, static int32 device tensors)).
+    Returns the list of the parts' loss dicts (unweighted, as the reference logs them)."""
+
+    def __init__(self, model, parts, world=1, rank=0, process_group=None, comm=None, warmup=1, enabled=True, verbose=False, **kw):
+        self.model, self.world, self.rank = model, world, rank
+        self.parts, self.steps = parts, []
+        for i, part in enumerate(parts):
+            w = float(part.get("weight", 1.0))
+            if "negatives" in part:
+                model.injected_negatives = part["negatives"]
+            self.steps.append(SegmentedStep(model, part["batch"], world=world, rank=rank, process_group=process_group, comm=comm,
+                                            warmup=warmup, enabled=enabled, verbose=verbose,
+                                            ret_bbox_loss=part.get("ret_bbox_loss", False), ret_match_loss=part.get("ret_match_loss", True),
+                                            recast_weights=(i == 0) and kw.get("recast_weights", True),
+                                            clamp_temp=(i == 0) and kw.get("clamp_temp", True),
+                                            total_loss=(lambda losses, w=w: w * sum(losses.values())),
+                                            reduce_grads=(i == 0), defer_reduce=True,
+                                            **{k: v for k, v in kw.items() if k not in ("recast_weights", "clamp_temp")}))
+        first = self.steps[0]
+        self.params = first.params
+        self.coll = first.coll
+        self.mode = "hipgraph-segments" if all(s_.graphs for s_ in self.steps) else "eager"
+        if self.mode == "eager":
+            for s_ in self.steps:                     # all parts or none (with more than one rank every part's mode was already agreed job-wide)
+                s_._drop_graphs()
+        self.error = next((s_.error for s_ in self.steps if s_.error), None)
+        self.messages = 0
+        self._dst, self._src, self._final, self._extra = [], [], [], None
+        if self.mode != "eager":
+            self._plan_accumulation()
+
+    def _plan_accumulation(self):
+        first = self.steps[0]
+        home = dict(first._home)                      # where the first part leaves a gradient = what its reduction plan sends
+        lonely = []                                   # parameters only later parts produce a gradient for (bbox head after an image part)
+        for s_ in self.steps[1:]:
+            for p in self.params:
+                g = s_._home.get(id(p))
+                if g is None:
+                    continue
+                if id(p) in home:
+                    self._dst.append(home[id(p)])
+                    self._src.append(g)
+                else:
+                    home[id(p)] = g
+                    lonely.append(p)
+        final = {id(p): g for p, g in first._grads}   # after the plan: packed views for the small tensors
+        if lonely and self.coll:
+            sizes = [home[id(p)].numel() for p in lonely]
+            flat = torch.empty(sum(sizes), device=home[id(lonely[0])].device, dtype=torch.float32)
+            views = [v.view_as(home[id(p)]) for v, p in zip(flat.split(sizes), lonely)]
+            self._extra = (flat, views, [home[id(p)] for p in lonely])
+            for p, v in zip(lonely, views):
+                final[id(p)] = v
+        else:
+            for p in lonely:
+                final[id(p)] = home[id(p)]
+        self._final = [(p, final[id(p)]) for p in self.params if id(p) in final]
+
+    def copy_inputs(self, i, batch):
+        GraphedStep.copy_inputs(self.parts[i]["batch"], batch)
+
+    def __call__(self):
+        cur = torch.cuda.current_stream()
+        first = self.steps[0]
+        self.messages = 0
+        if self.mode != "eager":
+            losses = [s_() for s_ in self.steps]
+            first.sA.wait_stream(cur)
+            with torch.cuda.stream(first.sA):
+                if self._dst:
+                    torch._foreach_add_(self._dst, self._src)
+                first.reduce_all()
+                if self._extra is not None:
+                    flat, views, srcs = self._extra
+                    torch._foreach_copy_(views, srcs)
+                    first._all_reduce(flat)
+            cur.wait_stream(first.sA)
+            for p, g in self._final:
+                if p.grad is not g:
+                    p.grad = g
+            self.messages = sum(s_.messages for s_ in self.steps)
+            return losses
+        # eager fallback (capture disabled or failed): every part launches its kernels from Python and starts from p.grad = None
+        total, losses = {}, []
+        for s_ in self.steps:
+            losses.append(s_())
+            for p in self.params:
+                if p.grad is not None:
+                    total[id(p)] = p.grad if id(p) not in total else total[id(p)] + p.grad
+        for p in self.params:
+            p.grad = total.get(id(p))
+        if self.coll:
+            first.sA.wait_stream(cur)
+            with torch.cuda.stream(first.sA):
+                first._reduce_eager_fallback()
+            cur.wait_stream(first.sA)
+        self.messages = sum(s_.messages for s_ in self.steps)
+        return losses
