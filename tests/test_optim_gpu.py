@@ -158,7 +158,8 @@ def test_fifty_step_loss_curve_at_the_real_geometry_through_replayed_segments(sy
     inside the graphs after every update) + the fused multi-tensor AdamW + global-norm clip 1.0 with the reference's parameter
     groups (optim.py:26-104, Pretrain.py:54-76) - against the CPU oracle trained on the same batches with the transformers
     4.12.5 AdamW rule in float64.  Eval-mode layers (the two sides cannot share dropout streams through an optimizer run);
-    band: every step within 1.5e-2 of the oracle's loss, the mean deviation over the run within 5e-3."""
+    band: every step within 4e-3 of the oracle's loss, the mean deviation over the run within 1e-3 (measured on MI355X:
+    1.3e-3 / 2.3e-4, profiles/r05f_loss_curve_50_steps.txt)."""
     mp = importlib.import_module("x2-vlm_amd.model_pretrain")
     optim = importlib.import_module("x2-vlm_amd.optim")
     graph = importlib.import_module("x2-vlm_amd.graph")
@@ -220,7 +221,7 @@ def test_fifty_step_loss_curve_at_the_real_geometry_through_replayed_segments(sy
     dev_rel = [abs(a - b_) / abs(b_) for a, b_ in zip(curve_hip, curve_ref)]
     print("max / mean relative deviation %.3e / %.3e" % (max(dev_rel), sum(dev_rel) / len(dev_rel)))
     assert sum(curve_ref[-10:]) / 10 < sum(curve_ref[:10]) / 10 - 0.05                   # it does train
-    assert max(dev_rel) <= 1.5e-2 and sum(dev_rel) / len(dev_rel) <= 5e-3, (max(dev_rel), sum(dev_rel) / len(dev_rel))
+    assert max(dev_rel) <= 4e-3 and sum(dev_rel) / len(dev_rel) <= 1e-3, (max(dev_rel), sum(dev_rel) / len(dev_rel))
     # the trained weights themselves: a large matrix of each tower ends within 2e-3 of the oracle's (relative Frobenius distance)
     got = dict(model.named_parameters())
     for name in ("vision_encoder.blocks.1.mlp.fc1.weight", "text_encoder.bert.encoder.layer.2.crossattention.self.query.weight",

@@ -364,6 +364,13 @@ class _LayerPairs:
                 if GRAD_READY_HOOK is not None:
                     for flat, key, params in pubs:
                         GRAD_READY_HOOK(flat, key, None, params)
+            # one contribution per parameter: autograd ADDS a second call's arena view to the first's the moment it receives
+            # it - both still empty - and the late GEMMs would then overwrite the sum with one of them
+            later.params = set(id(p_) for _, _, ps in pubs for p_ in ps)
+            for fn in WGRAD_QUEUE:
+                if getattr(fn, "params", set()) & later.params:
+                    raise RuntimeError("engine.WGRAD_QUEUE: a layer ran twice in one pass; its weight gradients cannot be deferred "
+                                       "(graph.SegmentedStep: defer_tail_wgrad / defer_vision_wgrad)")
             WGRAD_QUEUE.append(later)
             return
         assert not extra, "param_only closures are only collected while WGRAD_QUEUE is set"

@@ -174,7 +174,11 @@ class SegmentedStep:
         self._home = {}                         # id(param) -> the static tensor the captured segments leave its gradient in
         self.side_stream = (os.environ.get("X2_SEG_SIDE", "0") == "1") if side_stream is None else bool(side_stream)
         # fusion-layer weight gradients as a segment of their own on stream B (engine.WGRAD_QUEUE); X2_SEG_TAIL_WGRAD=0: in line
-        self.defer_tail_wgrad = os.environ.get("X2_SEG_TAIL_WGRAD", "1") == "1"
+        # Not with ret_bbox_loss: predict_bbox runs the fusion layers a SECOND time in the same pass, and a queued weight gradient
+        # is only valid with one contribution per parameter - autograd adds the second call's (still empty) arena view to the
+        # first's when it receives it, long before the queue fills either; the late TN GEMM then overwrites the sum with one
+        # contribution (round 4: the replayed region iteration had lost the other one; the eager path was right).
+        self.defer_tail_wgrad = os.environ.get("X2_SEG_TAIL_WGRAD", "1") == "1" and not ret_bbox_loss
         self._queue = None
         # The vision tower as a chain of stages cut at these block numbers (beit2.VisionTransformer.chunk_at): its backward
         # becomes one segment per stage, top first; the weight gradients of every stage but the lowest run as segments of
