@@ -23,7 +23,7 @@ extern "C" {
 #endif
 
 const char* x2_last_error(void);
-int x2_abi_version(void);          /* == 6 */
+int x2_abi_version(void);          /* == 7 */
 int x2_device_cus(void);           /* compute units of the current HIP device, 0 if none */
 int x2_tune(int key, int value);   /* kernel-variant knobs for probes/ and tests (0 = automatic); keys listed in csrc/gemm.hip */
 
@@ -132,14 +132,6 @@ int x2_reduce_partials_multi(const int64_t* desc, int count, void* stream);
 /* backward of x + gamma * u (beit2.py:206-207): du = gamma*dx (bf16), dgamma += sum dx*u, dbias += sum du */
 int x2_layerscale_bwd(const float* dx, const void* u, const float* gamma, void* du, float* dgamma, float* dbias,
                       const float* rowscale, int M, int D, float* ws /* [ceil(M/32)][2][D] */, int defer, void* stream);
-/* x2_layernorm_bwd and the x2_layerscale_bwd its output feeds in ONE pass over the rows (BEiT pre-LN blocks, beit2.py:
- * 205-207: every LayerNorm backward of the vision tower feeds exactly one layer-scale backward): dx = dres + LN'(dy) (fp32),
- * du = gamma * rowscale * dx (bf16), dw += , db += , dgamma += sum dx*rowscale*u, dbias += sum du.
- * ws: [ceil(rows/16)][4][D] partial rows {dw, db, dgamma, dbias}; defer != 0: the caller reduces them (x2_reduce_partials_multi) */
-int x2_layernorm_bwd_layerscale(const void* dy /* fp32, or bf16 when dy_is_bf16 */, int dy_is_bf16, const float* x, const float* mean,
-                                const float* rstd, const float* w, const float* dres, float* dx, float* dw, float* db,
-                                const void* u, const float* gamma, const float* rowscale, void* du, float* dgamma, float* dbias,
-                                int rows, int D, float* ws, int defer, void* stream);
 int x2_cast_bf16(const float* src, void* dst, long n, void* stream);
 int x2_cast_transpose_bf16(const float* src, void* dst, void* dstT, int R, int C, int ldt, void* stream);
 /* bf16 (W, W^T) copies of many fp32 weights in one launch (what apex O1's per-call weight casts amount to, done once per

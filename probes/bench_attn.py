@@ -40,27 +40,6 @@ def case(B, H, Lq, Lk, bias, mask, drop=None):
                    **({"drop": drop} if drop else {}), **kw)
     return fwd, bwd
 
-LIB = importlib.import_module("x2-vlm_amd._lib").lib()
-# in-process A/B of the strip-walking resident kernels at N = 197 (x2_tune(8, bits): attention.hip attn_variant())
-fwd, bwd = case(64, 12, 197, 197, True, False)
-for rnd in range(3):
-    row = []
-    for bits in (0, 4096, 8192, 4096 | 8192):
-        LIB.x2_tune(8, bits)
-        row.append("v%-5d fwd %6.1f bwd %6.1f" % (bits, timeit(fwd), timeit(bwd)))
-    print("vision N=197 round %d: " % rnd + "   ".join(row))
-LIB.x2_tune(8, -1)
-# XCD-aware workgroup order of the bias kernels (attention.hip attn_block) against the plain 3-D grid (bit 14 = 16384)
-for name, B, H, N in (("vision large N=577", 32, 16, 577), ("vision base N=197", 64, 12, 197)):
-    fwd, bwd = case(B, H, N, N, True, False)
-    for rnd in range(2):
-        row = []
-        for bits, tag in ((4096 | 8192, "default  "), (4096 | 8192 | 32768, "2waves/SIMD")):
-            LIB.x2_tune(8, bits)
-            row.append("%s fwd %6.1f bwd %6.1f" % (tag, timeit(fwd), timeit(bwd)))
-        print("%s round %d: " % (name, rnd) + "   ".join(row))
-LIB.x2_tune(8, -1)
-
 for name, B, H, Lq, Lk, bias, mask in [("vision large", 32, 16, 577, 577, True, False), ("vision", 64, 12, 197, 197, True, False), ("text self", 128, 12, 30, 30, False, True),
                                        ("fusion self", 256, 12, 30, 30, False, True)]:
     fwd, bwd = case(B, H, Lq, Lk, bias, mask)
@@ -99,6 +78,6 @@ def cross_case(S=256, Bi=64, H=12, L=30, T=197, drop=None):
     return fwd, bwd
 
 fwd, bwd = cross_case()
-print("cross (256 rows on 64 images)  fwd %6.1fus   bwd(dq+dkv) %6.1fus   [X2_ATTN_VARIANT=%s]" % (timeit(fwd), timeit(bwd), os.environ.get("X2_ATTN_VARIANT", "0")))
+print("cross (256 rows on 64 images)  fwd %6.1fus   bwd(dq+dkv) %6.1fus" % (timeit(fwd), timeit(bwd)))
 _, bwd = cross_case(drop=DROP)
 print("cross bwd with dropout 0.1: %6.1f us" % min(timeit(bwd) for _ in range(3)))

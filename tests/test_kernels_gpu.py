@@ -90,46 +90,6 @@ def test_gemm_nt_plain_and_epilogues(K, M, N, K_, nt_tile):
     assert relerr(out, resid + ref + bias) < 1e-5
 
 
-@pytest.mark.parametrize("tile", [1, 2, 3, 4], ids=["tile128", "tile192", "tile64", "tile160"])
-@pytest.mark.parametrize("M,N,K_", [(300, 200, 192), (788, 2304, 128), (1000, 768, 256)])
-def test_gemm_nt_row_contiguous_fp32_epilogue_matches_the_default_one(K, M, N, K_, tile):
-    """x2_tune(2, 64): the fp32-out feature sets with a lane owning 4 columns of two rows (stores of 4 rows x 256 contiguous
-    bytes) instead of 8 columns of one row - same arithmetic, so outputs and the saved bf16 side output must agree."""
-    lib = importlib.import_module("x2-vlm_amd._lib").lib()
-    A, B = bf(rnd(M, K_, seed=31)).to(dev), bf(rnd(N, K_, seed=32, scale=K_ ** -0.5)).to(dev)
-    bias, gamma, resid = rnd(N, seed=33).to(dev), rnd(N, seed=34).to(dev), rnd(M, N, seed=35).to(dev)
-    rowscale = (torch.rand(M, generator=torch.Generator().manual_seed(37)) > 0.2).float().to(dev) * 1.25
-    drop = K.dropout_spec(0.1, 1234, 5)
-
-    def run(kind):
-        aux = torch.zeros(M, N, device=dev, dtype=torch.bfloat16)
-        if kind == "bias_f32":
-            return K.gemm_nt(A, B, bias=bias, out_dtype=torch.float32), aux
-        if kind == "plain_f32":
-            return K.gemm_nt(A, B, out_dtype=torch.float32), aux
-        if kind == "bias_drop_resid":
-            return K.gemm_nt(A, B, bias=bias, resid=resid, out_dtype=torch.float32, drop=drop), aux
-        if kind == "bias_resid":
-            return K.gemm_nt(A, B, bias=bias, resid=resid, out_dtype=torch.float32), aux
-        if kind == "layerscale":
-            return K.gemm_nt(A, B, bias=bias, gamma=gamma, resid=resid, aux=aux, out_dtype=torch.float32), aux
-        return K.gemm_nt(A, B, bias=bias, gamma=gamma, resid=resid, aux=aux, out_dtype=torch.float32, rowscale=rowscale), aux
-
-    lib.x2_tune(1, 1); lib.x2_tune(3, tile)
-    try:
-        for kind in ("bias_f32", "plain_f32", "bias_drop_resid", "bias_resid", "layerscale", "layerscale_droppath"):
-            lib.x2_tune(2, 0)
-            ref, ref_aux = run(kind)
-            lib.x2_tune(2, 64)
-            got, got_aux = run(kind)
-            # same operations in the same order; only the compiler's fma contraction may differ between the two instantiations
-            for g_, r_ in ((got, ref), (got_aux, ref_aux)):
-                tol = 2e-6 if g_.dtype == torch.float32 else 4e-3
-                assert float((g_.float() - r_.float()).abs().max()) <= tol * max(1.0, float(r_.float().abs().max())), kind
-    finally:
-        lib.x2_tune(1, 0); lib.x2_tune(2, 0); lib.x2_tune(3, 0)
-
-
 @pytest.mark.parametrize("tile", [0, 1, 2, 3], ids=["auto", "tile128", "tile192", "tile64"])
 @pytest.mark.parametrize("M,N,K_", [(300, 200, 192), (788, 3072, 128), (3840, 3072, 64), (130, 64, 64)])
 def test_gemm_nt_dgelu_with_column_sums(K, M, N, K_, tile):
@@ -415,40 +375,26 @@ def test_attention_text_self_mask(K):
     run_attention(K, B=2, Bkv=2, H=4, Lq=40, Lk=40, use_bias=False, use_mask=True, kv_map=None, seed=220)
 
 
-def _attn_variant(K, bits):
-    """x2_tune(8, bits): attention kernel selection bits (csrc/attention.hip attn_variant()), switched inside the process."""
-    import importlib
-    importlib.import_module("x2-vlm_amd._lib").lib().x2_tune(8, bits)
+def test_attention_vision_bias_resident_kernels(K):
+    """The strip-walking resident forward / dQ kernels (one workgroup per (image, head), K / V loaded once; Lk <= 208) and the
+    two-workgroup resident kernels that serve 208 < Lk <= 256, against the same oracle: N = 197 with the relative-position bias (both
+    bias units), a short ragged case (one partial key tile), the full 208 rows the strips hold, and 230 / 256 keys."""
+    run_attention(K, B=3, Bkv=3, H=12, Lq=197, Lk=197, use_bias=True, use_mask=False, kv_map=None, seed=100)
+    run_attention(K, B=3, Bkv=3, H=12, Lq=197, Lk=197, use_bias=True, use_mask=False, kv_map=None, seed=100, bias_log2=True)
+    run_attention(K, B=2, Bkv=2, H=3, Lq=70, Lk=70, use_bias=True, use_mask=True, kv_map=None, seed=110)
+    run_attention(K, B=2, Bkv=2, H=2, Lq=208, Lk=208, use_bias=True, use_mask=False, kv_map=None, seed=120)
+    run_attention(K, B=2, Bkv=2, H=2, Lq=208, Lk=208, use_bias=True, use_mask=False, kv_map=None, seed=120, bias_log2=True)
+    run_attention(K, B=2, Bkv=2, H=2, Lq=230, Lk=230, use_bias=True, use_mask=False, kv_map=None, seed=130)
+    run_attention(K, B=1, Bkv=1, H=3, Lq=256, Lk=256, use_bias=True, use_mask=True, kv_map=None, seed=140)
 
 
-@pytest.mark.parametrize("bits", [0, 4096, 8192, 4096 | 8192], ids=["two_workgroups", "walk_fwd", "walk_dq", "walk_both"])
-def test_attention_vision_bias_strip_walking_variants(K, bits):
-    """The strip-walking resident forward / dQ kernels (one workgroup per (image, head), K / V loaded once; the default) and the
-    two-workgroup resident kernels they replaced (bits 0) against the same oracle: N = 197 with the relative-position bias,
-    a short ragged case (one partial key tile), and the full 208 rows the strips hold."""
-    _attn_variant(K, bits)
-    try:
-        run_attention(K, B=3, Bkv=3, H=12, Lq=197, Lk=197, use_bias=True, use_mask=False, kv_map=None, seed=100)
-        run_attention(K, B=3, Bkv=3, H=12, Lq=197, Lk=197, use_bias=True, use_mask=False, kv_map=None, seed=100, bias_log2=True)
-        run_attention(K, B=2, Bkv=2, H=3, Lq=70, Lk=70, use_bias=True, use_mask=True, kv_map=None, seed=110)
-        run_attention(K, B=2, Bkv=2, H=2, Lq=208, Lk=208, use_bias=True, use_mask=False, kv_map=None, seed=120)
-        run_attention(K, B=2, Bkv=2, H=2, Lq=208, Lk=208, use_bias=True, use_mask=False, kv_map=None, seed=120, bias_log2=True)
-    finally:
-        _attn_variant(K, -1)
-
-
-@pytest.mark.parametrize("bits", [0, 8, 16], ids=["default", "grouped_fwd", "per_row_dq"])
-def test_attention_cross_shared_kv(K, bits):
-    """default = per-row forward + grouped dQ; bit 3 = grouped forward as well; bit 4 = per-row dQ."""
-    _attn_variant(K, bits)
-    try:
-        run_attention(K, B=6, Bkv=3, H=12, Lq=30, Lk=197, use_bias=False, use_mask=True, kv_map=[0, 2, 1, 1, 0, 1], seed=300)
-        run_attention(K, B=4, Bkv=2, H=2, Lq=8, Lk=5, use_bias=False, use_mask=False, kv_map=[1, 0, 1, 1], seed=310)
-        # an image nobody attends to (zero gradient, nothing to do), and more rows per image than one 128-query pass holds
-        run_attention(K, B=4, Bkv=3, H=2, Lq=30, Lk=197, use_bias=False, use_mask=True, kv_map=[0, 2, 2, 0], seed=320)
-        run_attention(K, B=11, Bkv=2, H=3, Lq=30, Lk=70, use_bias=False, use_mask=True, kv_map=[0] * 9 + [1] * 2, seed=330)
-    finally:
-        _attn_variant(K, -1)
+def test_attention_cross_shared_kv(K):
+    """per-row forward + grouped dQ (one workgroup per (image, head) over all the rows sharing that image's K / V)."""
+    run_attention(K, B=6, Bkv=3, H=12, Lq=30, Lk=197, use_bias=False, use_mask=True, kv_map=[0, 2, 1, 1, 0, 1], seed=300)
+    run_attention(K, B=4, Bkv=2, H=2, Lq=8, Lk=5, use_bias=False, use_mask=False, kv_map=[1, 0, 1, 1], seed=310)
+    # an image nobody attends to (zero gradient, nothing to do), and more rows per image than one 128-query pass holds
+    run_attention(K, B=4, Bkv=3, H=2, Lq=30, Lk=197, use_bias=False, use_mask=True, kv_map=[0, 2, 2, 0], seed=320)
+    run_attention(K, B=11, Bkv=2, H=3, Lq=30, Lk=70, use_bias=False, use_mask=True, kv_map=[0] * 9 + [1] * 2, seed=330)
 
 
 def test_attention_long_keys(K):
@@ -486,42 +432,6 @@ def test_layernorm(K, rows, D, period):
     dw2, db2, dcol = torch.zeros(D, device=dev), torch.zeros(D, device=dev), torch.zeros(D, device=dev)
     dx2, _ = K.layernorm_bwd(dy.to(dev), x.to(dev), mean, rstd, w.to(dev), dw2, db2, dcol=dcol, period=period)
     assert relerr(dcol, xl.grad[sel].sum(0)) < 5e-5 and relerr(dx2[sel], xl.grad[sel]) < 2e-5
-
-
-@pytest.mark.parametrize("rows,D,dy_bf16,use_rowscale", [(700, 768, True, True), (333, 1024, True, False), (50, 128, False, True)])
-def test_layernorm_bwd_with_fused_layerscale_bwd(K, rows, D, dy_bf16, use_rowscale):
-    """x2_layernorm_bwd_layerscale == x2_layernorm_bwd followed by x2_layerscale_bwd (same arithmetic in one pass), in both
-    reduction modes: immediate, and deferred with the layer-scale sums registered separately (how the vision backward
-    hands them to the NEXT block's gradient arena)."""
-    x = (rnd(rows, D, seed=1, scale=2.0) + 0.5).to(dev)
-    w = (rnd(D, seed=2) * 0.1 + 1).to(dev)
-    dy = rnd(rows, D, seed=4)
-    dy = (bf(dy) if dy_bf16 else dy).to(dev)
-    dres, u, gamma = rnd(rows, D, seed=5).to(dev), bf(rnd(rows, D, seed=6)).to(dev), rnd(D, seed=7).to(dev)
-    rowscale = ((torch.rand(rows, generator=torch.Generator().manual_seed(8)) > 0.3).float() * 1.25).to(dev) if use_rowscale else None
-    _, _, mean, rstd = K.layernorm_fwd(x, w, torch.zeros(D, device=dev), 1e-6)
-    dw0, db0, dg0, dbias0 = (torch.zeros(D, device=dev) for _ in range(4))
-    dx0, _ = K.layernorm_bwd(dy, x, mean, rstd, w, dw0, db0, dres=dres)
-    du0 = K.layerscale_bwd(dx0, u, gamma, dg0, dbias0, rowscale=rowscale)
-    # immediate reduction
-    dw1, db1, dg1, dbias1 = (torch.zeros(D, device=dev) for _ in range(4))
-    dx1, du1, _ = K.layernorm_bwd_layerscale(dy, x, mean, rstd, w, dw1, db1, dres, u, gamma, dg1, dbias1, rowscale=rowscale)
-    assert torch.equal(dx1, dx0) and relerr(du1, du0.float().cpu()) < 1e-6
-    for a, b_ in ((dw1, dw0), (db1, db0), (dg1, dg0), (dbias1, dbias0)):
-        assert relerr(a, b_.cpu()) < 2e-5
-    # deferred, layer-scale sums registered by the caller
-    dw2, db2, dg2, dbias2 = (torch.zeros(D, device=dev) for _ in range(4))
-    K.DEFERRED = []
-    try:
-        dx2, du2, (ws, nblk) = K.layernorm_bwd_layerscale(dy, x, mean, rstd, w, dw2, db2, dres, u, gamma, rowscale=rowscale)
-        K.DEFERRED.append((ws, nblk, 4, D, (None, None, dg2, dbias2)))
-        items, K.DEFERRED = K.DEFERRED, None
-        K.reduce_partials_multi(items)
-    finally:
-        K.DEFERRED = None
-    assert torch.equal(dx2, dx0) and torch.equal(du2, du1)
-    for a, b_ in ((dw2, dw1), (db2, db1), (dg2, dg1), (dbias2, dbias1)):
-        assert relerr(a, b_.cpu()) < 1e-6
 
 
 def test_colsum_layerscale_casts(K):

@@ -38,7 +38,6 @@ _SIGS = {
     "x2_attn_bwd": [C.POINTER(AttnArgs), P],
     "x2_layernorm_fwd": [P, P, P, P, P, P, P, I, I, F, I, U, U, F, P, P],
     "x2_layernorm_bwd": [P, I, P, P, P, P, P, P, P, P, P, P, I, I, I, U, U, F, U, U, F, P, P, I, P],
-    "x2_layernorm_bwd_layerscale": [P, I, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, P, I, P],
     "x2_colsum_bf16": [P, P, I, I, I, P, I, P],
     "x2_reduce_partials": [P, I, I, I, P, P, P, P],
     "x2_reduce_partials_multi": [P, I, P],

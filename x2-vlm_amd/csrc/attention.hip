@@ -483,116 +483,14 @@ __global__ __launch_bounds__(64 * QW, WPS) void attn_bwd_dq_kernel(AttnArgs a) {
   }
 }
 
-// ------------------------------------------------------------------------------------------ grouped forms (shared K/V)
+// ------------------------------------------------------------------------------------------ grouped form (shared K/V)
 // Cross-attention of the fusion stack: several text rows attend to the same image (the 4-pass batch: ~4 rows per image).
 // One workgroup per (image, head) keeps that image's K / V resident in LDS and walks the concatenated queries of all rows
 // that use it (CSR seq_off / seq_ids), 16 per wave and pass - the image's K / V leave L2 once per head instead of once
 // per text row, and the 30-query rows fill 8-wave workgroups.  The batch index is per lane (rows of different sequences
-// share a wave).
-template <int QW>
-__global__ __launch_bounds__(64 * QW) void attn_fwd_grouped_kernel(AttnArgs a) {
-  const DropSpec drop_ = drop_at_epoch(a.drop, a.drop_epoch);
-  constexpr int NT = 64 * QW;
-  __shared__ __attribute__((aligned(16))) char smem[4][2 * KT * 128];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int fi = lane & 15, g = lane >> 4;
-  const int h = blockIdx.y, bk = blockIdx.z;
-  const int sb = a.seq_off[bk], nrows = (a.seq_off[bk + 1] - sb) * a.Lq;
-  if (nrows == 0) return;
-  const bf16_t* Kp = a.K + bk * a.k_bs + h * HD;
-  const bf16_t* Vp = a.V + bk * a.v_bs + h * HD;
-  const float sc2 = a.scale * LOG2E;
-  const int lkp = (a.Lk + 63) & ~63;
-  const int nkt = (a.Lk + KT - 1) / KT;
-  {
-    TileRegs<NT> rka[4], rva[4];
-#pragma unroll
-    for (int kt = 0; kt < 4; ++kt)
-      if (kt < nkt) { tile_load<NT>(rka[kt], Kp, a.k_rs, kt * KT, a.Lk, tid); tile_load<NT>(rva[kt], Vp, a.v_rs, kt * KT, a.Lk, tid); }
-#pragma unroll
-    for (int kt = 0; kt < 4; ++kt)
-      if (kt < nkt) { tile_store<NT>(rka[kt], smem[kt], tid); tile_store<NT>(rva[kt], smem[kt] + KT * 128, tid); }
-  }
-  __syncthreads();
-  for (int base = wave * 16; base < nrows; base += QW * 16) {        // no barrier below: waves run on their own
-    const bool qok = base + fi < nrows;
-    const int v = min(base + fi, nrows - 1), sq = v / a.Lq, q = v - sq * a.Lq;
-    const int b = a.seq_ids[sb + sq];
-    bf16x8 qf[2];
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-      qf[ks] = *reinterpret_cast<const bf16x8*>(a.Q + b * a.q_bs + (long)q * a.q_rs + h * HD + ks * 32 + g * 8);
-    f32x4 o[4];
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float m_i = NEG_BIG, l_i = 0.f;
-    for (int kt = 0; kt < nkt; ++kt) {
-      const uint32_t ktile = lds_addr(smem[kt]), vtile = ktile + KT * 128;
-      const int nsub = min(4, (a.Lk - kt * KT + 15) >> 4);
-      float4 mm[4];
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt)
-        mm[nt] = (a.mask && nt < nsub) ? *reinterpret_cast<const float4*>(a.mask + (long)b * a.mask_ld + kt * KT + nt * 16 + g * 4)
-                                       : float4{0.f, 0.f, 0.f, 0.f};
-      f32x4 st[4];
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt) st[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-          if (nt >= nsub) continue;
-          st[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(ktile, nt * 16 + fi, ks * 4 + g), qf[ks], st[nt], 0, 0, 0);
-        }
-      float mx = NEG_BIG;
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt) {
-        if (nt >= nsub) continue;
-        st[nt] = apply_bias_mask(st[nt], float4{0.f, 0.f, 0.f, 0.f}, mm[nt], kt * KT + nt * 16 + g * 4, a.Lk, sc2);
-        mx = fmaxf(fmaxf(mx, fmaxf(st[nt][0], st[nt][1])), fmaxf(st[nt][2], st[nt][3]));
-      }
-      mx = group_max(mx);
-      const float m_new = fmaxf(m_i, mx), alpha = fast_exp2(m_i - m_new);
-      float rs = 0.f;
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt) {
-        if (nt >= nsub) continue;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { st[nt][r] = fast_exp2(st[nt][r] - m_new); rs += st[nt][r]; }
-      }
-      l_i = l_i * alpha + group_sum(rs);
-      m_i = m_new;
-      if (drop_.thr16) {
-        const uint32_t e0 = (uint32_t)(((long)b * a.H + h) * a.Lq + q) * (uint32_t)lkp + (uint32_t)(kt * KT + g * 4);
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-          if (nt >= nsub) continue;
-          float dm[4];
-          drop_mul4(drop_, e0 + nt * 16, dm);
-          st[nt][0] *= dm[0]; st[nt][1] *= dm[1]; st[nt][2] *= dm[2]; st[nt][3] *= dm[3];
-        }
-      }
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt) o[dt] *= alpha;
-      const bf16x8 pf[2] = {pack8(st[0], st[1]), pack8(st[2], st[3])};
-#pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-          if (2 * s2 >= nsub) continue;
-          o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_cols(vtile, s2, dt, lane), pf[s2], o[dt], 0, 0, 0);
-        }
-    }
-    if (qok) {
-      const float inv = 1.0f / l_i;
-      bf16_t* op = a.Out + b * a.o_bs + (long)q * a.o_rs + h * HD + g * 4;
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt)
-        *reinterpret_cast<u32x2*>(op + dt * 16) = u32x2{pack_bf16(o[dt][0] * inv, o[dt][1] * inv), pack_bf16(o[dt][2] * inv, o[dt][3] * inv)};
-      if (g == 0) a.LSE[((long)b * a.H + h) * a.Lq + q] = m_i + log2f(l_i);
-    }
-  }
-}
+// share a wave).  Backward (dQ) only: the forward twin of this kernel was 62 vs 68 us in isolation but slower in the step -
+// round 2: -3 % with three streams; round 4, tail segment alone on the GPU: 23.63-23.70 vs 23.42 ms per base step
+// (profiles/r05i_knob_ab.txt) - and was removed.
 
 template <int QW>
 __global__ __launch_bounds__(64 * QW, 32 / QW) void attn_bwd_dq_grouped_kernel(AttnArgs a) {
@@ -1121,31 +1019,15 @@ __global__ __launch_bounds__(64 * KW, WPS) void attn_bwd_dkv_kernel(AttnArgs a) 
 // ------------------------------------------------------------------------------------------ C ABI
 // `args` is the AttnArgs struct laid out as 8-byte slots (pointers, longs) followed by ints/floats;
 // the Python side fills it through ctypes.Structure with the same field order.
-// experiment switch (probes/bench_attn.py): X2_ATTN_VARIANT bit 0: dkv back to 4 waves per workgroup,
-// bit 1: dq with 2 query groups per wave, bit 2: fwd with 2 query groups per wave,
-// bit 3: grouped (shared K/V) forward kernel for cross-attention; bit 4: per-row dQ kernel instead of the grouped one.  Measured on the
-// fusion shapes (256 rows on 64 images): 62 vs 68 us forward, 132 vs 147 us backward in isolation, but -3 % on the whole
-// step (64 KB workgroups co-reside worse with the other streams' kernels), so off by default;
-// bit 12 (4096) / bit 13 (8192): strip-walking resident forward / dQ kernels (the default; see their header);
-// bit 14 (16384): bias kernels on the plain 3-D grid instead of the XCD-aware 1-D order (attn_block);
-// bit 15 (32768): the 8-wave streaming / resident-dK/dV kernels compiled for 2 waves per SIMD (256 VGPRs) instead of 4 (128)
-// x2_tune(8, v) (gemm.hip) overrides the environment at run time: tests and probes A/B variants inside one process
-int x2_attn_variant_override = -1;
-static int attn_variant() {
-  static int v = -1;
-  if (x2_attn_variant_override >= 0) return x2_attn_variant_override;
-  // default: the strip-walking forward and dQ kernels at N <= 208 (measured on [64, 12, 197]: forward 47.3 -> 45.6 us, dQ + dK/dV
-  // 128.1 -> 118.8 us, profiles/r03a_attn_walk_ab.txt)
-  if (v < 0) { const char* e = getenv("X2_ATTN_VARIANT"); v = e ? atoi(e) : (4096 | 8192); }
-  return v;
-}
-
+// Kernel selection is fixed (round 4 pruned the run-time variant bits; what they measured is in DESIGN section 5.1 / 5.3): strip-walking
+// resident forward / dQ kernels at Lk <= WALK_ROWS, two-workgroup resident kernels up to 256 keys, 8-wave streaming kernels
+// beyond, per-row forward + grouped dQ for rows that share K/V, XCD-aware block order for the kernels that read a bias.
 // Launch `kernel` over the logical grid (nx tiles, ny heads, nz batches): as a 3-D grid, or - xmap, the kernels that read a
-// relative-position bias - as the 1-D XCD-aware grid attn_block() decodes (x2_tune(8) bit 14 = 16384 switches it off).
+// relative-position bias - as the 1-D XCD-aware grid attn_block() decodes.
 template <typename Kern>
 static void attn_launch(Kern kernel, AttnArgs a, int nx, int ny, int nz, int threads, bool xmap, hipStream_t st) {
   a.grid_nx = nx; a.grid_ny = ny; a.grid_nz = nz; a.grid_map = 0;
-  if (xmap && !(attn_variant() & 16384)) {
+  if (xmap) {
     int C = 1;
     while (C < 8 && (ny * C) % 8 != 0) C *= 2;        // batch chunks per head: (head, chunk) units divide evenly over 8 XCDs
     if (C > nz) C = 1;
@@ -1178,21 +1060,13 @@ extern "C" int x2_attn_fwd(const AttnArgs* pa, void* stream) {
   // long query side and <= 4 key tiles: 8-wave workgroups with K/V resident in LDS (64 KB); otherwise key tiles are
   // streamed through a double buffer (short query side: the 64 KB would leave 2 waves / workgroup alone on a CU)
   X2_REQUIRE(!a.seq_off || (a.seq_ids && a.Bkv > 0), "x2_attn_fwd: seq_off needs seq_ids and Bkv");
-  if (a.seq_off && a.Lk <= 256 && !a.bias && (attn_variant() & 8))       // rows sharing K/V: one workgroup per (K/V batch, head)
-    hipLaunchKernelGGL((attn_fwd_grouped_kernel<8>), dim3(1, a.H, a.Bkv), dim3(512), 0, st, a);
-  else if (a.Lq <= 32 && a.Lk <= 64) hipLaunchKernelGGL((attn_fwd_kernel<2, 1, true, 1>), dim3(1, a.H, a.B), dim3(128), 0, st, a);
+  if (a.Lq <= 32 && a.Lk <= 64) hipLaunchKernelGGL((attn_fwd_kernel<2, 1, true, 1>), dim3(1, a.H, a.B), dim3(128), 0, st, a);
   else if (a.Lq <= 32) hipLaunchKernelGGL((attn_fwd_kernel<2, 1, false>), dim3(1, a.H, a.B), dim3(128), 0, st, a);
-  else if (a.Lk > 256 && a.Lq > 64 && (attn_variant() & 256))
-    hipLaunchKernelGGL((attn_fwd_kernel<8, 2, false>), dim3((a.Lq + 255) / 256, a.H, a.B), dim3(512), 0, st, a);
-  else if (a.Lk > 256 && a.Lq > 64 && (attn_variant() & 1024))
-    hipLaunchKernelGGL((attn_fwd_kernel<4, 2, false>), dim3((a.Lq + 127) / 128, a.H, a.B), dim3(256), 0, st, a);
-  else if (a.Lk > 256 && a.Lq > 64 && !(attn_variant() & 32))      // long sequences (X2VLM-large, N = 577): 8 waves share each streamed K/V tile (285 -> 254 us)
-    { if (attn_variant() & 32768) attn_launch(attn_fwd_kernel<8, 1, false, 2, 2>, a, (a.Lq + 127) / 128, a.H, a.B, 512, xm, st);
-      else if (bl2) attn_launch(attn_fwd_kernel<8, 1, false, 2, 4, true>, a, (a.Lq + 127) / 128, a.H, a.B, 512, xm, st);
+  else if (a.Lk > 256 && a.Lq > 64)      // long sequences (X2VLM-large, N = 577): 8 waves share each streamed K/V tile (285 -> 254 us)
+    { if (bl2) attn_launch(attn_fwd_kernel<8, 1, false, 2, 4, true>, a, (a.Lq + 127) / 128, a.H, a.B, 512, xm, st);
       else attn_launch(attn_fwd_kernel<8, 1, false>, a, (a.Lq + 127) / 128, a.H, a.B, 512, xm, st); }
   else if (a.Lq <= 64 || a.Lk > 256) hipLaunchKernelGGL((attn_fwd_kernel<4, 1, false>), dim3((a.Lq + 63) / 64, a.H, a.B), dim3(256), 0, st, a);
-  else if (attn_variant() & 4) hipLaunchKernelGGL((attn_fwd_kernel<4, 2, true>), dim3((a.Lq + 127) / 128, a.H, a.B), dim3(256), 0, st, a);
-  else if ((attn_variant() & 4096) && !a.kv_idx && a.Lk <= WALK_ROWS)      // staged: one strip-walking workgroup per (sequence, head)
+  else if (!a.kv_idx && a.Lk <= WALK_ROWS)      // staged: one strip-walking workgroup per (sequence, head)
     { if (bl2) attn_launch(attn_fwd_walk_kernel<4, true>, a, 1, a.H, a.B, 256, xm, st);
       else attn_launch(attn_fwd_walk_kernel<4>, a, 1, a.H, a.B, 256, xm, st); }
   else attn_launch(attn_fwd_kernel<8, 1, true>, a, (a.Lq + 127) / 128, a.H, a.B, 512, xm, st);
@@ -1211,21 +1085,15 @@ extern "C" int x2_attn_bwd(const AttnArgs* pa, void* stream) {
   X2_REQUIRE((a.kv_idx == nullptr) == (a.seq_off == nullptr), "x2_attn_bwd: kv_idx and seq_off/seq_ids come together");
   X2_REQUIRE(a.Bkv > 0, "x2_attn_bwd: Bkv");
   const hipStream_t st = (hipStream_t)stream;
-  if (a.seq_off && a.Lk <= 256 && !a.bias && !a.dS && !(attn_variant() & 16))
+  if (a.seq_off && a.Lk <= 256 && !a.bias && !a.dS)      // rows sharing K/V: one workgroup per (K/V batch, head)
     hipLaunchKernelGGL((attn_bwd_dq_grouped_kernel<8>), dim3(1, a.H, a.Bkv), dim3(512), 0, st, a);
   else if (a.Lq <= 32 && a.Lk <= 64) hipLaunchKernelGGL((attn_bwd_dq_kernel<2, 1, true, 1>), dim3(1, a.H, a.B), dim3(128), 0, st, a);
   else if (a.Lq <= 32) hipLaunchKernelGGL((attn_bwd_dq_kernel<2, 1, false>), dim3(1, a.H, a.B), dim3(128), 0, st, a);
-  else if (a.Lk > 256 && a.Lq > 64 && (attn_variant() & 512))
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<8, 2, false>), dim3((a.Lq + 255) / 256, a.H, a.B), dim3(512), 0, st, a);
-  else if (a.Lk > 256 && a.Lq > 64 && (attn_variant() & 2048))
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<4, 2, false>), dim3((a.Lq + 127) / 128, a.H, a.B), dim3(256), 0, st, a);
-  else if (a.Lk > 256 && a.Lq > 64 && !(attn_variant() & 64))      // N = 577: dQ + dK/dV 810 -> 652 us with 8-wave workgroups
-    { if (attn_variant() & 32768) attn_launch(attn_bwd_dq_kernel<8, 1, false, 2, 2>, a, (a.Lq + 127) / 128, a.H, a.B, 512, xm, st);
-      else if (bl2) attn_launch(attn_bwd_dq_kernel<8, 1, false, 2, 4, true>, a, (a.Lq + 127) / 128, a.H, a.B, 512, xm, st);
+  else if (a.Lk > 256 && a.Lq > 64)      // N = 577: dQ + dK/dV 810 -> 652 us with 8-wave workgroups
+    { if (bl2) attn_launch(attn_bwd_dq_kernel<8, 1, false, 2, 4, true>, a, (a.Lq + 127) / 128, a.H, a.B, 512, xm, st);
       else attn_launch(attn_bwd_dq_kernel<8, 1, false>, a, (a.Lq + 127) / 128, a.H, a.B, 512, xm, st); }
   else if (a.Lq <= 64 || a.Lk > 256) hipLaunchKernelGGL((attn_bwd_dq_kernel<4, 1, false>), dim3((a.Lq + 63) / 64, a.H, a.B), dim3(256), 0, st, a);
-  else if (attn_variant() & 2) hipLaunchKernelGGL((attn_bwd_dq_kernel<4, 2, true>), dim3((a.Lq + 127) / 128, a.H, a.B), dim3(256), 0, st, a);
-  else if ((attn_variant() & 8192) && !a.kv_idx && a.Lk <= WALK_ROWS)
+  else if (!a.kv_idx && a.Lk <= WALK_ROWS)
     { if (bl2) attn_launch(attn_bwd_dq_walk_kernel<4, true>, a, 1, a.H, a.B, 256, xm, st);
       else attn_launch(attn_bwd_dq_walk_kernel<4>, a, 1, a.H, a.B, 256, xm, st); }
   else attn_launch(attn_bwd_dq_kernel<8, 1, true>, a, (a.Lq + 127) / 128, a.H, a.B, 512, xm, st);
@@ -1235,17 +1103,13 @@ extern "C" int x2_attn_bwd(const AttnArgs* pa, void* stream) {
     hipLaunchKernelGGL((attn_bwd_dkv_kernel<2, 1, true, 1>), dim3(1, a.H, a.Bkv), dim3(128), 0, st, a);
   } else if (a.Lk <= 32) {
     hipLaunchKernelGGL((attn_bwd_dkv_kernel<2, 1, false>), dim3(1, a.H, a.Bkv), dim3(128), 0, st, a);
-  } else if (res && !(attn_variant() & 1)) {
-    // 8 waves (128 keys) share the resident Q / dO image (133 KB: one workgroup per CU either way): 206 -> 189 us per
-    // vision layer against 4-wave workgroups, which left 4 waves on a CU (probes/bench_attn.py)
-    if (attn_variant() & 32768) attn_launch(attn_bwd_dkv_kernel<8, 1, true, 4, 2>, a, (a.Lk + 127) / 128, a.H, a.Bkv, 512, xmT, st);
-    else if (bl2) attn_launch(attn_bwd_dkv_kernel<8, 1, true, 4, 4, true>, a, (a.Lk + 127) / 128, a.H, a.Bkv, 512, xmT, st);
-    else attn_launch(attn_bwd_dkv_kernel<8, 1, true>, a, (a.Lk + 127) / 128, a.H, a.Bkv, 512, xmT, st);
   } else if (res) {
-    hipLaunchKernelGGL((attn_bwd_dkv_kernel<4, 1, true>), dim3((a.Lk + 63) / 64, a.H, a.Bkv), dim3(256), 0, st, a);
-  } else if (a.Lk > 256 && !a.seq_off && !(attn_variant() & 128)) {
-    if (attn_variant() & 32768) attn_launch(attn_bwd_dkv_kernel<8, 1, false, 2, 2>, a, (a.Lk + 127) / 128, a.H, a.Bkv, 512, xmT, st);
-    else if (bl2) attn_launch(attn_bwd_dkv_kernel<8, 1, false, 2, 4, true>, a, (a.Lk + 127) / 128, a.H, a.Bkv, 512, xmT, st);
+    // 8 waves (128 keys) share the resident Q / dO image (133 KB: one workgroup per CU either way): 206 -> 189 us per
+    // vision layer against 4-wave workgroups, which left 4 waves on a CU
+    if (bl2) attn_launch(attn_bwd_dkv_kernel<8, 1, true, 4, 4, true>, a, (a.Lk + 127) / 128, a.H, a.Bkv, 512, xmT, st);
+    else attn_launch(attn_bwd_dkv_kernel<8, 1, true>, a, (a.Lk + 127) / 128, a.H, a.Bkv, 512, xmT, st);
+  } else if (a.Lk > 256 && !a.seq_off) {
+    if (bl2) attn_launch(attn_bwd_dkv_kernel<8, 1, false, 2, 4, true>, a, (a.Lk + 127) / 128, a.H, a.Bkv, 512, xmT, st);
     else attn_launch(attn_bwd_dkv_kernel<8, 1, false>, a, (a.Lk + 127) / 128, a.H, a.Bkv, 512, xmT, st);
   } else {
     hipLaunchKernelGGL((attn_bwd_dkv_kernel<4, 1, false>), dim3((a.Lk + 63) / 64, a.H, a.Bkv), dim3(256), 0, st, a);

@@ -34,8 +34,7 @@ struct GemmNT {
   const uint32_t* drop_epoch;  // device step counter mixed into drop.seed, or NULL (x2_common.h drop_at_epoch)
   const float* rowscale;    // [M] per-row factor before the residual add: DropPath keep/(1-p) per sample (beit2.py:206-207)
   float* colsum;            // [N] += column sums of the stored C (bias gradient of the layer below, fused)
-  int dbg;                  // ablation switches for probes/bench_gemm.py: 4 = no epilogue, 16 = sc1 output stores
-  int stagger;              // experiment: odd workgroups start `stagger` x 4 us late (de-phases the two workgroups of a CU)
+  int dbg;                  // ablation switches for probes: 4 = no epilogue, 16 = sc1 output stores
   int ksplit;               // split-contraction launches (epilogue variant 7): columns of A / B per blockIdx.y slice
   // fused MLM cross-entropy (epilogue variants 8 / 9, x2_mlm_ce_fwd / _bwd): the logits never leave the accumulators
   const long* ce_labels;    // [M] target column or < 0 (ignored row)
@@ -385,19 +384,6 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNT p) {
   const uint32_t offB = (uint32_t)(A_BYTES + (wn * 64 + frow) * 128);
 
   const int nk = p.K / BK;
-  // The two workgroups of a CU are dispatched together and take equally long, so they stay in phase for the whole
-  // kernel: both in the L2-bound main loop, then both in the HBM-write-bound epilogue.  Delaying the second-slot
-  // workgroups of the FIRST round once (workgroups 256..511) de-phases every later round.
-  // stagger & 256: "spread" form, unit 0.43 us: the first 512 workgroups start in eight phases - the two slots of a CU half
-  // a period apart, neighbouring CUs of an XCD a quarter - so that the chip's main loops (L2 reads) and epilogues (HBM
-  // writes) are spread over time from the first round on.
-  if (p.stagger & 256) {
-    if (blockIdx.x < 512) {
-      const int n = ((((int)blockIdx.x >> 3) & 3) * 2 + (((int)blockIdx.x >> 8) & 1) * 4) * (p.stagger & 255);
-      for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(16);
-    }
-  } else if (p.stagger && blockIdx.x >= 256 && blockIdx.x < 512)
-    for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(127);
   // Software pipeline (one barrier per K-step, placed in the MIDDLE of the step):
   //   fragments of k-half 1 are requested before the MFMAs of k-half 0 are issued, and the fragments of the NEXT
   //   tile's k-half 0 before the MFMAs of k-half 1, so every LDS read has 4*TM MFMAs (>= 256 cycles) to land behind;
@@ -460,87 +446,6 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNT p) {
   }
   if (p.dbg & 4) { if (acc[0][0][0] == 12345.678f) reinterpret_cast<float*>(p.C)[0] = acc[1][1][1] + acc[2][2][2] + acc[3][3][3]; return; }
   nt_epilogue<TM, VAR>(p, acc, smem, wave, lane, m0 + wm * 16 * TM, n0 + wn * 64, tm * 2 + wm);
-}
-
-// ---------------------------------------------------------------------------------------------
-// NT, large tile: 256x128 output tile, 512 threads (8 waves as 4x2, same 64x64 per-wave code), 3-deep LDS ring
-// (3 x 48 KB): tile kt+2 is requested while tile kt is multiplied, the wait in front of each barrier is a
-// COUNTED s_waitcnt vmcnt(6) (the six LDS-DMA instructions of tile kt+1 stay in flight across the barrier), so
-// the prefetch distance is two K-steps instead of one.  25 % less operand traffic per FLOP than 128x128.
-// ---------------------------------------------------------------------------------------------
-#define W8_STAGE_BYTES (48 * 1024)
-#define W8_LDS_BYTES (3 * W8_STAGE_BYTES)
-__global__ __launch_bounds__(512, 2) void gemm_nt_w8_kernel(GemmNT p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
-  const int tiles_n = (p.N + 127) / 128, tiles_m = (p.M + 255) / 256;
-  int tm, tn;
-  tile_coords(xcd_remap(blockIdx.x, gridDim.x), tiles_m, tiles_n, p.group_m, tm, tn);
-  const int m0 = tm * 256, n0 = tn * 128;
-
-  const bf16_t* srcA[4]; const bf16_t* srcB[2];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int q = i * 512 + tid, row = q >> 3, c = (q & 7) ^ (row & 7);
-    int ra = m0 + row; ra = ra < p.M ? ra : p.M - 1;
-    srcA[i] = p.A + (size_t)ra * p.lda + c * 8;
-  }
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int q = i * 512 + tid, row = q >> 3, c = (q & 7) ^ (row & 7);
-    int rb = n0 + row; rb = rb < p.N ? rb : p.N - 1;
-    srcB[i] = p.B + (size_t)rb * p.ldb + c * 8;
-  }
-  auto stage = [&](int kt, int buf) {
-    char* base = smem + buf * W8_STAGE_BYTES;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) glds16(srcA[i] + (size_t)kt * BK, base + (i * 512 + wave * 64) * 16);
-#pragma unroll
-    for (int i = 0; i < 2; ++i) glds16(srcB[i] + (size_t)kt * BK, base + 32768 + (i * 512 + wave * 64) * 16);
-  };
-
-  f32x4 acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  const uint32_t lds0 = lds_addr(smem);
-  const int frow = lane & 15, fg = lane >> 4, fsw = lane & 7;
-  const uint32_t offA = (uint32_t)((wm * 64 + frow) * 128);
-  const uint32_t offB = (uint32_t)(32768 + (wn * 64 + frow) * 128);
-
-  const int nk = p.K / BK;
-  stage(0, 0);
-  if (nk > 1) stage(1, 1);
-  int buf = 0;
-  for (int kt = 0; kt < nk; ++kt) {
-    // tile kt must have landed; tile kt+1 (6 LDS-DMA instructions per thread) may stay in flight
-    if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-    // every wave has passed the barrier => compute(kt-1) is finished => ring slot (kt+2) % 3 is free
-    if (kt + 2 < nk) stage(kt + 2, buf >= 1 ? buf - 1 : 2);
-    const uint32_t sb = lds0 + buf * W8_STAGE_BYTES;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const uint32_t cs = (uint32_t)(((ks * 4 + fg) ^ fsw) << 4);
-      bf16x8 a[4], b[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) a[i] = lds_read_b128(sb + offA + i * 2048 + cs);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) b[j] = lds_read_b128(sb + offB + j * 2048 + cs);
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
-    }
-    buf = buf == 2 ? 0 : buf + 1;
-  }
-  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // every wave is done reading operand tiles
-  nt_epilogue<4, 4>(p, acc, smem, wave, lane, m0 + wm * 64, n0 + wn * 64);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -687,16 +592,14 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmNT p) {
   nt_epilogue<TMW, VAR>(p, acc, smem, wave, lane, m0 + wr * HROWS, n0 + wc * 64);
 }
 
-// knobs for A/B measurements and for the tests that pin a kernel variant (0 = automatic everywhere); [7] 1: no 160x128 NT tiles
-//   [0] GROUP_M of the NT tile raster            [1] 0: automatic, 1: 128-column kernels only, 2: the 8-wave 256x128 kernel, 3: always the 256-column kernel
-//   [2] NT ablation bits (4 no epilogue, 16 sc1 stores, 64 row-contiguous fp32 stores)          [6] 1: always the generic (run-time flags) NT epilogue
-//   [3] NT tile: 1 = 128x128, 2 = 192x128, 3 = 64x128, 4 = 160x128; 5..8 = rows / 32 of the 256-column kernel        [4] NT start stagger (x 4 us; | 256: eight start phases, x 0.43 us)
+// knobs for A/B measurements and for the tests that pin a kernel variant (0 = automatic everywhere)
+//   [0] GROUP_M of the NT tile raster            [1] 0: automatic, 1: 128-column kernels only, 3: always the 256-column kernel
+//   [2] NT ablation bits (4 no epilogue, 16 sc1 stores)          [6] 1: always the generic (run-time flags) NT epilogue
+//   [3] NT tile: 1 = 128x128, 2 = 192x128, 3 = 64x128, 4 = 160x128; 5..8 = rows / 32 of the 256-column kernel        [7] 1: no 160x128 NT tiles
 //   [5] TN: 1 = always 128x128 tiles, 2 = 256x256 tiles whenever the contraction lengths allow
-//   [8] attention kernel variant bits (attention.hip attn_variant(); -1 = back to the X2_ATTN_VARIANT environment value)
-//   [9] percent of perfect CU fill the 256-column NT kernel's plan must reach to be chosen when [1] = 4 (0 = 80)
+//   [9] percent of perfect CU fill the 256-column NT kernel's plan must reach to be chosen automatically (0 = 80)
 static int g_tune[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-static int g_tune_x[4] = {0, 0, 0, 0};          // keys 8.. : [0] unused here (attention variant lives in attention.hip), [1] = key 9
-extern int x2_attn_variant_override;
+static int g_tune_x[4] = {0, 0, 0, 0};          // keys 8.. : [1] = key 9
 extern "C" int x2_device_cus(void);
 // compute units of the current device (256 on MI355X), asked once: grid-fill decisions below are made in units of it
 static int x2_cus() {
@@ -705,7 +608,6 @@ static int x2_cus() {
   return n;
 }
 extern "C" int x2_tune(int key, int value) {
-  if (key == 8) { x2_attn_variant_override = value; return X2_OK; }
   if (key >= 9 && key < 12) { g_tune_x[key - 8] = value; return X2_OK; }
   if (key < 0 || key >= 8) return X2_ERR_ARG;
   g_tune[key] = value;
@@ -771,12 +673,7 @@ extern "C" int x2_gemm_nt(const void* A, const void* B, void* C, int M, int N, i
   X2_REQUIRE(act == 0 || aux, "x2_gemm_nt: act=%d needs aux", act);
   X2_REQUIRE((!resid || ldr % 4 == 0) && (!aux || ldaux % 8 == 0), "x2_gemm_nt: ldr/ldaux alignment");
   GemmNT p{(const bf16_t*)A, (const bf16_t*)B, C, bias, gamma, resid, (bf16_t*)aux, M, N, K, lda, ldb, ldc, ldr, ldaux, act, out_f32,
-           g_tune[0] > 0 ? g_tune[0] : 8, DropSpec{drop_thr16, drop_seed, drop_scale}, drop_epoch, rowscale, colsum, g_tune[2], g_tune[4], 0};
-  // tile choice: [1] = 0 auto, 1 force 128x128 (4 waves), 2 force 256x128 (8 waves, 3-deep ring)
-  const int tiles8 = ((M + 255) / 256) * ((N + 127) / 128);
-  // measured (probes/bench_gemm.py): two independent 4-wave workgroups per CU beat one 8-wave workgroup with a
-  // 3-deep ring on every shape of this model (676 vs 583 TFLOP/s on 12608x2304x768), so auto = 128x128
-  const bool big = g_tune[1] == 2;
+           g_tune[0] > 0 ? g_tune[0] : 8, DropSpec{drop_thr16, drop_seed, drop_scale}, drop_epoch, rowscale, colsum, g_tune[2], 0};
   // epilogue variant (EpiTraits): the feature sets the step uses are compiled separately, anything else runs the generic one
   int var = 4;
   {
@@ -801,7 +698,6 @@ extern "C" int x2_gemm_nt(const void* A, const void* B, void* C, int M, int N, i
   const bool auto256 = (light || K >= 2048) && eff256 * 100.0 >= (g_tune_x[1] > 0 ? g_tune_x[1] : 80) && !(resid && M < 8192);
   const bool use256 = var != 4 && N % 8 == 0 && (g_tune[1] == 3 || ((g_tune[1] == 0 || g_tune[1] == 4) && g_tune[3] == 0 && auto256));
   if (use256) {
-    p.dbg &= ~64;
     switch (var) {
       case 0: launch_nt256_h<0>(p, tmw, (hipStream_t)stream); break;
       case 1: launch_nt256_h<1>(p, tmw, (hipStream_t)stream); break;
@@ -810,13 +706,6 @@ extern "C" int x2_gemm_nt(const void* A, const void* B, void* C, int M, int N, i
       case 5: launch_nt256_h<5>(p, tmw, (hipStream_t)stream); break;
       default: launch_nt256_h<6>(p, tmw, (hipStream_t)stream); break;
     }
-  } else if (big) {
-    static bool attr_set = false;
-    if (!attr_set) {
-      hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_w8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, W8_LDS_BYTES);
-      attr_set = true;
-    }
-    hipLaunchKernelGGL(gemm_nt_w8_kernel, dim3(tiles8), dim3(512), W8_LDS_BYTES, (hipStream_t)stream, p);
   } else {
     // 192x128 tiles when that gives a single resident round (<= 2 workgroups per CU) where 128x128 needs a second,
     // nearly empty one: the N = 768 outputs of this model (66 x 6 = 396 tiles vs 99 x 6 = 594 on 512 slots).
@@ -837,8 +726,8 @@ extern "C" int x2_gemm_nt(const void* A, const void* B, void* C, int M, int N, i
     // (balanced would be 148): x2_tune(7, 1) switches the rule off
     const int t160 = ((M + 159) / 160) * ((N + BN - 1) / BN);
     const bool use160 = g_tune[3] == 4 || (use192 && g_tune[3] == 0 && g_tune[7] != 1 && t160 <= slots);
-    // [2] & 64: row-contiguous stores for the fp32-out feature sets (nt_epilogue_f4)
-    const bool f4 = (g_tune[2] & 64) != 0 && (var == 1 || var == 5 || var == 6);
+    // fp32-out feature sets (1, 5, 6) store row-contiguously (nt_epilogue_f4: in-step A/B 23.33-23.38 vs 23.42-23.43 ms per base step,
+    // profiles/r05i_knob_ab.txt - the 8-columns-per-lane form of these three sets was removed in round 4)
 #define X2_NT_LAUNCH(V, SW)                                                                          \
     do {                                                                                              \
       if (use64) launch_nt<2, V, SW>(p, t64, (hipStream_t)stream);                                    \
@@ -846,15 +735,15 @@ extern "C" int x2_gemm_nt(const void* A, const void* B, void* C, int M, int N, i
       else if (use192) launch_nt<6, V, SW>(p, t192, (hipStream_t)stream);                             \
       else launch_nt<4, V, SW>(p, t128, (hipStream_t)stream);                                         \
     } while (0)
-#define X2_NT_CASE(V) case V: if (f4) X2_NT_LAUNCH(V, true); else X2_NT_LAUNCH(V, false); break
     switch (var) {
       case 0: X2_NT_LAUNCH(0, false); break;
       case 2: X2_NT_LAUNCH(2, false); break;
       case 3: X2_NT_LAUNCH(3, false); break;
-      X2_NT_CASE(1); X2_NT_CASE(5); X2_NT_CASE(6);
+      case 1: X2_NT_LAUNCH(1, true); break;
+      case 5: X2_NT_LAUNCH(5, true); break;
+      case 6: X2_NT_LAUNCH(6, true); break;
       default: X2_NT_LAUNCH(4, false); break;
     }
-#undef X2_NT_CASE
 #undef X2_NT_LAUNCH
   }
   return x2_check_launch("x2_gemm_nt");
@@ -870,7 +759,7 @@ extern "C" int x2_gemm_nt_dgelu_colparts(const void* A, const void* B, void* C, 
   X2_REQUIRE(M > 0 && N > 0 && K > 0 && K % BK == 0 && N % 8 == 0, "x2_gemm_nt_dgelu_colparts: M=%d N=%d K=%d", M, N, K);
   X2_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && ldc % 8 == 0 && ldaux % 8 == 0, "x2_gemm_nt_dgelu_colparts: leading dims must keep 16-byte rows");
   GemmNT p{(const bf16_t*)A, (const bf16_t*)B, C, nullptr, nullptr, nullptr, (bf16_t*)aux, M, N, K, lda, ldb, ldc, 0, ldaux, 2, 0,
-           g_tune[0] > 0 ? g_tune[0] : 8, DropSpec{0u, 0u, 1.f}, nullptr, nullptr, colparts, 0, 0, 0};
+           g_tune[0] > 0 ? g_tune[0] : 8, DropSpec{0u, 0u, 1.f}, nullptr, nullptr, colparts, 0, 0};
   // the tile rule of x2_gemm_nt for this feature set (never the 160-row tile: it exists to balance N = 768 outputs)
   const int tiles_n = (N + BN - 1) / BN, t128 = ((M + 127) / 128) * tiles_n, t192 = ((M + 191) / 192) * tiles_n, t64 = ((M + 63) / 64) * tiles_n;
   const int slots = 2 * x2_cus();
@@ -919,7 +808,7 @@ extern "C" int x2_gemm_nt_splitk(const void* A, const void* B, float* C, int M, 
   const int steps = (nk + S - 1) / S;                             // contraction steps per slice; the last slice may be shorter
   S = (nk + steps - 1) / steps;                                   // no empty slice
   GemmNT p{(const bf16_t*)A, (const bf16_t*)B, S > 1 ? (void*)ws : (void*)C, nullptr, nullptr, nullptr, nullptr, M, N, K, lda, ldb,
-           S > 1 ? N : ldc, 0, 0, 0, 1, g_tune[0] > 0 ? g_tune[0] : 8, DropSpec{0u, 0u, 1.f}, nullptr, nullptr, nullptr, 0, 0, steps * BK};
+           S > 1 ? N : ldc, 0, 0, 0, 1, g_tune[0] > 0 ? g_tune[0] : 8, DropSpec{0u, 0u, 1.f}, nullptr, nullptr, nullptr, 0, steps * BK};
   if (small) hipLaunchKernelGGL((gemm_nt_kernel<2, 7>), dim3(tiles, S), dim3(256), 2 * (64 * 128 + TILE_BYTES), (hipStream_t)stream, p);
   else hipLaunchKernelGGL((gemm_nt_kernel<4, 7>), dim3(tiles, S), dim3(256), GEMM_LDS_BYTES, (hipStream_t)stream, p);
   if (S > 1)
@@ -955,7 +844,7 @@ extern "C" int x2_mlm_ce_fwd(const void* X, const void* E, const float* bias, co
   X2_REQUIRE(X && E && labels && part && zlab, "x2_mlm_ce_fwd: null argument");
   X2_REQUIRE(mlm_ce_shapes_ok(R, Vp, V, Hd, ldx, lde), "x2_mlm_ce_fwd: R=%d Vp=%d V=%d Hd=%d ldx=%d lde=%d", R, Vp, V, Hd, ldx, lde);
   GemmNT p{(const bf16_t*)X, (const bf16_t*)E, nullptr, bias, nullptr, nullptr, nullptr, R, Vp, Hd, ldx, lde, Vp, 0, 0, 0, 0,
-           g_tune[0] > 0 ? g_tune[0] : 8, DropSpec{0u, 0u, 1.f}, nullptr, nullptr, nullptr, 0, 0, 0,
+           g_tune[0] > 0 ? g_tune[0] : 8, DropSpec{0u, 0u, 1.f}, nullptr, nullptr, nullptr, 0, 0,
            labels, nullptr, nullptr, nullptr, part, zlab, 1.f, V};
   launch_nt_ce(p, 8, (hipStream_t)stream);
   return x2_check_launch("x2_mlm_ce_fwd");
@@ -966,7 +855,7 @@ extern "C" int x2_mlm_ce_bwd(const void* X, const void* E, const float* bias, co
   X2_REQUIRE(X && E && labels && lse && g && stat && dl_bf16, "x2_mlm_ce_bwd: null argument");
   X2_REQUIRE(mlm_ce_shapes_ok(R, Vp, V, Hd, ldx, lde) && ldd >= Vp && ldd % 8 == 0, "x2_mlm_ce_bwd: R=%d Vp=%d V=%d Hd=%d ldd=%ld", R, Vp, V, Hd, ldd);
   GemmNT p{(const bf16_t*)X, (const bf16_t*)E, dl_bf16, bias, nullptr, nullptr, nullptr, R, Vp, Hd, ldx, lde, (int)ldd, 0, 0, 0, 0,
-           g_tune[0] > 0 ? g_tune[0] : 8, DropSpec{0u, 0u, 1.f}, nullptr, nullptr, nullptr, 0, 0, 0,
+           g_tune[0] > 0 ? g_tune[0] : 8, DropSpec{0u, 0u, 1.f}, nullptr, nullptr, nullptr, 0, 0,
            labels, lse, g, stat, nullptr, nullptr, gscale, V};
   launch_nt_ce(p, 9, (hipStream_t)stream);
   return x2_check_launch("x2_mlm_ce_bwd");

@@ -188,31 +188,26 @@ extern "C" int x2_reduce_partials_multi(const int64_t* desc, int count, void* st
 #define LNB_ROWS 16
 // DYB: the incoming gradient dy is bf16 (the input-gradient GEMM of a pre-LN block writes bf16, as the reference's apex-O1
 // linears hand fp16 gradients to their LayerNorm: 2 bytes instead of 4 written by the GEMM and read here)
-// LS: the row gradient leaves through a layer-scale branch as well (BEiT pre-LN blocks: every LayerNorm backward of the vision
-// tower feeds exactly one layer-scale backward - norm2 -> gamma_1 of its block, norm1 -> gamma_2 of the block below): with
-// the finished row dX still in registers, dU = gamma * rowscale * dX leaves as the bf16 operand of the next input-gradient
-// GEMM and dgamma += dX * rowscale * u, dbias += dU join the partial rows (4 sets: dw, db, dgamma, dbias; no dcol).  Saves
-// the stand-alone layer-scale kernel's 4-byte-per-element read of dX and its launch (x2_layernorm_bwd_layerscale).
-template <int NV, bool DYB, bool LS = false>
-__global__ __launch_bounds__(256, (NV <= 3 && !LS) ? 4 : (NV <= 3 ? 3 : 1)) void layernorm_bwd_kernel(const void* __restrict__ dy_, const float* __restrict__ x,
+// (A variant that also did the layer-scale backward its output feeds - x2_layernorm_bwd_layerscale, rounds 3-4 - saved a 38.7 MB read per
+// vision block but needed 156 VGPRs (3 waves per SIMD): 25.16 vs 24.92 ms per base step; with LDS atomics at 128 VGPRs 25.22 vs 23.58;
+// forced to 128 VGPRs with 29 spilled dwords 24.05-24.17 vs 23.59-23.62 (profiles/r05j_fused_ln_layerscale_ab.txt).  Removed.)
+template <int NV, bool DYB>
+__global__ __launch_bounds__(256, NV <= 3 ? 4 : 1) void layernorm_bwd_kernel(const void* __restrict__ dy_, const float* __restrict__ x,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
                                                             const float* __restrict__ w, const float* dres, float* dx, bf16_t* dxb,
                                                             float* ws, int rows, int D, int period,
-                                                            DropSpec din_, DropSpec dout_, const uint32_t* __restrict__ epoch,
-                                                            const bf16_t* __restrict__ ls_u = nullptr, const float* __restrict__ ls_gamma = nullptr,
-                                                            const float* __restrict__ ls_rowscale = nullptr, bf16_t* ls_du = nullptr) {
-  constexpr int NSET = LS ? 4 : 3;
+                                                            DropSpec din_, DropSpec dout_, const uint32_t* __restrict__ epoch) {
+  constexpr int NSET = 3;
   extern __shared__ __attribute__((aligned(16))) float red[];      // [NSET][3 waves][D]
   const DropSpec din = drop_at_epoch(din_, epoch), dout = drop_at_epoch(dout_, epoch);
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int nv = D >> 2;
-  float4 ww[NV], aw[NV], ab[NV], ac[NV], ad[LS ? NV : 1];      // LS: ac = dgamma partials, ad = layer-scale bias partials
+  float4 ww[NV], aw[NV], ab[NV], ac[NV];
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int c = lane + i * 64;
     ww[i] = c < nv ? *reinterpret_cast<const float4*>(w + c * 4) : float4{0.f, 0.f, 0.f, 0.f};
     aw[i] = float4{0.f, 0.f, 0.f, 0.f}; ab[i] = float4{0.f, 0.f, 0.f, 0.f}; ac[i] = float4{0.f, 0.f, 0.f, 0.f};
-    if constexpr (LS) ad[i] = float4{0.f, 0.f, 0.f, 0.f};
   }
   const int r0 = blockIdx.x * LNB_ROWS, r1 = min(rows, r0 + LNB_ROWS);
   for (int row = r0 + wv; row < r1; row += 4) {
@@ -259,20 +254,10 @@ __global__ __launch_bounds__(256, (NV <= 3 && !LS) ? 4 : (NV <= 3 ? 3 : 1)) void
           drop_mul4(dout, (uint32_t)gr * (uint32_t)D + (uint32_t)(c * 4), dm);
           om.x *= dm[0]; om.y *= dm[1]; om.z *= dm[2]; om.w *= dm[3];
         }
-        if constexpr (!LS) { ac[i].x += om.x; ac[i].y += om.y; ac[i].z += om.z; ac[i].w += om.w; }
+        ac[i].x += om.x; ac[i].y += om.y; ac[i].z += om.z; ac[i].w += om.w;
         if (dres) { const float4 rr = *reinterpret_cast<const float4*>(dres + gr * D + c * 4); o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w; }
         if (dx) *reinterpret_cast<float4*>(dx + gr * D + c * 4) = o;
         if (dxb) *reinterpret_cast<u32x2*>(dxb + gr * D + c * 4) = u32x2{pack_bf16(om.x, om.y), pack_bf16(om.z, om.w)};
-        if constexpr (LS) {       // layerscale_bwd_kernel's arithmetic on the finished row (gamma re-read per row: L1-resident, no registers held)
-          const float rsc = ls_rowscale ? ls_rowscale[gr] : 1.f;
-          const float4 gm = *reinterpret_cast<const float4*>(ls_gamma + c * 4);
-          const u32x2 uu = *reinterpret_cast<const u32x2*>(ls_u + gr * D + c * 4);
-          const float d0 = o.x * rsc, d1 = o.y * rsc, d2 = o.z * rsc, d3 = o.w * rsc;
-          const float o0 = d0 * gm.x, o1 = d1 * gm.y, o2 = d2 * gm.z, o3 = d3 * gm.w;
-          *reinterpret_cast<u32x2*>(ls_du + gr * D + c * 4) = u32x2{pack_bf16(o0, o1), pack_bf16(o2, o3)};
-          ac[i].x += d0 * bf_lo(uu[0]); ac[i].y += d1 * bf_hi(uu[0]); ac[i].z += d2 * bf_lo(uu[1]); ac[i].w += d3 * bf_hi(uu[1]);
-          ad[i].x += o0; ad[i].y += o1; ad[i].z += o2; ad[i].w += o3;
-        }
       }
     }
   }
@@ -285,7 +270,6 @@ __global__ __launch_bounds__(256, (NV <= 3 && !LS) ? 4 : (NV <= 3 ? 3 : 1)) void
         *reinterpret_cast<float4*>(red + ((0 * 3 + wv - 1) * D) + c * 4) = aw[i];
         *reinterpret_cast<float4*>(red + ((1 * 3 + wv - 1) * D) + c * 4) = ab[i];
         *reinterpret_cast<float4*>(red + ((2 * 3 + wv - 1) * D) + c * 4) = ac[i];
-        if constexpr (LS) *reinterpret_cast<float4*>(red + ((3 * 3 + wv - 1) * D) + c * 4) = ad[i];
       }
     }
   }
@@ -302,16 +286,11 @@ __global__ __launch_bounds__(256, (NV <= 3 && !LS) ? 4 : (NV <= 3 ? 3 : 1)) void
           aw[i].x += a.x; aw[i].y += a.y; aw[i].z += a.z; aw[i].w += a.w;
           ab[i].x += b.x; ab[i].y += b.y; ab[i].z += b.z; ab[i].w += b.w;
           ac[i].x += cc.x; ac[i].y += cc.y; ac[i].z += cc.z; ac[i].w += cc.w;
-          if constexpr (LS) {
-            const float4 dd = *reinterpret_cast<const float4*>(red + ((3 * 3 + k) * D) + c * 4);
-            ad[i].x += dd.x; ad[i].y += dd.y; ad[i].z += dd.z; ad[i].w += dd.w;
-          }
         }
         float* wp = ws + (long)blockIdx.x * NSET * D + c * 4;
         *reinterpret_cast<float4*>(wp) = aw[i];
         *reinterpret_cast<float4*>(wp + D) = ab[i];
         *reinterpret_cast<float4*>(wp + 2 * D) = ac[i];
-        if constexpr (LS) *reinterpret_cast<float4*>(wp + 3 * D) = ad[i];
       }
     }
   }
@@ -332,25 +311,6 @@ extern "C" int x2_layernorm_bwd(const void* dy, int dy_is_bf16, const float* x, 
   LN_DISPATCH(D, X2_LNB);
   if (!defer) launch_reduce(ws, (rows + LNB_ROWS - 1) / LNB_ROWS, 3, D, dw, db, dcol, (hipStream_t)stream);
   return x2_check_launch("x2_layernorm_bwd");
-}
-
-// LayerNorm backward + the layer-scale backward its output feeds (template flag LS above).  dx (fp32, = dres + LN-input
-// gradient) is still written: it is the residual gradient of the next LayerNorm backward.  ws: [ceil(rows/16)][4][D].
-extern "C" int x2_layernorm_bwd_layerscale(const void* dy, int dy_is_bf16, const float* x, const float* mean, const float* rstd,
-                                           const float* w, const float* dres, float* dx, float* dw, float* db, const void* u,
-                                           const float* gamma, const float* rowscale, void* du, float* dgamma, float* dbias, int rows,
-                                           int D, float* ws, int defer, void* stream) {
-  X2_REQUIRE(rows > 0 && D > 0 && D % 4 == 0 && D <= 256 * LN_MAXV, "x2_layernorm_bwd_layerscale: rows=%d D=%d", rows, D);
-  X2_REQUIRE(dy && x && mean && rstd && w && dx && dw && db && u && gamma && du && ws, "x2_layernorm_bwd_layerscale: null argument");
-  X2_REQUIRE(defer || (dgamma && dbias), "x2_layernorm_bwd_layerscale: dgamma / dbias may only be left to the caller's own reduction (defer != 0)");
-  const DropSpec nod{0u, 0u, 1.f};
-#define X2_LNBL_T(NV, B) hipLaunchKernelGGL((layernorm_bwd_kernel<NV, B, true>), dim3((rows + LNB_ROWS - 1) / LNB_ROWS), dim3(256), 12 * D * sizeof(float), \
-                     (hipStream_t)stream, dy, x, mean, rstd, w, dres, dx, (bf16_t*)nullptr, ws, rows, D, 0, nod, nod, (const uint32_t*)nullptr,        \
-                     (const bf16_t*)u, gamma, rowscale, (bf16_t*)du)
-#define X2_LNBL(NV) do { if (dy_is_bf16) X2_LNBL_T(NV, true); else X2_LNBL_T(NV, false); } while (0)
-  LN_DISPATCH(D, X2_LNBL);
-  if (!defer) launch_reduce(ws, (rows + LNB_ROWS - 1) / LNB_ROWS, 4, D, dw, db, dgamma, (hipStream_t)stream, dbias);
-  return x2_check_launch("x2_layernorm_bwd_layerscale");
 }
 
 // ---------------------------------------------------------------------------------- column sums

@@ -182,12 +182,6 @@ BANK = WeightBank()
 SPLIT_DECODER_DGRAD = os.environ.get("X2_SPLIT_DECODER_DGRAD", "1") == "1"     # A/B switches (probes/run_ab3.sh)
 FUSED_MLM_CE = os.environ.get("X2_FUSED_MLM_CE", "1") == "1"
 FUSE_DGELU_COLSUM = os.environ.get("X2_FUSE_DGELU_COLSUM", "1") == "1"       # fc1 / intermediate bias gradient from the GELU' GEMM's epilogue
-# layer-scale backward inside the LayerNorm backward that feeds it (x2_layernorm_bwd_layerscale).  Measured in the step (same
-# box, profiles/r03c_ab_switches.txt): 25.16 ms with it, 24.92 without - the fused kernel needs 156 VGPRs (3 waves per SIMD
-# instead of 4) and the HBM-bound LayerNorm backward loses more to the lower occupancy than the saved 38.7 MB read and
-# launch give back.  A register-leaner form (the two extra column sums as ds_add_f32 into LDS: 128 VGPRs, no spill) was worse:
-# 25.22 vs 23.58 ms - the LDS atomics of four waves on the same columns serialise.  Off by default; the kernel stays, parity-tested.
-FUSE_LAYERSCALE_BWD = os.environ.get("X2_FUSE_LAYERSCALE_BWD", "0") == "1"
 KEEP_MLM_LOGITS = False     # tests: also materialise the MLM logits (inspection only; the loss still comes from the fused path)
 # Tied decoder / word-embedding gradient in ONE buffer (graph.SegmentedStep switches it on for its passes): the MLM head's
 # backward parks its [V, Hd] weight gradient here instead of handing it to autograd, and the embedding backward - which
@@ -556,7 +550,6 @@ class VisionEncoderFn(torch.autograd.Function):
         F4 = p["blocks.%d.mlp.fc1.weight" % lo].shape[0] if hi > lo else 0
         dpath = meta.get("drop_path")
         pairs = _LayerPairs()
-        dy2_fused = None
         for i in reversed(range(lo, hi)):
             b = "blocks.%d." % i
             rs1, rs2 = dpath[i] if dpath is not None else (None, None)
@@ -574,25 +567,15 @@ class VisionEncoderFn(torch.autograd.Function):
             _, w1T = BANK.linear(p[b + "mlp.fc1.weight"])
             _, wprojT = BANK.linear(p[b + "attn.proj.weight"])
             _, wqkvT = BANK.linear(p[b + "attn.qkv.weight"])
-            # dy2 = gamma_2 * DropPath * dx comes from the LayerNorm backward that produced dx (norm1 of the block above, fused
-            # below, when FUSE_LAYERSCALE_BWD); otherwise from the stand-alone layer-scale backward
-            if dy2_fused is None:
-                dy2 = K.layerscale_bwd(dx, aux2, p[b + "gamma_2"], G["gamma_2"], G["mlp.fc2.bias"], rowscale=rs2)
-            else:
-                dy2, (ws_, nblk_) = dy2_fused
-                K.DEFERRED.append((ws_, nblk_, 4, D, (None, None, G["gamma_2"], G["mlp.fc2.bias"])))
+            dy2 = K.layerscale_bwd(dx, aux2, p[b + "gamma_2"], G["gamma_2"], G["mlp.fc2.bias"], rowscale=rs2)
             if FUSE_DGELU_COLSUM:     # fc1's bias gradient as per-wave partial rows from the GEMM epilogue (no pass over dpre, no atomics)
                 dpre = K.gemm_nt_dgelu_colsum(dy2, w2T, pre, G["mlp.fc1.bias"])
             else:
                 dpre = K.gemm_nt(dy2, w2T, aux=pre, act=2)
                 K.colsum_bf16(dpre, G["mlp.fc1.bias"])    # two-stage sums: 20 us; fused into the GEMM epilogue with atomics: 30 us
             dh2 = K.gemm_nt(dpre, w1T)            # bf16, like the fp16 grad_input of the reference's O1 linears: half the bytes
-            if FUSE_LAYERSCALE_BWD:
-                dx1, dy1, _ = K.layernorm_bwd_layerscale(dh2, x1, mean2, rstd2, p[b + "norm2.weight"], G["norm2.weight"], G["norm2.bias"], dx,
-                                                         aux1, p[b + "gamma_1"], G["gamma_1"], G["attn.proj.bias"], rowscale=rs1)
-            else:
-                dx1, _ = K.layernorm_bwd(dh2, x1, mean2, rstd2, p[b + "norm2.weight"], G["norm2.weight"], G["norm2.bias"], dres=dx)
-                dy1 = K.layerscale_bwd(dx1, aux1, p[b + "gamma_1"], G["gamma_1"], G["attn.proj.bias"], rowscale=rs1)
+            dx1, _ = K.layernorm_bwd(dh2, x1, mean2, rstd2, p[b + "norm2.weight"], G["norm2.weight"], G["norm2.bias"], dres=dx)
+            dy1 = K.layerscale_bwd(dx1, aux1, p[b + "gamma_1"], G["gamma_1"], G["attn.proj.bias"], rowscale=rs1)
             datt = K.gemm_nt(dy1, wprojT)
             dqkv = torch.empty_like(qkv)
             delta = torch.empty_like(lse)
@@ -613,16 +596,7 @@ class VisionEncoderFn(torch.autograd.Function):
             G.alias("attn.q_bias", G["qkv_bias"][:D])
             G.alias("attn.v_bias", G["qkv_bias"][2 * D:])
             dh1 = K.gemm_nt(dqkv, wqkvT)
-            dy2_fused = None
-            if FUSE_LAYERSCALE_BWD and i > lo and K.DEFERRED is not None:
-                # the block below's MLP branch: its gamma_2 / fc2-bias sums are registered with ITS arena in the next iteration
-                bb = "blocks.%d." % (i - 1)
-                rs2b = dpath[i - 1][1] if dpath is not None else None
-                dxn, dyb, pend = K.layernorm_bwd_layerscale(dh1, x, mean1, rstd1, p[b + "norm1.weight"], G["norm1.weight"], G["norm1.bias"], dx1,
-                                                            ctx.saved[i - 1 - lo][16], p[bb + "gamma_2"], rowscale=rs2b)
-                dy2_fused = (dyb, pend)
-            else:
-                dxn, _ = K.layernorm_bwd(dh1, x, mean1, rstd1, p[b + "norm1.weight"], G["norm1.weight"], G["norm1.bias"], dres=dx1)
+            dxn, _ = K.layernorm_bwd(dh1, x, mean1, rstd1, p[b + "norm1.weight"], G["norm1.weight"], G["norm1.bias"], dres=dx1)
             tn = [(dy2, act, G["mlp.fc2.weight"]), (dpre, h2, G["mlp.fc1.weight"]),
                   (dy1, att, G["attn.proj.weight"]), (dqkv, h1, G["attn.qkv.weight"])]
             pairs.add(G, tn, po)

@@ -320,29 +320,6 @@ def layernorm_bwd(dy, x, mean, rstd, w, dw, db, *, dres=None, dcol=None, period=
     return dx, dxb
 
 
-def layernorm_bwd_layerscale(dy, x, mean, rstd, w, dw, db, dres, u, gamma, dgamma=None, dbias=None, rowscale=None):
-    """LayerNorm backward whose result leaves through a layer-scale branch as well (BEiT blocks): returns (dx fp32 = dres +
-    LN-input gradient, du bf16 = gamma * rowscale * dx, pending); dw / db (LayerNorm) are accumulated, and so are dgamma /
-    dbias (layer scale, bias of the branch's last linear) when given.  dgamma = None (only while a layer's reductions are
-    being deferred): the layer-scale sums belong to ANOTHER layer's gradient arena that does not exist yet - `pending` =
-    (ws, nblk) lets the caller register them later: DEFERRED.append((ws, nblk, 4, D, (None, None, dgamma, dbias))).
-    = layernorm_bwd followed by layerscale_bwd in one pass over the rows."""
-    assert dy.dtype in (F32, BF16) and x.dtype == F32 and dy.is_contiguous() and x.is_contiguous() and u.dtype == BF16 and u.is_contiguous()
-    D = x.shape[-1]
-    R = mean.numel()
-    assert x.numel() == R * D and u.numel() == x.numel() and (dres is None or dres.numel() == x.numel())
-    assert dgamma is not None or DEFERRED is not None
-    dx = torch.empty_like(x)
-    du = torch.empty_like(u)
-    nblk = (R + 15) // 16
-    ws, defer = _ws_and_defer(x.device, nblk * 4 * D)
-    call("x2_layernorm_bwd_layerscale", ptr(dy), 1 if dy.dtype == BF16 else 0, ptr(x), ptr(mean), ptr(rstd), ptr(w), ptr(dres), ptr(dx),
-         ptr(dw), ptr(db), ptr(u), ptr(gamma), ptr(rowscale), ptr(du), ptr(dgamma), ptr(dbias), R, D, ptr(ws), defer)
-    if defer:
-        DEFERRED.append((ws, nblk, 4, D, (dw, db, dgamma, dbias)))
-    return dx, du, (ws, nblk)
-
-
 def colsum_bf16(y, out):
     nblk = (y.shape[0] + 63) // 64
     ws, defer = _ws_and_defer(y.device, nblk * y.shape[1])
