@@ -23,7 +23,7 @@ extern "C" {
 #endif
 
 const char* x2_last_error(void);
-int x2_abi_version(void);          /* == 7 */
+int x2_abi_version(void);          /* == 8 */
 int x2_device_cus(void);           /* compute units of the current HIP device, 0 if none */
 int x2_tune(int key, int value);   /* kernel-variant knobs for probes/ and tests (0 = automatic); keys listed in csrc/gemm.hip */
 
@@ -205,6 +205,19 @@ int x2_additive_mask(const long* atts, float* out, int S, int L, int Lp, float n
 /* CSR "K/V batch -> query sequences using it" from kv[S] (values in [0, Bi)): off[Bi+1], order[S] (stable counting sort);
  * the seq_off / seq_ids tables of X2AttnArgs for rows that share an image's K/V (the 4-pass fusion batch) */
 int x2_kv_csr(const int* kv, int S, int Bi, int* off, int* order, void* stream);
+/* row tables of the 4B-row fusion batch the step runs instead of the reference's four fusion passes (models/model_pretrain.py:44-62,
+ * xvlm.py:859-899): row q * B + b = (text b, image b) | (text b, image ineg[b]) | (text tneg[b], image b) | (masked text b, image b);
+ * t_idx[r] = row of the 2B-row [clean ; masked] text batch, kv[r] = image, atts_out[r] = text mask, enc_out[r] = image mask.
+ * with_match == 0: the masked rows only (ret_match_loss=False).  Replaces torch.arange / cat / index launches. */
+int x2_tail_index(const int* ineg, const int* tneg, const long* text_atts /* [B][L] */, const long* image_atts /* [Bi][T] */, int B, int L,
+                  int T, int with_match, int* t_idx, int* kv, long* atts_out /* [R][L] */, long* enc_out /* [R][T] */, void* stream);
+/* timm drop_path of the BEiT blocks (beit2.py:205-207, rates linspace(0, 0.1, depth) beit2.py:314): per-row keep / (1 - rate[l])
+ * factors out[depth][2 branches][B * T], one Bernoulli per (block, branch, sample) hashed from (seed [, *epoch]) */
+int x2_droppath_rows(const float* rates, unsigned seed, const unsigned* epoch, int depth, int B, int T, float* out, void* stream);
+/* video path, xvlm.py:627-645 ('avgpool'): forward out[Bc][T][D] = mean_f (x[Bc * F][T][D] + pos[F][D]) (pos may be NULL);
+ * backward (bwd != 0): out = dx[Bc * F][T][D] = dy / F per frame, dpos[F][D] = column sums of dy / F (NULL: not wanted) */
+int x2_frame_mean(const float* x, const float* pos, const float* dy, float* out, float* dpos, int Bc, int F, int T, int D, int bwd,
+                  void* stream);
 int x2_gelu_f32(const float* x, const float* dy, float* out, long n, void* stream);               /* nn.GELU, xvlm.py:167 */
 int x2_colsum_f32(const float* x, float* out, int M, int N, void* stream);
 

@@ -609,3 +609,62 @@ def test_kv_csr_and_additive_mask(K, S, Bi):
         m = K.additive_mask(atts.to(dev), neg)
         assert m.shape == (S, K.round_up(L, 64))
         assert torch.equal(m[:, :L].cpu(), (1.0 - atts.float()) * neg) and float(m[:, L:].abs().max()) == 0.0
+
+
+def test_tail_index_tables(K):
+    """x2_tail_index: row tables of the 4B-row fusion batch == the torch cat / index expressions they replace."""
+    g = torch.Generator().manual_seed(5)
+    B, L, T = 7, 9, 13
+    ineg = torch.randint(0, B, (B,), generator=g, dtype=torch.int32)
+    tneg = torch.randint(0, B, (B,), generator=g, dtype=torch.int32)
+    ta = (torch.rand(B, L, generator=g) > 0.3).long()
+    ia = (torch.rand(B, T, generator=g) > 0.2).long()
+    ar = torch.arange(B, dtype=torch.int32)
+    for with_match in (True, False):
+        t_idx, kv, atts, enc = K.tail_index(ineg.to(dev) if with_match else None, tneg.to(dev) if with_match else None, ta.to(dev), ia.to(dev),
+                                            with_match=with_match)
+        ti = torch.cat([ar, ar, tneg, ar + B]) if with_match else ar + B
+        ki = torch.cat([ar, ineg, ar, ar]) if with_match else ar
+        assert torch.equal(t_idx.cpu(), ti) and torch.equal(kv.cpu(), ki)
+        assert torch.equal(atts.cpu(), torch.cat([ta, ta])[ti.long()]) and torch.equal(enc.cpu(), ia[ki.long()])
+
+
+def test_droppath_rows_match_host_mirror_and_rates(K):
+    """x2_droppath_rows: keeps are the host mirror's (hash of (seed, epoch, block, branch, sample)), constant over a sample's T rows,
+    scaled by 1 / (1 - rate); rate 0 keeps everything; the empirical drop frequency follows the rate; a new epoch redraws."""
+    rates = [0.0, 0.05, 0.1, 0.5]
+    r = torch.tensor(rates, device=dev)
+    B, T = 6, 5
+    old = K.DROP_EPOCH
+    try:
+        K.DROP_EPOCH = None
+        rows = K.droppath_rows(r, 1234, B, T).cpu().view(len(rates), 2, B, T)
+        keep = K.droppath_keep(rates, 1234, B)
+        for l, rate in enumerate(rates):
+            assert torch.equal(rows[l], (keep[l] / (1.0 - torch.tensor(rate, dtype=torch.float32))).unsqueeze(-1).expand(2, B, T).contiguous()), l
+        assert float(rows[0].min()) == 1.0
+        K.DROP_EPOCH = torch.tensor([7], dtype=torch.int32, device=dev)
+        rows7 = K.droppath_rows(r, 1234, B, T).cpu().view(len(rates), 2, B, T)
+        assert torch.equal((rows7[..., 0] > 0).float(), K.droppath_keep(rates, 1234, B, epoch=7))
+        K.DROP_EPOCH = None
+        big = K.droppath_rows(r, 99, 4096, 1).cpu().view(len(rates), 2, 4096)
+        for l, rate in enumerate(rates):
+            frac = float((big[l] == 0).float().mean())
+            assert abs(frac - rate) < 0.03, (l, frac)
+    finally:
+        K.DROP_EPOCH = old
+
+
+def test_frame_mean_forward_backward(K):
+    """x2_frame_mean (video path, xvlm.py:627-645) against autograd of the tensor expression."""
+    ops = importlib.import_module("x2-vlm_amd.ops")
+    Bc, F, T, D = 3, 4, 5, 64
+    x = rnd(Bc * F, T, D, seed=1).requires_grad_(True)
+    pos = rnd(1, F, 1, D, seed=2).requires_grad_(True)
+    dy = rnd(Bc, T, D, seed=3)
+    ref = (x.view(Bc, F, T, D) + pos.view(1, F, 1, D)).mean(1)
+    ref.backward(dy)
+    xd, pd = x.detach().to(dev).requires_grad_(True), pos.detach().to(dev).requires_grad_(True)
+    out = ops.frame_mean(xd, pd, F)
+    out.backward(dy.to(dev))
+    assert relerr(out, ref.detach()) < 1e-6 and relerr(xd.grad, x.grad) < 1e-6 and relerr(pd.grad, pos.grad) < 1e-5

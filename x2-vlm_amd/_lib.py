@@ -66,6 +66,9 @@ _SIGS = {
     "x2_sample_negatives": [P, I, P, P, P, P],
     "x2_additive_mask": [P, P, I, I, I, F, P],
     "x2_kv_csr": [P, I, I, P, P, P],
+    "x2_tail_index": [P, P, P, P, I, I, I, I, P, P, P, P, P],
+    "x2_droppath_rows": [P, U, P, I, I, I, P, P],
+    "x2_frame_mean": [P, P, P, P, P, I, I, I, I, I, P],
     "x2_gelu_f32": [P, P, P, L, P],
     "x2_grad_norm": [P, I, I, F, P, P, P],
     "x2_adamw_multi": [P, I, I, P, P, I, F, F, F, P, P],

@@ -9,6 +9,7 @@ from functools import partial
 import torch
 import torch.nn as nn
 
+from . import kernels as K
 from .engine import VisionEncoderFn, vision_param_names
 
 
@@ -130,10 +131,15 @@ class VisionTransformer(nn.Module):
         rates = cache.get(device)
         if rates is None:
             rates = cache[device] = torch.tensor([b.drop_path_rate for b in self.blocks], device=device, dtype=torch.float32)
-        if keep is None:
-            keep = (torch.rand(self.depth, 2, B, device=device) >= rates.view(-1, 1, 1)).float()
-        scale = keep.to(device).float() / (1.0 - rates).view(-1, 1, 1)
-        rows = scale.repeat_interleave(T, dim=2)                       # (depth, 2, B*T)
+        if keep is None and rates.is_cuda:
+            # one kernel: Bernoulli keeps hashed from (seed, device epoch word) like the dropout masks, scaled and spread over the rows
+            from .xbert import next_dropout_seed
+            rows = K.droppath_rows(rates, next_dropout_seed(), B, T)
+        else:
+            if keep is None:
+                keep = (torch.rand(self.depth, 2, B, device=device) >= rates.view(-1, 1, 1)).float()
+            scale = keep.to(device).float() / (1.0 - rates).view(-1, 1, 1)
+            rows = scale.repeat_interleave(T, dim=2)                   # (depth, 2, B*T)
         return [(rows[i, 0].contiguous(), rows[i, 1].contiguous()) if float(self.blocks[i].drop_path_rate) > 0 else (None, None)
                 for i in range(self.depth)]
 

@@ -402,3 +402,109 @@ extern "C" int x2_colsum_f32(const float* x, float* out, int M, int N, void* str
   hipLaunchKernelGGL(colsum_f32_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, out, M, N);
   return x2_check_launch("x2_colsum_f32");
 }
+
+// ------------------------------------------------------------------------------------ glue of the step that used to be ATen launches
+// Row tables of the pre-training step's 4B-row fusion batch (model_pretrain.py tail_losses; the reference runs these rows as four
+// passes, xvlm.py:859-899 + model_pretrain.py:44-62): row r = q * B + b,
+//   q = 0: (text b, image b)   q = 1: (text b, image ineg[b])   q = 2: (text tneg[b], image b)   q = 3: (masked text b = row B + b, image b)
+// (with_match == 0: only the masked rows).  Writes t_idx[r] (row of the 2B-row text batch), kv[r] (image whose K / V row r attends
+// to), the text attention mask of every row and its image attention mask.  One launch instead of ~12 (arange, add, 2 x cat,
+// 2 x index, casts).
+__global__ __launch_bounds__(256) void tail_index_kernel(const int* __restrict__ ineg, const int* __restrict__ tneg,
+                                                         const long* __restrict__ text_atts, const long* __restrict__ image_atts, int B, int L,
+                                                         int T, int with_match, int* __restrict__ t_idx, int* __restrict__ kv,
+                                                         long* __restrict__ atts_out, long* __restrict__ enc_out) {
+  const int r = blockIdx.x, q = with_match ? r / B : 3, b = r % B;
+  const int ti = q == 2 ? tneg[b] : (q == 3 ? B + b : b), ki = q == 1 ? ineg[b] : b;
+  if (threadIdx.x == 0) { t_idx[r] = ti; kv[r] = ki; }
+  const long* ta = text_atts + (long)(ti % B) * L;
+  for (int l = threadIdx.x; l < L; l += 256) atts_out[(long)r * L + l] = ta[l];
+  const long* ia = image_atts + (long)ki * T;
+  for (int t = threadIdx.x; t < T; t += 256) enc_out[(long)r * T + t] = ia[t];
+}
+extern "C" int x2_tail_index(const int* ineg, const int* tneg, const long* text_atts, const long* image_atts, int B, int L, int T,
+                             int with_match, int* t_idx, int* kv, long* atts_out, long* enc_out, void* stream) {
+  X2_REQUIRE(text_atts && image_atts && t_idx && kv && atts_out && enc_out && B > 0 && L > 0 && T > 0, "x2_tail_index: B=%d L=%d T=%d", B, L, T);
+  X2_REQUIRE(!with_match || (ineg && tneg), "x2_tail_index: with_match needs the negative indices");
+  hipLaunchKernelGGL(tail_index_kernel, dim3(with_match ? 4 * B : B), dim3(256), 0, (hipStream_t)stream, ineg, tneg, text_atts, image_atts, B, L, T,
+                     with_match, t_idx, kv, atts_out, enc_out);
+  return x2_check_launch("x2_tail_index");
+}
+
+// Stochastic depth (timm drop_path as the reference's Block uses it, beit2.py:205-207): one Bernoulli(1 - rate[l]) per block l,
+// residual branch br and SAMPLE b; out[(l * 2 + br) * B * T + b * T + t] = keep / (1 - rate[l]) - the per-row factor the
+// projection / fc2 GEMM epilogues multiply in.  Counter-based like the dropout masks (x2_common.h): the uniform of (l, br, b) is
+// a hash of (seed [, device epoch word]), so a replayed hipGraph draws new keeps every step and the backward needs no mask tensor.
+// Mirrored by kernels.droppath_keep() on the host.  One launch instead of rand + compare + cast + divide + repeat_interleave.
+__global__ __launch_bounds__(256) void droppath_rows_kernel(const float* __restrict__ rates, uint32_t seed, const uint32_t* __restrict__ epoch,
+                                                            int depth, int B, int T, float* __restrict__ out) {
+  const long e = blockIdx.x * 256L + threadIdx.x, rows = (long)B * T;
+  if (e >= 2L * depth * rows) return;
+  const int lb = (int)(e / rows), b = (int)((e % rows) / T), l = lb >> 1;
+  uint32_t s_ = seed;
+  if (epoch) s_ = x2_hash(s_ + 0x9E3779B1u * epoch[0]);
+  const uint32_t h = x2_hash(((uint32_t)lb * (uint32_t)B + (uint32_t)b) ^ s_);
+  const float rate = rates[l], u = (float)(h >> 8) * (1.0f / 16777216.0f);
+  out[e] = u >= rate ? 1.0f / (1.0f - rate) : 0.0f;
+}
+extern "C" int x2_droppath_rows(const float* rates, unsigned seed, const unsigned* epoch, int depth, int B, int T, float* out, void* stream) {
+  X2_REQUIRE(rates && out && depth > 0 && B > 0 && T > 0, "x2_droppath_rows: depth=%d B=%d T=%d", depth, B, T);
+  const long n = 2L * depth * B * T;
+  hipLaunchKernelGGL(droppath_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, rates, seed, epoch, depth, B, T, out);
+  return x2_check_launch("x2_droppath_rows");
+}
+
+// Video path (xvlm.py:627-645, video_encoding 'avgpool'): out[b][t][:] = mean over the F frames of (x[b * F + f][t][:] + pos[f][:]).
+// Backward: dx[b * F + f] = dy[b] / F for every frame, dpos[f][:] = sum over (b, t) of dy / F (the same row for every frame).
+__global__ __launch_bounds__(256) void frame_mean_fwd_kernel(const float* __restrict__ x, const float* __restrict__ pos, float* __restrict__ out,
+                                                             int Bc, int F, long TD, int D) {
+  const long e = (blockIdx.x * 256L + threadIdx.x) * 4;
+  if (e >= (long)Bc * TD) return;
+  const long b = e / TD, o = e % TD;
+  const int d = (int)(o % D);
+  float4 a = float4{0.f, 0.f, 0.f, 0.f};
+  for (int f = 0; f < F; ++f) {
+    const float4 v = *reinterpret_cast<const float4*>(x + (b * F + f) * TD + o);
+    float4 pp = float4{0.f, 0.f, 0.f, 0.f};
+    if (pos) pp = *reinterpret_cast<const float4*>(pos + (long)f * D + d);
+    a.x += v.x + pp.x; a.y += v.y + pp.y; a.z += v.z + pp.z; a.w += v.w + pp.w;
+  }
+  const float inv = 1.0f / (float)F;
+  *reinterpret_cast<float4*>(out + e) = float4{a.x * inv, a.y * inv, a.z * inv, a.w * inv};
+}
+__global__ __launch_bounds__(256) void frame_mean_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int Bc, int F, long TD) {
+  const long e = (blockIdx.x * 256L + threadIdx.x) * 4;
+  if (e >= (long)Bc * TD) return;
+  const long b = e / TD, o = e % TD;
+  const float inv = 1.0f / (float)F;
+  float4 g = *reinterpret_cast<const float4*>(dy + e);
+  g.x *= inv; g.y *= inv; g.z *= inv; g.w *= inv;
+  for (int f = 0; f < F; ++f) *reinterpret_cast<float4*>(dx + (b * F + f) * TD + o) = g;
+}
+// dpos[f][d] = (1 / F) sum over rows of dy[row][d]: one workgroup per 64 columns, 4 row slices, LDS fold
+__global__ __launch_bounds__(256) void frame_pos_grad_kernel(const float* __restrict__ dy, float* __restrict__ dpos, long rows, int D, int F) {
+  __shared__ float sh[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), sl = threadIdx.x >> 6;
+  float s = 0.f;
+  if (c < D) for (long r = sl; r < rows; r += 4) s += dy[r * D + c];
+  sh[sl][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (sl == 0 && c < D) {
+    const float v = (sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x]) / (float)F;
+    for (int f = 0; f < F; ++f) dpos[(long)f * D + c] = v;
+  }
+}
+extern "C" int x2_frame_mean(const float* x, const float* pos, const float* dy, float* out, float* dpos, int Bc, int F, int T, int D, int bwd,
+                             void* stream) {
+  X2_REQUIRE(Bc > 0 && F > 0 && T > 0 && D > 0 && D % 4 == 0, "x2_frame_mean: Bc=%d F=%d T=%d D=%d", Bc, F, T, D);
+  const long TD = (long)T * D, n4 = (long)Bc * TD / 4;
+  if (!bwd) {
+    X2_REQUIRE(x && out, "x2_frame_mean: forward needs x and out");
+    hipLaunchKernelGGL(frame_mean_fwd_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, pos, out, Bc, F, TD, D);
+  } else {
+    X2_REQUIRE(dy && out, "x2_frame_mean: backward needs dy and out (= dx)");
+    hipLaunchKernelGGL(frame_mean_bwd_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dy, out, Bc, F, TD);
+    if (dpos) hipLaunchKernelGGL(frame_pos_grad_kernel, dim3((D + 63) / 64), dim3(256), 0, (hipStream_t)stream, dy, dpos, (long)Bc * T, D, F);
+  }
+  return x2_check_launch("x2_frame_mean");
+}

@@ -154,10 +154,16 @@ class WeightBank:
         key = ("vec",) + tuple(it if isinstance(it, int) else _tok(it) for it in items)
         vers = tuple(0 if isinstance(it, int) else (it._version, it.data_ptr()) for it in items)
 
-        def build():
-            dev = next(it for it in items if not isinstance(it, int)).device
-            return torch.cat([torch.zeros(it, device=dev, dtype=F32) if isinstance(it, int) else it.detach().reshape(-1) for it in items])
-        return self._get(key, vers, build, [it for it in items if not isinstance(it, int)])
+        ent = self._c.get(key)
+        if ent is None or ent[0] != vers:
+            if next(it for it in items if not isinstance(it, int)).is_cuda:
+                self.prepare_vectors([items])          # one multi-tensor launch (zeros included) instead of zeros + cat
+                ent = self._c[key]
+            else:
+                dev = next(it for it in items if not isinstance(it, int)).device
+                val = torch.cat([torch.zeros(it, device=dev, dtype=F32) if isinstance(it, int) else it.detach().reshape(-1) for it in items])
+                ent = self._c[key] = (vers, val, tuple(weakref.ref(it) for it in items if not isinstance(it, int)))
+        return ent[1]
 
     def vocab(self, w):
         """word embeddings [V,Hd] -> (bf16 [Vp,Hd] zero-padded rows, bf16 [Hd,Vp]), Vp = V rounded to 64."""
@@ -204,19 +210,36 @@ class Grads:
     spec: list of (name, shape, zero_init); a name may be a fused block (e.g. q/k/v weights stacked)
     that the caller later splits into views with `alias`."""
 
-    def __init__(self, device, spec, key=None, params=()):
+    def __init__(self, device, spec, key=None, params=(), zero=True):
+        """zero=False: the caller zeroes the accumulated-into front of several arenas with ONE launch (`Grads.zero_all`) -
+        a stage's backward knows all its layers' arenas up front (30 memsets per base step were 30 launches)."""
         self.params = list(params)      # the Parameter objects whose gradients live in this arena (data parallelism)
         spec = [s for s in spec if s[2]] + [s for s in spec if not s[2]]
         offs, o = [], 0
         for _, shape, _z in spec:
             offs.append(o)
             o += (int(torch.Size(shape).numel()) + 3) // 4 * 4
-        nzero = sum((int(torch.Size(sh).numel()) + 3) // 4 * 4 for _, sh, z in spec if z)
+        self.nzero = sum((int(torch.Size(sh).numel()) + 3) // 4 * 4 for _, sh, z in spec if z)
         self.flat = torch.empty(o, device=device, dtype=F32)
-        if nzero:
-            self.flat[:nzero].zero_()
+        if zero and self.nzero:
+            self.flat[:self.nzero].zero_()
         self.g = {n: self.flat[of:of + torch.Size(sh).numel()].view(sh) for (n, sh, _z), of in zip(spec, offs)}
         self.key = key
+
+    @staticmethod
+    def zero_all(arenas, extra=()):
+        """One multi-tensor launch that zeroes the accumulated-into fronts of `arenas` (built with zero=False) and any further
+        fp32 tensors in `extra`."""
+        desc = [(0, g.flat.data_ptr(), g.nzero) for g in arenas if g.nzero] + [(0, t.data_ptr(), t.numel()) for t in extra]
+        if not desc:
+            return
+        if arenas[0].flat.is_cuda if arenas else extra[0].is_cuda:
+            K.copy_f32_multi(desc)
+        else:
+            for g in arenas:
+                g.flat[:g.nzero].zero_()
+            for t in extra:
+                t.zero_()
 
     def __getitem__(self, name):
         return self.g[name]
@@ -550,18 +573,28 @@ class VisionEncoderFn(torch.autograd.Function):
         F4 = p["blocks.%d.mlp.fc1.weight" % lo].shape[0] if hi > lo else 0
         dpath = meta.get("drop_path")
         pairs = _LayerPairs()
+        # every block's gradient arena up front: their accumulated-into fronts are zeroed by ONE launch
+        arenas = {}
+        for i in range(lo, hi):
+            b = "blocks.%d." % i
+            arenas[i] = Grads(dev, [("gamma_1", (D,), True), ("gamma_2", (D,), True), ("norm1.weight", (D,), True), ("norm1.bias", (D,), True),
+                                    ("qkv_bias", (3 * D,), True), ("attn.relative_position_bias_table", p[b + "attn.relative_position_bias_table"].shape, True),
+                                    ("attn.proj.bias", (D,), True), ("norm2.weight", (D,), True), ("norm2.bias", (D,), True),
+                                    ("mlp.fc1.bias", (F4,), True), ("mlp.fc2.bias", (D,), True),
+                                    ("attn.qkv.weight", (3 * D, D), False), ("attn.proj.weight", (D, D), False),
+                                    ("mlp.fc1.weight", (F4, D), False), ("mlp.fc2.weight", (D, F4), False)], key=("vit", id(p[b + "gamma_1"])),
+                              params=[p[n] for n in names if n.startswith(b)], zero=False)
+        Gs = None
+        if stem:
+            sn = ("cls_token", "patch_embed.proj.weight", "patch_embed.proj.bias")
+            Gs = Grads(dev, [(n, p[n].shape, True) for n in sn], key=("vit-stem", id(p["cls_token"])), params=[p[n] for n in sn], zero=False)
+        Grads.zero_all(list(arenas.values()) + ([Gs] if Gs is not None else []))
         for i in reversed(range(lo, hi)):
             b = "blocks.%d." % i
             rs1, rs2 = dpath[i] if dpath is not None else (None, None)
             (x, h1, mean1, rstd1, qkv, bias, biasT, att, lse, aux1, x1, h2, mean2, rstd2, pre, act, aux2) = ctx.saved[i - lo]
             ctx.saved[i - lo] = None
-            G = Grads(dev, [("gamma_1", (D,), True), ("gamma_2", (D,), True), ("norm1.weight", (D,), True), ("norm1.bias", (D,), True),
-                            ("qkv_bias", (3 * D,), True), ("attn.relative_position_bias_table", p[b + "attn.relative_position_bias_table"].shape, True),
-                            ("attn.proj.bias", (D,), True), ("norm2.weight", (D,), True), ("norm2.bias", (D,), True),
-                            ("mlp.fc1.bias", (F4,), True), ("mlp.fc2.bias", (D,), True),
-                            ("attn.qkv.weight", (3 * D, D), False), ("attn.proj.weight", (D, D), False),
-                            ("mlp.fc1.weight", (F4, D), False), ("mlp.fc2.weight", (D, F4), False)], key=("vit", id(p[b + "gamma_1"])),
-                      params=[p[n] for n in names if n.startswith(b)])
+            G = arenas.pop(i)
             _begin_layer_backward()
             _, w2T = BANK.linear(p[b + "mlp.fc2.weight"])
             _, w1T = BANK.linear(p[b + "mlp.fc1.weight"])
@@ -606,8 +639,6 @@ class VisionEncoderFn(torch.autograd.Function):
             dx = dxn
         pairs.flush()
         if stem:
-            sn = ("cls_token", "patch_embed.proj.weight", "patch_embed.proj.bias")
-            Gs = Grads(dev, [(n, p[n].shape, True) for n in sn], key=("vit-stem", id(p["cls_token"])), params=[p[n] for n in sn])
             dpatch = K.assemble_tokens_bwd(dx.view(B, T, D), Gs["cls_token"].view(-1))
             K.colsum_bf16(dpatch, Gs["patch_embed.proj.bias"])
             # 36 output tiles only: split the 12k-long contraction over 8 workgroups per tile (fp32 atomics)
@@ -757,11 +788,10 @@ class BertLayersFn(torch.autograd.Function):
         if cross:
             Bi, T, Dv = enc_shape
         pairs = _LayerPairs()
-        for li, i in reversed(list(enumerate(range(meta["lo"], meta["hi"])))):
+        # every layer's gradient arena up front: their accumulated-into fronts are zeroed by ONE launch
+        arenas = {}
+        for li, i in enumerate(range(meta["lo"], meta["hi"])):
             b = "layer.%d." % i
-            a = b + "attention."
-            hb, qkv, att, lse, s1, m1, r1, h1b, cr, h2b, pre, act, s3, m3, r3 = ctx.saved[li]
-            ctx.saved[li] = None
             Ff = p[b + "intermediate.dense.weight"].shape[0]
             spec = [("a.qkv_bias", (3 * Hd,), True), ("attention.output.dense.bias", (Hd,), True),
                     ("attention.output.LayerNorm.weight", (Hd,), True), ("attention.output.LayerNorm.bias", (Hd,), True),
@@ -769,12 +799,21 @@ class BertLayersFn(torch.autograd.Function):
                     ("output.LayerNorm.weight", (Hd,), True), ("output.LayerNorm.bias", (Hd,), True),
                     ("a.qkv_weight", (3 * Hd, Hd), False), ("attention.output.dense.weight", (Hd, Hd), False),
                     ("intermediate.dense.weight", (Ff, Hd), False), ("output.dense.weight", (Hd, Ff), False)]
-            if cr is not None:
+            if ctx.saved[li][8] is not None:            # cr: the layer has a cross-attention branch in this pass
                 spec += [("crossattention.self.query.bias", (Hd,), True), ("c.kv_bias", (2 * Hd,), True),
                          ("crossattention.output.dense.bias", (Hd,), True), ("crossattention.output.LayerNorm.weight", (Hd,), True),
                          ("crossattention.output.LayerNorm.bias", (Hd,), True), ("crossattention.self.query.weight", (Hd, Hd), False),
                          ("c.kv_weight", (2 * Hd, Dv), False), ("crossattention.output.dense.weight", (Hd, Hd), False)]
-            G = Grads(dev, spec, key=("bert", id(p[a + "self.query.weight"])), params=[p[n] for n in names if n.startswith(b)])
+            arenas[i] = Grads(dev, spec, key=("bert", id(p[b + "attention.self.query.weight"])), params=[p[n] for n in names if n.startswith(b)],
+                              zero=False)
+        Grads.zero_all(list(arenas.values()))
+        for li, i in reversed(list(enumerate(range(meta["lo"], meta["hi"])))):
+            b = "layer.%d." % i
+            a = b + "attention."
+            hb, qkv, att, lse, s1, m1, r1, h1b, cr, h2b, pre, act, s3, m3, r3 = ctx.saved[li]
+            ctx.saved[li] = None
+            Ff = p[b + "intermediate.dense.weight"].shape[0]
+            G = arenas.pop(i)
             tn, po = [], []
             _begin_layer_backward()
             ds3, ds3b = K.layernorm_bwd(dh, s3, m3, r3, p[b + "output.LayerNorm.weight"], G["output.LayerNorm.weight"],
@@ -865,10 +904,11 @@ class EmbeddingsFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         ids, e, mean, rstd, word, pos, typ, lnw = ctx.saved_tensors
-        small = torch.zeros(2 * lnw.numel(), device=dy.device, dtype=F32)
-        dw, db = small[:lnw.numel()], small[lnw.numel():]
+        n = lnw.numel()
+        zeros = torch.zeros(2 * n + pos.numel() + typ.numel(), device=dy.device, dtype=F32)      # one fill for the four small gradients
+        dw, db = zeros[:n], zeros[n:2 * n]
+        dpos, dtyp = zeros[2 * n:2 * n + pos.numel()].view_as(pos), zeros[2 * n + pos.numel():].view_as(typ)
         de, _ = K.layernorm_bwd(dy.contiguous().view(e.shape), e, mean, rstd, lnw, dw, db, drop_in=ctx.drop)
-        dpos, dtyp = torch.zeros_like(pos), torch.zeros_like(typ)
         dword = _TIED_DWORD.pop(_tok(word), None)          # the tied decoder's gradient, if the MLM head left it (TIE_WORD_GRAD)
         if dword is None:
             dword = torch.zeros_like(word)
@@ -900,8 +940,7 @@ class MlmLossFn(torch.autograd.Function):
         tb, _, mean, rstd = K.layernorm_fwd(t_act, lnw, lnb, eps)
         Eb, EbT = BANK.vocab(word)
         Vp = Eb.shape[0]
-        bias_p = torch.zeros(Vp, device=rows.device, dtype=F32)
-        bias_p[:V] = dec_bias.detach()
+        bias_p = BANK.vector(dec_bias, Vp - V) if Vp > V else dec_bias.detach()        # zero-padded to the padded vocabulary
         labels = labels.contiguous().view(-1)
         ctx.fused = FUSED_MLM_CE
         logits = None
@@ -933,12 +972,12 @@ class MlmLossFn(torch.autograd.Function):
         else:
             dl = K.ce_bwd(saved, labels, lse, g1, stat, C_valid=V, out_dtype=BF16)
         Vp = dl.shape[1]
-        dbias = torch.zeros(Vp, device=dev, dtype=F32)
+        zeros = torch.zeros(Vp + 3 * Hd, device=dev, dtype=F32)          # one fill: decoder-bias gradient + the three head vectors below
+        dbias, small = zeros[:Vp], zeros[Vp:]
         K.colsum_bf16(dl, dbias)
         # [R, Hd] from a 30528-long contraction: 36-72 output tiles, so the contraction is split (354 -> ~50 us)
         dt = K.gemm_nt_splitk(dl, EbT) if SPLIT_DECODER_DGRAD else K.gemm_nt(dl, EbT, out_dtype=F32)
         dword = torch.empty_like(word)
-        small = torch.zeros(3 * Hd, device=dev, dtype=F32)
         dlnw, dlnb, dbd = small[:Hd], small[Hd:2 * Hd], small[2 * Hd:]
         dact, _ = K.layernorm_bwd(dt, t_act, mean, rstd, lnw, dlnw, dlnb)
         dpre = K.gelu_f32(t_pre.float(), dact)                        # small [R,Hd]: GELU' on the saved pre-activation

@@ -580,6 +580,67 @@ def kv_csr(kv, Bi):
     return off, order
 
 
+def tail_index(ineg, tneg, text_atts, image_atts, with_match=True):
+    """Row tables of the 4B-row fusion batch (x2_tail_index): -> (t_idx int32 [R], kv int32 [R], atts int64 [R, L], enc_atts
+    int64 [R, T]), R = 4B (with_match) or B."""
+    B, L = text_atts.shape
+    T = image_atts.shape[1]
+    assert text_atts.dtype == torch.int64 and image_atts.dtype == torch.int64 and text_atts.is_contiguous() and image_atts.is_contiguous()
+    assert not with_match or (ineg.dtype == torch.int32 and tneg.dtype == torch.int32 and ineg.numel() == B and tneg.numel() == B)
+    R = 4 * B if with_match else B
+    dev = text_atts.device
+    t_idx = torch.empty(R, device=dev, dtype=torch.int32)
+    kv = torch.empty(R, device=dev, dtype=torch.int32)
+    atts = torch.empty(R, L, device=dev, dtype=torch.int64)
+    enc = torch.empty(R, T, device=dev, dtype=torch.int64)
+    call("x2_tail_index", ptr(ineg) if with_match else None, ptr(tneg) if with_match else None, ptr(text_atts), ptr(image_atts), B, L, T,
+         1 if with_match else 0, ptr(t_idx), ptr(kv), ptr(atts), ptr(enc))
+    return t_idx, kv, atts, enc
+
+
+def droppath_rows(rates, seed, B, T):
+    """fp32 [depth, 2, B * T] per-row keep / (1 - rate) factors of every block's two residual branches (x2_droppath_rows); the
+    uniforms are hashed from (seed, DROP_EPOCH) like the dropout masks."""
+    depth = rates.numel()
+    out = torch.empty(depth, 2, B * T, device=rates.device, dtype=F32)
+    call("x2_droppath_rows", ptr(rates), int(seed) & 0xFFFFFFFF, ptr(DROP_EPOCH), depth, B, T, ptr(out))
+    return out
+
+
+def droppath_keep(rates, seed, B, epoch=None):
+    """Host mirror of droppath_rows_kernel: 0/1 keep tensor [depth, 2, B] for (seed [, epoch])."""
+    s_ = int(seed) & 0xFFFFFFFF
+    if epoch is not None:
+        s_ = _hash32_int((s_ + 0x9E3779B1 * (int(epoch) & 0xFFFFFFFF)) & 0xFFFFFFFF)
+    depth = len(rates)
+    keep = torch.zeros(depth, 2, B)
+    for lb in range(2 * depth):
+        for b in range(B):
+            h = _hash32_int(((lb * B + b) & 0xFFFFFFFF) ^ s_)
+            u = torch.tensor(float(h >> 8), dtype=torch.float32) * torch.tensor(1.0 / 16777216.0, dtype=torch.float32)
+            keep[lb >> 1, lb & 1, b] = 1.0 if float(u) >= float(torch.tensor(rates[lb >> 1], dtype=torch.float32)) else 0.0
+    return keep
+
+
+def frame_mean(x, pos, frames):
+    """(B * F, T, D) fp32 [+ pos (F, D)] -> (B, T, D): mean over the frames (x2_frame_mean forward)."""
+    BF, T, D = x.shape
+    assert x.dtype == F32 and x.is_contiguous() and BF % frames == 0 and (pos is None or (pos.is_contiguous() and pos.numel() == frames * D))
+    out = torch.empty(BF // frames, T, D, device=x.device, dtype=F32)
+    call("x2_frame_mean", ptr(x), ptr(pos), None, ptr(out), None, BF // frames, frames, T, D, 0)
+    return out
+
+
+def frame_mean_bwd(dy, frames, want_dpos=True):
+    """-> (dx (B * F, T, D), dpos (F, D) or None)."""
+    B, T, D = dy.shape
+    assert dy.dtype == F32 and dy.is_contiguous()
+    dx = torch.empty(B * frames, T, D, device=dy.device, dtype=F32)
+    dpos = torch.empty(frames, D, device=dy.device, dtype=F32) if want_dpos else None
+    call("x2_frame_mean", None, None, ptr(dy), ptr(dx), ptr(dpos), B, frames, T, D, 1)
+    return dx, dpos
+
+
 def gelu_f32(x, dy=None):
     out = torch.empty_like(x)
     call("x2_gelu_f32", ptr(x), ptr(dy), ptr(out), x.numel())

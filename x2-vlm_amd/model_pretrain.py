@@ -8,6 +8,7 @@ row as the reference's separate passes; 4x fewer, 4x larger GEMMs; F_min FLOPs (
 """
 import torch
 
+from . import kernels as K
 from . import ops
 from .xvlm import XVLMBase
 
@@ -46,16 +47,17 @@ class XVLM(XVLMBase):
         dev = both.device
         text_embeds = both[:B]
         loss_itc = self.get_contrastive_loss(image_feat, text_feat, gathered=gathered)
-        ar = torch.arange(B, device=dev, dtype=torch.int32)
-        if ret_match_loss:
-            ineg, tneg = self.get_hard_negatives(image_feat, text_feat)
-            t_idx = torch.cat([ar, ar, tneg, ar + B])          # rows of `both`: pos | neg(text b) | neg(text neg) | masked
-            kv = torch.cat([ar, ineg, ar, ar])
+        # rows of `both` that enter the fusion pass: pos | neg(text b, image neg) | neg(text neg, image b) | masked, the image each
+        # attends to, and the two attention masks per row
+        ineg, tneg = self.get_hard_negatives(image_feat, text_feat) if ret_match_loss else (None, None)
+        if both.is_cuda:
+            t_idx, kv, atts, enc_atts = K.tail_index(ineg, tneg, text_atts.contiguous(), image_atts.contiguous(), with_match=ret_match_loss)
         else:
-            t_idx, kv = ar + B, ar
+            ar = torch.arange(B, device=dev, dtype=torch.int32)
+            t_idx, kv = (torch.cat([ar, ar, tneg, ar + B]), torch.cat([ar, ineg, ar, ar])) if ret_match_loss else (ar + B, ar)
+            atts, enc_atts = torch.cat([text_atts, text_atts])[t_idx.long()], image_atts[kv.long()]
         h0 = ops.gather_rows(both, t_idx)
-        atts = torch.cat([text_atts, text_atts])[t_idx.long()]
-        fused = self.get_cross_embeds(image_embeds, image_atts[kv.long()], text_embeds=h0, text_atts=atts, kv_idx=kv)
+        fused = self.get_cross_embeds(image_embeds, enc_atts, text_embeds=h0, text_atts=atts, kv_idx=kv)
         if ret_match_loss:
             loss_itm = self._itm_loss(fused[:3 * B, 0, :], B)
         else:

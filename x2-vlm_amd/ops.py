@@ -64,22 +64,26 @@ def masked_mean_token0(x, w):
 
 
 class _FrameMean(torch.autograd.Function):
-    """(B*F, T, D) + pos (1,F,1,D) -> mean over frames (B, T, D).  xvlm.py:627-645 (tiny, HBM-bound;
-    expressed with the fp32 linear kernel would be wasteful, so it is a plain row reduction)."""
+    """(B*F, T, D) + pos (1,F,1,D) -> mean over frames (B, T, D).  xvlm.py:627-645; x2_frame_mean forward / backward kernels
+    (HBM-bound row work)."""
 
     @staticmethod
     def forward(ctx, x, pos, frames):
         BF, T, D = x.shape
-        ctx.frames = frames
-        xv = x.view(BF // frames, frames, T, D)
-        return (xv.sum(1) + pos.view(1, frames, 1, D).sum(1)) / frames
+        ctx.frames, ctx.pos_shape = frames, pos.shape
+        if not x.is_cuda:                                        # host use (unit tests of the wrapper logic): plain tensor maths
+            return (x.view(BF // frames, frames, T, D).sum(1) + pos.view(1, frames, 1, D).sum(1)) / frames
+        return K.frame_mean(x.contiguous(), pos.detach().reshape(frames, D).contiguous(), frames)
 
     @staticmethod
     def backward(ctx, dy):
         f = ctx.frames
         B, T, D = dy.shape
-        g = (dy / f).unsqueeze(1).expand(B, f, T, D).reshape(B * f, T, D)
-        return g, (dy.sum((0, 1)) / f).view(1, 1, 1, D).expand(1, f, 1, D).clone(), None
+        if not dy.is_cuda:
+            g = (dy / f).unsqueeze(1).expand(B, f, T, D).reshape(B * f, T, D)
+            return g, (dy.sum((0, 1)) / f).view(1, 1, 1, D).expand(1, f, 1, D).clone(), None
+        dx, dpos = K.frame_mean_bwd(dy.contiguous(), f)
+        return dx, dpos.view(ctx.pos_shape), None
 
 
 def frame_mean(x, pos, frames):

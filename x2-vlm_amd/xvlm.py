@@ -275,8 +275,12 @@ class XVLMBase(nn.Module):
 
     def _itm_loss(self, cls, B):
         logits = ops.mlp_head(self.itm_head, cls)
-        labels = torch.zeros(3 * B, dtype=torch.long, device=cls.device)      # built on the device (graph-capturable)
-        labels[:B] = 1
+        cache = self.__dict__.setdefault("_itm_labels", {})                    # constant per (B, device): built once, no launch per step
+        labels = cache.get((B, cls.device))
+        if labels is None:
+            labels = torch.zeros(3 * B, dtype=torch.long, device=cls.device)
+            labels[:B] = 1
+            cache[(B, cls.device)] = labels
         self.last_itm_logits = logits.detach()
         return ops.cross_entropy(logits, labels)
 
