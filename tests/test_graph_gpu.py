@@ -193,6 +193,10 @@ def test_mixed_iteration_replayed_accumulates_like_the_oracle(synthetic):
     step = graph.MixedStep(model, [dict(batch=si, negatives=negi), dict(batch=sr, negatives=negr, weight=0.5, ret_bbox_loss=True)],
                            clamp_temp=False)
     assert step.mode == "hipgraph-segments", step.error
+    # every step object shares ONE set of streams: a parameter's AccumulateGrad node can be pinned to a stream only once, and the
+    # region part (fusion layers run twice: in-place accumulation) otherwise accumulates on the image part's streams, outside its
+    # own captures - a race that corrupted memory at random before round 4's fix
+    assert step.steps[0].sA is step.steps[1].sA and step.steps[0].sB is step.steps[1].sB
     cfg = O.config_from_case(c)
     torch.set_num_threads(8)
     for it in range(2):

@@ -43,6 +43,7 @@ class GraphedStep:
         self.stream = torch.cuda.Stream()
         self.mode = "eager"
         self.error = None
+        self._epoch = None                    # disabled: eager launches; the process-wide epoch word (if any step object made one) still advances
         if not enabled or os.environ.get("X2_GRAPH", "1") == "0":
             return
         from . import engine
@@ -102,7 +103,9 @@ class GraphedStep:
                     if p_.grad is not g_:
                         p_.grad = g_
             else:
-                self._epoch.add_(1)
+                ep = self._epoch if self._epoch is not None else K.DROP_EPOCH
+                if ep is not None:
+                    ep.add_(1)
                 self.out = self.fn()
         cur.wait_stream(self.stream)
         return self.out
@@ -153,6 +156,8 @@ class SegmentedStep:
     masked_pos, masked_ids [, image_atts, idx_to_group_img, target_bbox, is_image]); new data goes in with
     GraphedStep.copy_inputs.  Falls back to eager execution of the same segments when capture is disabled or fails."""
 
+    _STREAMS = {}
+
     def __init__(self, model, batch, world=1, rank=0, process_group=None, comm=None, warmup=2, enabled=True, verbose=False,
                  ret_bbox_loss=False, ret_match_loss=True, recast_weights=True, clamp_temp=True, total_loss=None, side_stream=None,
                  vision_cuts=None, reduce_grads=True, defer_reduce=False):
@@ -198,10 +203,22 @@ class SegmentedStep:
         self._held = []
         self._rorder = []                       # segment names in the order their reductions are issued (recorded at capture)
         self.total_loss = total_loss or (lambda losses: sum(losses.values()))
-        self.sA = torch.cuda.Stream()
-        self.sB = self.sA if os.environ.get("X2_SEG_ONE_STREAM", "0") == "1" else torch.cuda.Stream()    # A/B: everything on one stream
-        self.sC = torch.cuda.Stream() if self.coll else None     # gradient all-reduces
-        self.sG = torch.cuda.Stream() if self.coll else None     # ITC all-gathers (see _gather)
+        # ONE set of streams per process and device, shared by every SegmentedStep: a parameter's AccumulateGrad node is
+        # unique, and `_pin_accumulators` can bind it to a stream only once - a second step object with streams of its own (the
+        # region part of a MixedStep, or a separately built region step) had its in-place gradient accumulations (layers that
+        # run twice in a pass) executed on the FIRST object's streams, outside its captures: a race that corrupted memory at
+        # random (round 4: `bench.py --config mixed --tiny` died with GPU memory faults, image part first; region first was fine).
+        # Step objects never run concurrently, so sharing costs nothing.
+        dev_key = (batch["text_ids"].device.index, os.environ.get("X2_SEG_ONE_STREAM", "0") == "1")
+        st = SegmentedStep._STREAMS.get(dev_key)
+        if st is None:
+            a_ = torch.cuda.Stream()
+            st = SegmentedStep._STREAMS[dev_key] = dict(A=a_, B=a_ if dev_key[1] else torch.cuda.Stream(), C=None, G=None)
+        if self.coll and st["C"] is None:
+            st["C"], st["G"] = torch.cuda.Stream(), torch.cuda.Stream()
+        self.sA, self.sB = st["A"], st["B"]                      # B == A with X2_SEG_ONE_STREAM=1 (A/B: everything on one stream)
+        self.sC = st["C"] if self.coll else None                 # gradient all-reduces
+        self.sG = st["G"] if self.coll else None                 # ITC all-gathers (see _gather)
         self.t, self.graphs = {}, {}
         self.mode, self.error = "eager", None
         self.messages = 0                       # collectives issued per step (tests / diagnostics)
@@ -679,7 +696,7 @@ class MixedStep:
     way the optimizer sees the sum of the sub-iterations' gradients) and are averaged over the ranks ONCE, after the last one.
 
     Every part is a SegmentedStep of its own (own static inputs, own graphs and gradient buffers; the bf16 weight copies are
-    cast by the first part only and read by the others); after the last part ONE multi-tensor add folds the later parts'
+    re-cast inside every part's graphs); after the last part ONE multi-tensor add folds the later parts'
     gradients into the first part's static buffers, and - more than one rank - the first part's reduction plan runs: one
     message per layer arena, as for a single iteration.  p.grad of every parameter is a static tensor afterwards.
 
@@ -697,7 +714,10 @@ class MixedStep:
             self.steps.append(SegmentedStep(model, part["batch"], world=world, rank=rank, process_group=process_group, comm=comm,
                                             warmup=warmup, enabled=enabled, verbose=verbose,
                                             ret_bbox_loss=part.get("ret_bbox_loss", False), ret_match_loss=part.get("ret_match_loss", True),
-                                            recast_weights=(i == 0) and kw.get("recast_weights", True),
+                                            # every part re-casts inside its own graphs: a later part may use weights the first does
+                                            # not (bbox head after an image part), and a copy cached from a part's eager warm-up would
+                                            # never be refreshed after optimizer steps (0.4 ms per extra part)
+                                            recast_weights=kw.get("recast_weights", True),
                                             clamp_temp=(i == 0) and kw.get("clamp_temp", True),
                                             total_loss=(lambda losses, w=w: w * sum(losses.values())),
                                             reduce_grads=(i == 0), defer_reduce=True,

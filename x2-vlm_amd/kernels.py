@@ -73,6 +73,7 @@ def dropout_keep(spec, index):
 
 
 _WS = {}
+_WS_RETIRED = []
 
 
 def workspace(device, nfloats):
@@ -81,6 +82,8 @@ def workspace(device, nfloats):
     key = (device, raw_stream())
     buf = _WS.get(key)
     if buf is None or buf.numel() < nfloats:
+        if buf is not None:
+            _WS_RETIRED.append(buf)        # a captured hipGraph may have this address baked in: a retired buffer is never freed
         buf = torch.empty(max(nfloats, 1 << 22), device=device, dtype=F32)
         _WS[key] = buf
     return buf
