@@ -23,7 +23,7 @@ extern "C" {
 #endif
 
 const char* x2_last_error(void);
-int x2_abi_version(void);          /* == 8 */
+int x2_abi_version(void);          /* == 9 */
 int x2_device_cus(void);           /* compute units of the current HIP device, 0 if none */
 int x2_tune(int key, int value);   /* kernel-variant knobs for probes/ and tests (0 = automatic); keys listed in csrc/gemm.hip */
 
@@ -114,12 +114,15 @@ int x2_layernorm_fwd(const float* x, const float* w, const float* b, void* y_bf1
                      float* rstd, int rows, int D, float eps, int period, unsigned drop_thr16, unsigned drop_seed,
                      float drop_scale, const unsigned* drop_epoch, void* stream);   /* drop: dropout on the LN output (xbert.py:215) */
 /* g = LN'(mask_in(dy)); dx = dres + g (fp32); dx_bf16 = mask_out(g); dw += , db += ; dcol += column sums of mask_out(g)
- * (= gradient and bias gradient of the linear whose dropped output was added to the residual before this LN) */
+ * (= gradient and bias gradient of the linear whose dropped output was added to the residual before this LN).
+ * post != 0 (dy bf16, period 0, no output mask): the by-products describe the FINAL output instead - dx_bf16 =
+ * post_rowscale[row] * dx (post_rowscale NULL = 1), dcol += its column sums: what the layer scale below this LayerNorm needs
+ * of its incoming gradient (x2_layerscale_finish) */
 int x2_layernorm_bwd(const void* dy /* fp32, or bf16 when dy_is_bf16 */, int dy_is_bf16, const float* x, const float* mean, const float* rstd, const float* w,
                      const float* dres, float* dx, void* dx_bf16, float* dw, float* db, float* dcol, int rows, int D,
                      int period, unsigned in_thr16, unsigned in_seed, float in_scale, unsigned out_thr16,
                      unsigned out_seed, float out_scale, const unsigned* drop_epoch, float* ws /* [ceil(rows/16)][3][D] */,
-                     int defer, void* stream);
+                     int defer, int post, const float* post_rowscale, void* stream);
 /* Column reductions are two-stage (per-workgroup partial rows in the caller's workspace `ws`, then a deterministic
  * add): fp32 atomics measured ~43 G adds/s on MI355X, slower than the HBM traffic of these kernels. */
 int x2_colsum_bf16(const void* y, float* out, int M, int N, int ld, float* ws /* [ceil(M/64)][N] */, int defer, void* stream);
@@ -129,14 +132,21 @@ int x2_reduce_partials(const float* part, int nblk, int nk, int width, float* o0
 /* `count` such reductions in one launch (all parameter-gradient sums of one layer's backward), nk <= 4 here;
  * desc: count rows of 8 int64 {part, nblk, nk, width, o0, o1, o2, o3} (a null output skips that partial row) */
 int x2_reduce_partials_multi(const int64_t* desc, int count, void* stream);
-/* backward of x + gamma * u (beit2.py:206-207): du = gamma*dx (bf16), dgamma += sum dx*u, dbias += sum du */
-int x2_layerscale_bwd(const float* dx, const void* u, const float* gamma, void* du, float* dgamma, float* dbias,
-                      const float* rowscale, int M, int D, float* ws /* [ceil(M/32)][2][D] */, int defer, void* stream);
+/* backward of x + r[m] * gamma * u, u = A . W^T + b (beit2.py:206-207; r = DropPath factor or 1) without a pass over u: with
+ * dX' = r * dX the input gradient is dX' . (diag(gamma) W) (x2_cast_transpose_multi folds gamma into the W^T copy), the weight-
+ * gradient GEMM computes G = dX'^T . A, and x2_layerscale_finish turns G and cs = colsum(dX') into
+ *   dgamma += rowdot(G, W) + b * cs,  dbias += gamma * cs,  G <- diag(gamma) G  (= dW).
+ * desc: count rows of 9 int64 {G [N][K] fp32, W [N][K] fp32 master weight, b or 0, gamma, cs, dgamma, dbias or 0, N, K}.
+ * dX' (bf16) and cs come from x2_layernorm_bwd (post = 1) or from x2_rowscale_cast_colsum. */
+int x2_layerscale_finish(const int64_t* desc, int count, void* stream);
+int x2_rowscale_cast_colsum(const float* dx, const float* rowscale, void* dx_bf16, float* colsum, int M, int D,
+                            float* ws /* [ceil(M/32)][D] */, int defer, void* stream);
 int x2_cast_bf16(const float* src, void* dst, long n, void* stream);
 int x2_cast_transpose_bf16(const float* src, void* dst, void* dstT, int R, int C, int ldt, void* stream);
 /* bf16 (W, W^T) copies of many fp32 weights in one launch (what apex O1's per-call weight casts amount to, done once per
- * optimizer step): desc = count rows of 7 int64 {src, dst, dstT, R, C, ldt, roff}: src [R][C] fp32 -> rows roff.. of
- * dst [*][C] and columns roff.. of dstT [C][ldt]; R, C, ldt, roff multiples of 4 */
+ * optimizer step): desc = count rows of 8 int64 {src, dst, dstT, R, C, ldt, roff, tscale}: src [R][C] fp32 -> rows roff.. of
+ * dst [*][C] and columns roff.. of dstT [C][ldt]; R, C, ldt, roff multiples of 4; tscale (fp32 [R]) or 0: the transposed
+ * copy holds tscale[r] * src[r][c] (a layer scale folded into the weight of the input-gradient GEMM) */
 int x2_cast_transpose_multi(const int64_t* desc, int count, void* stream);
 /* many small fp32 vectors packed in one launch (stacked q/k/v biases): desc = count rows {src or 0 = zeros, dst, n} */
 int x2_copy_f32_multi(const int64_t* desc, int count, void* stream);

@@ -79,6 +79,9 @@ def test_gemm_nt_plain_and_epilogues(K, M, N, K_, nt_tile):
                     out_dtype=torch.float32)
     assert relerr(out, resid + gamma * (ref + bias)) < 1e-5
     assert relerr(aux, ref + bias) < 6e-3
+    # the step's own layer-scale form (compiled feature set 6): nothing saved, the backward needs no activation
+    out = K.gemm_nt(A.to(dev), B.to(dev), bias=bias.to(dev), gamma=gamma.to(dev), resid=resid.to(dev), out_dtype=torch.float32)
+    assert relerr(out, resid + gamma * (ref + bias)) < 1e-5
     # the compiled feature sets of the step that the calls above do not reach (they run the generic epilogue):
     # bias + GELU -> bf16, GELU' -> bf16, bias + residual -> fp32
     aux = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
@@ -150,8 +153,8 @@ def test_gemm_nt_256_column_kernel_matches_the_default_one(K, M, N, K_, tmw):
         if kind == "bias_drop_resid":
             return K.gemm_nt(A, B, bias=bias, resid=resid, out_dtype=torch.float32, drop=drop), aux
         if kind == "layerscale":
-            return K.gemm_nt(A, B, bias=bias, gamma=gamma, resid=resid, aux=aux, out_dtype=torch.float32), aux
-        return K.gemm_nt(A, B, bias=bias, gamma=gamma, resid=resid, aux=aux, out_dtype=torch.float32, rowscale=rowscale), aux
+            return K.gemm_nt(A, B, bias=bias, gamma=gamma, resid=resid, out_dtype=torch.float32), aux
+        return K.gemm_nt(A, B, bias=bias, gamma=gamma, resid=resid, out_dtype=torch.float32, rowscale=rowscale), aux
 
     try:
         for kind in ("bias_bf16", "bias_f32", "gelu", "dgelu", "bias_drop_resid", "layerscale", "layerscale_droppath"):
@@ -432,6 +435,15 @@ def test_layernorm(K, rows, D, period):
     dw2, db2, dcol = torch.zeros(D, device=dev), torch.zeros(D, device=dev), torch.zeros(D, device=dev)
     dx2, _ = K.layernorm_bwd(dy.to(dev), x.to(dev), mean, rstd, w.to(dev), dw2, db2, dcol=dcol, period=period)
     assert relerr(dcol, xl.grad[sel].sum(0)) < 5e-5 and relerr(dx2[sel], xl.grad[sel]) < 2e-5
+    if period == 0:
+        # by-products of the FINAL output for the layer scale below (post=): bf16(r * (dx + dres)) and its column sums
+        for rs in (None, (torch.rand(total, generator=torch.Generator().manual_seed(9)) > 0.2).float() * 1.25):
+            cs, dw3, db3 = torch.zeros(D, device=dev), torch.zeros(D, device=dev), torch.zeros(D, device=dev)
+            dx3, dx3b = K.layernorm_bwd(dyb.to(dev), x.to(dev), mean, rstd, w.to(dev), dw3, db3, dres=dres.to(dev),
+                                        post=(None if rs is None else rs.to(dev), cs))
+            want = (xl2.grad + dres) * (1.0 if rs is None else rs[:, None])
+            assert relerr(dx3, dxh.cpu()) < 1e-6 and relerr(dw3, dwb.cpu()) < 1e-6 and relerr(db3, dbb.cpu()) < 1e-6
+            assert relerr(dx3b, want) < 6e-3 and relerr(cs, want.sum(0)) < 2e-5
 
 
 def test_colsum_layerscale_casts(K):
@@ -439,15 +451,47 @@ def test_colsum_layerscale_casts(K):
     out = torch.zeros(768, device=dev)
     K.colsum_bf16(y.to(dev), out)
     assert relerr(out, y.float().sum(0)) < 1e-5
-    dx, u, gamma = rnd(500, 768, seed=2), bf(rnd(500, 768, seed=3)), rnd(768, seed=4)
-    dg, dbias = torch.zeros(768, device=dev), torch.zeros(768, device=dev)
-    du = K.layerscale_bwd(dx.to(dev), u.to(dev), gamma.to(dev), dg, dbias)
-    assert relerr(du, dx * gamma) < 6e-3
-    assert relerr(dg, (dx * u.float()).sum(0)) < 1e-5 and relerr(dbias, (dx * gamma).sum(0)) < 1e-5
+    dx = rnd(500, 768, seed=2)
+    for rs in (None, (torch.rand(500, generator=torch.Generator().manual_seed(3)) > 0.2).float() * 1.25):
+        cs = torch.zeros(768, device=dev)
+        dxb = K.rowscale_cast_colsum(dx.to(dev), cs, rowscale=None if rs is None else rs.to(dev))
+        want = dx if rs is None else dx * rs[:, None]
+        assert torch.equal(dxb.cpu(), bf(want)) and relerr(cs, want.sum(0)) < 1e-5
     w = rnd(300, 200, seed=5)
     assert torch.equal(K.cast_bf16(w.to(dev)).cpu(), bf(w))
     plain, tr = K.cast_transpose_bf16(w.to(dev), ldt=320)
     assert torch.equal(plain.cpu(), bf(w)) and torch.equal(tr[:, :300].cpu(), bf(w).t()) and float(tr[:, 300:].abs().max()) == 0
+
+
+@pytest.mark.parametrize("M,D,F", [(500, 768, 1024), (197, 128, 64), (1000, 256, 3072)])
+def test_layerscale_backward_without_activation(K, M, D, F):
+    """x_out = x_in + r * gamma * (A . W^T + b) (beit2.py:206-207 with DropPath): the pieces the vision backward runs - gamma folded
+    into the transposed weight copy, the weight-gradient GEMM on bf16(r * dX), x2_layerscale_finish - against autograd."""
+    eng = importlib.import_module("x2-vlm_amd.engine")
+    A, W, b, gamma = bf(rnd(M, F, seed=1)), rnd(D, F, seed=2, scale=F ** -0.5), rnd(D, seed=3), rnd(D, seed=4) * 0.3 + 0.1
+    dx = rnd(M, D, seed=5)
+    rs = (torch.rand(M, generator=torch.Generator().manual_seed(6)) > 0.2).double() * 1.25
+    Ad, Wd, bd, gd = (t.double().requires_grad_(True) for t in (A.float(), W, b, gamma))
+    ((rs[:, None] * gd * (Ad @ Wd.t() + bd)) * dx.double()).sum().backward()
+    Wp, gp = torch.nn.Parameter(W.to(dev)), torch.nn.Parameter(gamma.to(dev))
+    bank = eng.WeightBank()
+    bank.prepare([(Wp, eng.TScale(gp))])
+    plain, trs = bank.linear(Wp, tscale=gp)
+    assert len(bank._c) == 1 and torch.equal(plain.cpu(), bf(W)) and torch.equal(trs.cpu(), bf(W * gamma[:, None]).t())
+    cs, dg, db = torch.zeros(D, device=dev), torch.full((D,), 2.0, device=dev), torch.full((D,), 3.0, device=dev)
+    dxb = K.rowscale_cast_colsum(dx.to(dev), cs, rowscale=rs.float().to(dev))
+    dA = K.gemm_nt(dxb, trs, out_dtype=torch.float32)
+    G = torch.empty(D, F, device=dev)
+    K.gemm_tn_grouped([(dxb, A.to(dev), G)])
+    K.layerscale_finish([(G, Wp.detach(), b.to(dev), gp.detach(), cs, dg, db)])
+    torch.cuda.synchronize()
+    assert relerr(dA, Ad.grad) < 1e-2 and relerr(G, Wd.grad) < 6e-3
+    assert relerr(dg - 2.0, gd.grad) < 5e-3 and relerr(db - 3.0, bd.grad) < 1e-5
+    # stale-copy rule: a new gamma value (same storage) rebuilds the scaled copy on the next request after a version bump
+    with torch.no_grad():
+        gp.mul_(2.0)
+    _, trs2 = bank.linear(Wp, tscale=gp)
+    assert torch.equal(trs2.cpu(), bf(W * (2.0 * gamma)[:, None]).t())
 
 
 def test_multi_tensor_cast_and_reduce(K):

@@ -37,13 +37,14 @@ _SIGS = {
     "x2_attn_fwd": [C.POINTER(AttnArgs), P],
     "x2_attn_bwd": [C.POINTER(AttnArgs), P],
     "x2_layernorm_fwd": [P, P, P, P, P, P, P, I, I, F, I, U, U, F, P, P],
-    "x2_layernorm_bwd": [P, I, P, P, P, P, P, P, P, P, P, P, I, I, I, U, U, F, U, U, F, P, P, I, P],
+    "x2_layernorm_bwd": [P, I, P, P, P, P, P, P, P, P, P, P, I, I, I, U, U, F, U, U, F, P, P, I, I, P, P],
     "x2_colsum_bf16": [P, P, I, I, I, P, I, P],
     "x2_reduce_partials": [P, I, I, I, P, P, P, P],
     "x2_reduce_partials_multi": [P, I, P],
     "x2_cast_transpose_multi": [P, I, P],
     "x2_copy_f32_multi": [P, I, P],
-    "x2_layerscale_bwd": [P, P, P, P, P, P, P, I, I, P, I, P],
+    "x2_layerscale_finish": [P, I, P],
+    "x2_rowscale_cast_colsum": [P, P, P, P, I, I, P, I, P],
     "x2_cast_bf16": [P, P, L, P],
     "x2_cast_transpose_bf16": [P, P, P, I, I, I, P],
     "x2_patchify": [P, P, I, I, I, P],

@@ -78,7 +78,8 @@ __device__ __forceinline__ void st16(void* p, u32x4 v, bool wt) {
 //   3 x GELU'(saved pre-activation) -> bf16                     (input gradient through the GELU; its bias-gradient column
 //     sums are a separate two-stage kernel: fused as one atomic per column and wave they cost 30-50 us per launch)
 //   5 bias, (dropout), + residual -> fp32                       (BERT output projections, BERT input gradients)
-//   6 bias, layer scale (x DropPath row factor), value before the scale saved, + residual -> fp32   (BEiT proj / fc2)
+//   6 bias, layer scale (x DropPath row factor), + residual -> fp32   (BEiT proj / fc2; the value before the scale is NOT saved:
+//     the layer-scale backward needs no activation, rowwise.hip x2_layerscale_finish)
 //   4 everything decided at run time (any other combination)
 //   7 partial products of one contraction slice -> fp32 workspace (x2_gemm_nt_splitk; slice = blockIdx.y)
 //   8 bias, then per row and 64-column chunk (max, sum exp) + the logit at the label: softmax statistics, nothing stored
@@ -93,7 +94,7 @@ template <int V> struct EpiTraits {
   static constexpr bool out_f32 = V == 1 || V == 5 || V == 6 || V == 7;
   static constexpr bool resid = V == 5 || V == 6;
   static constexpr bool scale = V == 6;           // gamma and optional rowscale
-  static constexpr bool aux0 = V == 6;            // act == 0 with aux: save the value before the layer scale
+  static constexpr bool aux0 = false;             // act == 0 with aux (value before the layer scale saved): generic feature set only
   static constexpr bool drop = V == 5;            // dropout possible (still a runtime test on thr16, outside the hot variants)
   static constexpr bool colsum = false;
   static constexpr bool colparts = V == 10;       // column sums of the stored values as one partial row per wave row (no atomics)
@@ -256,8 +257,7 @@ __device__ __forceinline__ void nt_epilogue(const GemmNT& p, f32x4 (&acc)[TM][4]
 // nt_epilogue gives a lane 8 consecutive columns of one row; for fp32 outputs that is two 16-byte stores per lane whose
 // pieces interleave at a 32-byte stride: every store instruction half-fills 16 lines (8 rows x 2).  Here a lane takes 4
 // columns of TWO rows (r and r + 4): a store instruction writes 4 rows x 256 contiguous bytes = 8 full lines; the residual
-// is loaded the same way.  The bf16 side output of feature set 6 (value before the layer scale) becomes 8-byte stores
-// (16 lanes x 8 B = one full 128-byte line per row).  Feature sets 1, 5, 6 (the fp32-out ones), same arithmetic.
+// is loaded the same way.  Feature sets 1, 5, 6 (the fp32-out ones), same arithmetic.
 template <int TM, int VAR>
 __device__ __forceinline__ void nt_epilogue_f4(const GemmNT& p, f32x4 (&acc)[TM][4], char* smem, int wave, int lane, int mw0, int nw0) {
   using E = EpiTraits<VAR>;
@@ -303,10 +303,6 @@ __device__ __forceinline__ void nt_epilogue_f4(const GemmNT& p, f32x4 (&acc)[TM]
         const float4 a0 = *reinterpret_cast<const float4*>(stg + row * 68 + ec);
         if (m >= p.M || !nok) continue;
         float v[4] = {a0.x + bb[0], a0.y + bb[1], a0.z + bb[2], a0.w + bb[3]};
-        if (E::aux0) {
-          const u32x2 pk = u32x2{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])};
-          *reinterpret_cast<u32x2*>(p.aux + (size_t)m * p.ldaux + n) = pk;
-        }
         if (has_drop) {
           float dm[4];
           drop_mul4(drop_, (uint32_t)m * (uint32_t)p.N + (uint32_t)n, dm);
@@ -683,7 +679,7 @@ extern "C" int x2_gemm_nt(const void* A, const void* B, void* C, int M, int N, i
     else if (act == 2 && !out_f32 && !resid && plain) var = 3;
     else if (act == 0 && !aux && !resid && plain) var = out_f32 ? 1 : 0;
     else if (act == 0 && !aux && resid && out_f32 && !gamma && !rowscale && !colsum) var = 5;
-    else if (act == 0 && aux && resid && out_f32 && gamma && !drop_thr16 && !colsum) var = 6;
+    else if (act == 0 && !aux && resid && out_f32 && gamma && !drop_thr16 && !colsum) var = 6;
   }
   // 256-column kernel (gemm_nt256_kernel): [1] = 3 always (tile height from [3] = 5..8 or the plan), [1] = 1 never; the
   // generic feature set stays on the kernels above

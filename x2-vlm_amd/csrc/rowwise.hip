@@ -110,19 +110,22 @@ extern "C" int x2_reduce_partials(const float* part, int nblk, int nk, int width
 #define RPM_MAX 16
 struct ReduceDesc { const float* part; float* o[4]; int nblk, nk, width, blk0; };
 struct ReduceGroup { ReduceDesc d[RPM_MAX]; int count; };
-// Thread mapping: 16 column groups of 4 floats (one 64-column tile per workgroup) x 16 row slices; a thread walks the partial
-// rows b = slice, slice + 16, ... with 16-byte loads, four in flight; the 16 slices are added in a fixed order through LDS.
-// (The first form - 64 columns x 4 slices, 4-byte loads - moved 48 MB per launch at 1.1 TB/s: 42 us, on the critical path of
-// a single-stream hipGraph segment; this one reads the same bytes at the rate of a streaming kernel.)
+// Thread mapping: 4 column groups of 4 floats (one 16-column tile = one 64-byte segment per partial row and workgroup) x 64 row
+// slices; a thread walks the partial rows b = slice, slice + 64, ... with 16-byte loads, four in flight; the 64 slices are
+// added in a fixed order through LDS.  The reduction is a latency chain, not a bandwidth problem (a few MB per launch): what
+// counts is how few dependent load batches a thread issues and how many CUs take part - with 64-column tiles and 16 slices a
+// 788-row LayerNorm workspace was 12 batches deep on 36 workgroups (11.6 us for 7.3 MB; probes/bench_rowwise.py), this form is 3-4
+// batches on 144.
+#define RPM_COLS 16
 __global__ __launch_bounds__(256) void reduce_partials_multi_kernel(ReduceGroup g) {
   int e = 0;
 #pragma unroll
   for (int i = 1; i < RPM_MAX; ++i) if (i < g.count && (int)blockIdx.x >= g.d[i].blk0) e = i;
   const ReduceDesc d = g.d[e];
-  const int local = blockIdx.x - d.blk0, ctiles = (d.width + 63) / 64;
-  const int k = local / ctiles, cg = threadIdx.x & 15, sl = threadIdx.x >> 4;
-  const int c = (local % ctiles) * 64 + cg * 4;
-  __shared__ float4 red[15][16];
+  const int local = blockIdx.x - d.blk0, ctiles = (d.width + RPM_COLS - 1) / RPM_COLS;
+  const int k = local / ctiles, cg = threadIdx.x & 3, sl = threadIdx.x >> 2;
+  const int c = (local % ctiles) * RPM_COLS + cg * 4;
+  __shared__ float4 red[63][4];
   float4 s = float4{0.f, 0.f, 0.f, 0.f};
   float* o = d.o[k];
   const bool vec = (d.width & 3) == 0;                  // every row 16-byte aligned (the workspaces are)
@@ -131,18 +134,18 @@ __global__ __launch_bounds__(256) void reduce_partials_multi_kernel(ReduceGroup 
     const size_t rs = (size_t)d.nk * d.width;
     if (vec) {
       int b = sl;
-      for (; b + 48 < d.nblk; b += 64) {
-        const float4 v0 = *reinterpret_cast<const float4*>(base + (size_t)b * rs), v1 = *reinterpret_cast<const float4*>(base + (size_t)(b + 16) * rs),
-                     v2 = *reinterpret_cast<const float4*>(base + (size_t)(b + 32) * rs), v3 = *reinterpret_cast<const float4*>(base + (size_t)(b + 48) * rs);
+      for (; b + 192 < d.nblk; b += 256) {
+        const float4 v0 = *reinterpret_cast<const float4*>(base + (size_t)b * rs), v1 = *reinterpret_cast<const float4*>(base + (size_t)(b + 64) * rs),
+                     v2 = *reinterpret_cast<const float4*>(base + (size_t)(b + 128) * rs), v3 = *reinterpret_cast<const float4*>(base + (size_t)(b + 192) * rs);
         s.x += (v0.x + v1.x) + (v2.x + v3.x); s.y += (v0.y + v1.y) + (v2.y + v3.y);
         s.z += (v0.z + v1.z) + (v2.z + v3.z); s.w += (v0.w + v1.w) + (v2.w + v3.w);
       }
-      for (; b < d.nblk; b += 16) {
+      for (; b < d.nblk; b += 64) {
         const float4 v = *reinterpret_cast<const float4*>(base + (size_t)b * rs);
         s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
       }
     } else {
-      for (int b = sl; b < d.nblk; b += 16) {
+      for (int b = sl; b < d.nblk; b += 64) {
         const float* r = base + (size_t)b * rs;
         s.x += r[0]; if (c + 1 < d.width) s.y += r[1]; if (c + 2 < d.width) s.z += r[2]; if (c + 3 < d.width) s.w += r[3];
       }
@@ -151,8 +154,8 @@ __global__ __launch_bounds__(256) void reduce_partials_multi_kernel(ReduceGroup 
   if (sl > 0) red[sl - 1][cg] = s;
   __syncthreads();
   if (sl == 0 && o && c < d.width) {
-#pragma unroll
-    for (int i = 0; i < 15; ++i) { const float4 v = red[i][cg]; s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
+#pragma unroll 9
+    for (int i = 0; i < 63; ++i) { const float4 v = red[i][cg]; s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
     o[c] += s.x;
     if (c + 1 < d.width) o[c + 1] += s.y;
     if (c + 2 < d.width) o[c + 2] += s.z;
@@ -172,7 +175,7 @@ extern "C" int x2_reduce_partials_multi(const int64_t* desc, int count, void* st
       X2_REQUIRE(d.part && d.nblk > 0 && d.nk >= 1 && d.nk <= 4 && d.width > 0, "x2_reduce_partials_multi[%d]: nblk=%d nk=%d width=%d",
                  i0 + i, d.nblk, d.nk, d.width);
       d.blk0 = blocks;
-      blocks += ((d.width + 63) / 64) * d.nk;
+      blocks += ((d.width + RPM_COLS - 1) / RPM_COLS) * d.nk;
     }
     hipLaunchKernelGGL(reduce_partials_multi_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g);
   }
@@ -191,13 +194,18 @@ extern "C" int x2_reduce_partials_multi(const int64_t* desc, int count, void* st
 // (A variant that also did the layer-scale backward its output feeds - x2_layernorm_bwd_layerscale, rounds 3-4 - saved a 38.7 MB read per
 // vision block but needed 156 VGPRs (3 waves per SIMD): 25.16 vs 24.92 ms per base step; with LDS atomics at 128 VGPRs 25.22 vs 23.58;
 // forced to 128 VGPRs with 29 spilled dwords 24.05-24.17 vs 23.59-23.62 (profiles/r05j_fused_ln_layerscale_ab.txt).  Removed.)
-template <int NV, bool DYB>
+// MODE 0: dy fp32; 1: dy bf16; 2: dy bf16 and the by-products refer to the FINAL output times a per-row factor: the bf16 copy is
+// post_rs[row] * (dx + dres) and the third partial row its column sums - what the layer scale BELOW this LayerNorm needs of
+// its incoming gradient (x2_layerscale_finish; post_rs = DropPath factor of that branch or null).
+template <int NV, int MODE>
 __global__ __launch_bounds__(256, NV <= 3 ? 4 : 1) void layernorm_bwd_kernel(const void* __restrict__ dy_, const float* __restrict__ x,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
                                                             const float* __restrict__ w, const float* dres, float* dx, bf16_t* dxb,
                                                             float* ws, int rows, int D, int period,
-                                                            DropSpec din_, DropSpec dout_, const uint32_t* __restrict__ epoch) {
+                                                            DropSpec din_, DropSpec dout_, const uint32_t* __restrict__ epoch,
+                                                            const float* __restrict__ post_rs) {
   constexpr int NSET = 3;
+  constexpr bool DYB = MODE != 0;
   extern __shared__ __attribute__((aligned(16))) float red[];      // [NSET][3 waves][D]
   const DropSpec din = drop_at_epoch(din_, epoch), dout = drop_at_epoch(dout_, epoch);
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -254,9 +262,10 @@ __global__ __launch_bounds__(256, NV <= 3 ? 4 : 1) void layernorm_bwd_kernel(con
           drop_mul4(dout, (uint32_t)gr * (uint32_t)D + (uint32_t)(c * 4), dm);
           om.x *= dm[0]; om.y *= dm[1]; om.z *= dm[2]; om.w *= dm[3];
         }
-        ac[i].x += om.x; ac[i].y += om.y; ac[i].z += om.z; ac[i].w += om.w;
         if (dres) { const float4 rr = *reinterpret_cast<const float4*>(dres + gr * D + c * 4); o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w; }
         if (dx) *reinterpret_cast<float4*>(dx + gr * D + c * 4) = o;
+        if constexpr (MODE == 2) { om = o; if (post_rs) { const float f = post_rs[gr]; om.x *= f; om.y *= f; om.z *= f; om.w *= f; } }
+        ac[i].x += om.x; ac[i].y += om.y; ac[i].z += om.z; ac[i].w += om.w;
         if (dxb) *reinterpret_cast<u32x2*>(dxb + gr * D + c * 4) = u32x2{pack_bf16(om.x, om.y), pack_bf16(om.z, om.w)};
       }
     }
@@ -299,15 +308,18 @@ __global__ __launch_bounds__(256, NV <= 3 ? 4 : 1) void layernorm_bwd_kernel(con
 extern "C" int x2_layernorm_bwd(const void* dy, int dy_is_bf16, const float* x, const float* mean, const float* rstd, const float* w,
                                 const float* dres, float* dx, void* dx_bf16, float* dw, float* db, float* dcol, int rows, int D,
                                 int period, unsigned in_thr16, unsigned in_seed, float in_scale, unsigned out_thr16,
-                                unsigned out_seed, float out_scale, const unsigned* drop_epoch, float* ws, int defer, void* stream) {
+                                unsigned out_seed, float out_scale, const unsigned* drop_epoch, float* ws, int defer, int post,
+                                const float* post_rowscale, void* stream) {
   X2_REQUIRE(rows > 0 && D > 0 && D % 4 == 0 && D <= 256 * LN_MAXV, "x2_layernorm_bwd: rows=%d D=%d", rows, D);
   X2_REQUIRE(dw && db && ws, "x2_layernorm_bwd: dw/db and the workspace ws[ceil(rows/%d)*3*D] are required", LNB_ROWS);
-  X2_REQUIRE(!(dcol && dres), "x2_layernorm_bwd: dcol sums the LN-input gradient, which excludes dres");
+  X2_REQUIRE(post || !(dcol && dres), "x2_layernorm_bwd: dcol sums the LN-input gradient, which excludes dres (post = 0)");
   X2_REQUIRE(!(out_thr16 && dres), "x2_layernorm_bwd: an output mask applies to the bf16 copy, which excludes dres");
+  X2_REQUIRE(!post || (dy_is_bf16 && dx_bf16 && dcol && !out_thr16 && period == 0),
+             "x2_layernorm_bwd: post = 1 (by-products of the final output) takes a bf16 dy, dx_bf16 and dcol, no output mask, period 0");
 #define X2_LNB_T(NV, B) hipLaunchKernelGGL((layernorm_bwd_kernel<NV, B>), dim3((rows + LNB_ROWS - 1) / LNB_ROWS), dim3(256), 9 * D * sizeof(float), \
                      (hipStream_t)stream, dy, x, mean, rstd, w, dres, dx, (bf16_t*)dx_bf16, ws, rows, D, period,                \
-                     DropSpec{in_thr16, in_seed, in_scale}, DropSpec{out_thr16, out_seed, out_scale}, drop_epoch)
-#define X2_LNB(NV) do { if (dy_is_bf16) X2_LNB_T(NV, true); else X2_LNB_T(NV, false); } while (0)
+                     DropSpec{in_thr16, in_seed, in_scale}, DropSpec{out_thr16, out_seed, out_scale}, drop_epoch, post_rowscale)
+#define X2_LNB(NV) do { if (post) X2_LNB_T(NV, 2); else if (dy_is_bf16) X2_LNB_T(NV, 1); else X2_LNB_T(NV, 0); } while (0)
   LN_DISPATCH(D, X2_LNB);
   if (!defer) launch_reduce(ws, (rows + LNB_ROWS - 1) / LNB_ROWS, 3, D, dw, db, dcol, (hipStream_t)stream);
   return x2_check_launch("x2_layernorm_bwd");
@@ -354,50 +366,104 @@ extern "C" int x2_colsum_bf16(const void* y, float* out, int M, int N, int ld, f
 }
 
 // ---------------------------------------------------------------------------------- layer-scale backward
-// forward was  x_out = x_in + gamma * u  (u = aux, bf16).  Given dX (fp32):  dU = gamma * dX (bf16),
-// dgamma[n] += sum_m dX*u,  dbias[n] += sum_m dU.  Workgroup = 256 columns x LS_ROWS rows (64 lanes x 4
-// columns, 4 waves down), waves combined through LDS, one atomic per column per workgroup.
+// forward was  x_out = x_in + r[m] * gamma * u,  u = A . W^T + b  (r = DropPath row factor or 1).  With dX' = r[m] * dX (fp32):
+//   dA     = (gamma * dX') . W        = dX' . (diag(gamma) W)      the GEMM reads a weight copy with gamma folded in (cast_transpose_multi)
+//   dW     = (gamma * dX')^T . A      = diag(gamma) G,  G = dX'^T . A   the weight-gradient GEMM runs on dX' itself
+//   db     = gamma * colsum(dX')
+//   dgamma = sum_m dX' * u            = rowdot(G, W) + b * colsum(dX')   (u = A . W^T + b substituted: no pass over activations)
+// so the backward needs from the [M, D] tensors only a bf16 copy of dX' and its column sums - both by-products of the
+// LayerNorm backward that produces dX (MODE 2 there) - and x2_layerscale_finish, a pass over the [D, K] weight gradient.
+// Against the kernel this replaces (dU = gamma * dX as a separate pass over dX and the saved u): 77 MB less traffic per layer scale
+// in the backward and no 19 MB side output `u` from the forward GEMM (X2VLM-base, 12608 x 768).
+//
+// x2_rowscale_cast_colsum: the same two by-products from a stand-alone pass, for a dX that no LayerNorm backward of this stage
+// produced (top of a tower / of a chunk of blocks).  Workgroup = 256 columns x LS_ROWS rows, partial rows ws[blk][D].
 #define LS_ROWS 32
-__global__ __launch_bounds__(256) void layerscale_bwd_kernel(const float* __restrict__ dx, const bf16_t* __restrict__ u,
-                                                             const float* __restrict__ gamma, bf16_t* du, float* ws,
-                                                             const float* __restrict__ rowscale, int M, int D) {
-  __shared__ float red[2][3][256];
+__global__ __launch_bounds__(256) void rowscale_cast_colsum_kernel(const float* __restrict__ dx, const float* __restrict__ rowscale,
+                                                                   bf16_t* dxb, float* ws, int M, int D) {
+  __shared__ float red[3][256];
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const int c0 = blockIdx.y * 256 + tx * 4;
   const int r0 = blockIdx.x * LS_ROWS, r1 = min(M, r0 + LS_ROWS);
-  float ag[4] = {0.f, 0.f, 0.f, 0.f}, ab[4] = {0.f, 0.f, 0.f, 0.f};
+  float ab[4] = {0.f, 0.f, 0.f, 0.f};
   if (c0 < D) {
-    const float4 gm = *reinterpret_cast<const float4*>(gamma + c0);
+#pragma unroll 4
     for (int r = r0 + ty; r < r1; r += 4) {
       float4 d = *reinterpret_cast<const float4*>(dx + (long)r * D + c0);
       if (rowscale) { const float rs_ = rowscale[r]; d.x *= rs_; d.y *= rs_; d.z *= rs_; d.w *= rs_; }   // DropPath keep/(1-p)
-      const u32x2 uu = *reinterpret_cast<const u32x2*>(u + (long)r * D + c0);
-      const float o0 = d.x * gm.x, o1 = d.y * gm.y, o2 = d.z * gm.z, o3 = d.w * gm.w;
-      *reinterpret_cast<u32x2*>(du + (long)r * D + c0) = u32x2{pack_bf16(o0, o1), pack_bf16(o2, o3)};
-      ag[0] += d.x * bf_lo(uu[0]); ag[1] += d.y * bf_hi(uu[0]); ag[2] += d.z * bf_lo(uu[1]); ag[3] += d.w * bf_hi(uu[1]);
-      ab[0] += o0; ab[1] += o1; ab[2] += o2; ab[3] += o3;
+      *reinterpret_cast<u32x2*>(dxb + (long)r * D + c0) = u32x2{pack_bf16(d.x, d.y), pack_bf16(d.z, d.w)};
+      ab[0] += d.x; ab[1] += d.y; ab[2] += d.z; ab[3] += d.w;
     }
   }
   if (ty > 0) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { red[0][ty - 1][tx * 4 + e] = ag[e]; red[1][ty - 1][tx * 4 + e] = ab[e]; }
+    for (int e = 0; e < 4; ++e) red[ty - 1][tx * 4 + e] = ab[e];
   }
   __syncthreads();
   if (ty == 0 && c0 < D) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      ws[((long)blockIdx.x * 2 + 0) * D + c0 + e] = ag[e] + red[0][0][tx * 4 + e] + red[0][1][tx * 4 + e] + red[0][2][tx * 4 + e];
-      ws[((long)blockIdx.x * 2 + 1) * D + c0 + e] = ab[e] + red[1][0][tx * 4 + e] + red[1][1][tx * 4 + e] + red[1][2][tx * 4 + e];
-    }
+    for (int e = 0; e < 4; ++e) ws[(long)blockIdx.x * D + c0 + e] = ab[e] + red[0][tx * 4 + e] + red[1][tx * 4 + e] + red[2][tx * 4 + e];
   }
 }
-extern "C" int x2_layerscale_bwd(const float* dx, const void* u, const float* gamma, void* du, float* dgamma, float* dbias,
-                                 const float* rowscale, int M, int D, float* ws, int defer, void* stream) {
-  X2_REQUIRE(M > 0 && D > 0 && D % 4 == 0 && ws, "x2_layerscale_bwd: M=%d D=%d (workspace ws[ceil(M/%d)*2*D] required)", M, D, LS_ROWS);
-  hipLaunchKernelGGL(layerscale_bwd_kernel, dim3((M + LS_ROWS - 1) / LS_ROWS, (D + 255) / 256), dim3(256), 0, (hipStream_t)stream, dx,
-                     (const bf16_t*)u, gamma, (bf16_t*)du, ws, rowscale, M, D);
-  if (!defer) launch_reduce(ws, (M + LS_ROWS - 1) / LS_ROWS, 2, D, dgamma, dbias, nullptr, (hipStream_t)stream);
-  return x2_check_launch("x2_layerscale_bwd");
+extern "C" int x2_rowscale_cast_colsum(const float* dx, const float* rowscale, void* dx_bf16, float* colsum, int M, int D, float* ws,
+                                       int defer, void* stream) {
+  X2_REQUIRE(dx && dx_bf16 && colsum && M > 0 && D > 0 && D % 4 == 0 && ws,
+             "x2_rowscale_cast_colsum: M=%d D=%d (workspace ws[ceil(M/%d)*D] required)", M, D, LS_ROWS);
+  hipLaunchKernelGGL(rowscale_cast_colsum_kernel, dim3((M + LS_ROWS - 1) / LS_ROWS, (D + 255) / 256), dim3(256), 0, (hipStream_t)stream, dx,
+                     rowscale, (bf16_t*)dx_bf16, ws, M, D);
+  if (!defer) launch_reduce(ws, (M + LS_ROWS - 1) / LS_ROWS, 1, D, colsum, nullptr, nullptr, (hipStream_t)stream);
+  return x2_check_launch("x2_rowscale_cast_colsum");
+}
+
+// One wave per row n of a [N, K] weight gradient G = dX'^T . A (as the TN GEMM left it):
+//   dgamma[n] += rowdot(G[n], W[n]) + bias[n] * cs[n];   dbias[n] += gamma[n] * cs[n];   G[n][:] *= gamma[n]
+// desc rows of 9 int64: {G, W, bias or 0, gamma, cs, dgamma, dbias or 0, N, K}; W the fp32 master weight; K % 4 == 0.
+#define LSF_MAX 8
+struct LsfDesc { float* G; const float* W; const float* bias; const float* gamma; const float* cs; float* dgamma; float* dbias; int N, K, blk0; };
+struct LsfGroup { LsfDesc d[LSF_MAX]; int count; };
+__global__ __launch_bounds__(256) void layerscale_finish_kernel(LsfGroup g) {
+  int e = 0;
+#pragma unroll
+  for (int i = 1; i < LSF_MAX; ++i) if (i < g.count && (int)blockIdx.x >= g.d[i].blk0) e = i;
+  const LsfDesc d = g.d[e];
+  const int n = (blockIdx.x - d.blk0) * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (n >= d.N) return;
+  float* gr = d.G + (size_t)n * d.K;
+  const float* wr = d.W + (size_t)n * d.K;
+  const float gm = d.gamma[n];
+  float dot = 0.f;
+  for (int k = lane * 4; k < d.K; k += 256) {
+    float4 gv = *reinterpret_cast<const float4*>(gr + k);
+    const float4 wv = *reinterpret_cast<const float4*>(wr + k);
+    dot += gv.x * wv.x + gv.y * wv.y + gv.z * wv.z + gv.w * wv.w;
+    gv.x *= gm; gv.y *= gm; gv.z *= gm; gv.w *= gm;
+    *reinterpret_cast<float4*>(gr + k) = gv;
+  }
+  dot = wave_sum(dot);
+  if (lane == 0) {
+    const float c = d.cs[n];
+    d.dgamma[n] += dot + (d.bias ? d.bias[n] * c : 0.f);
+    if (d.dbias) d.dbias[n] += gm * c;
+  }
+}
+extern "C" int x2_layerscale_finish(const int64_t* desc, int count, void* stream) {
+  X2_REQUIRE(desc && count >= 1, "x2_layerscale_finish: count=%d", count);
+  for (int i0 = 0; i0 < count; i0 += LSF_MAX) {
+    LsfGroup g; g.count = count - i0 < LSF_MAX ? count - i0 : LSF_MAX;
+    int blocks = 0;
+    for (int i = 0; i < g.count; ++i) {
+      const int64_t* q = desc + (size_t)(i0 + i) * 9;
+      LsfDesc& d = g.d[i];
+      d.G = (float*)q[0]; d.W = (const float*)q[1]; d.bias = (const float*)q[2]; d.gamma = (const float*)q[3]; d.cs = (const float*)q[4];
+      d.dgamma = (float*)q[5]; d.dbias = (float*)q[6]; d.N = (int)q[7]; d.K = (int)q[8];
+      X2_REQUIRE(d.G && d.W && d.gamma && d.cs && d.dgamma && d.N > 0 && d.K > 0 && d.K % 4 == 0, "x2_layerscale_finish[%d]: N=%d K=%d", i0 + i,
+                 d.N, d.K);
+      d.blk0 = blocks;
+      blocks += (d.N + 3) / 4;
+    }
+    hipLaunchKernelGGL(layerscale_finish_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g);
+  }
+  return x2_check_launch("x2_layerscale_finish");
 }
 
 // ---------------------------------------------------------------------------------- casts
@@ -466,9 +532,11 @@ extern "C" int x2_cast_transpose_bf16(const float* src, void* dst, void* dstT, i
 // The bf16 copies of MANY fp32 weights in one launch (all linears of a tower: once per optimizer step).  Entry i
 // casts src_i [R_i][C_i] into rows roff_i.. of a bf16 matrix dst [*][C_i] and into columns roff_i.. of the transposed
 // bf16 matrix dstT [C_i][ldt_i], so weights that are used stacked (q/k/v) need no concatenation pass.
-// desc rows of 7 int64: {src, dst, dstT, R, C, ldt, roff}; R, C, ldt, roff multiples of 4.
+// desc rows of 8 int64: {src, dst, dstT, R, C, ldt, roff, tscale}; R, C, ldt, roff multiples of 4.  tscale (fp32 [R] or 0): the
+// TRANSPOSED copy holds tscale[r] * src[r][c] - a BEiT layer scale folded into the weight its input-gradient GEMM reads
+// (dA = (gamma * dX) . W = dX . (diag(gamma) W): the backward then never forms gamma * dX; x2_layerscale_finish).
 #define CTM_MAX 48
-struct CastDesc { const float* s; bf16_t* d; bf16_t* dT; int R, C, ldt, blk0; };
+struct CastDesc { const float* s; bf16_t* d; bf16_t* dT; const float* sc; int R, C, ldt, blk0; };
 struct CastGroup { CastDesc e[CTM_MAX]; int count; };
 __global__ __launch_bounds__(256) void cast_transpose_multi_kernel(CastGroup g) {
   __shared__ float tile[64][65];
@@ -486,6 +554,7 @@ __global__ __launch_bounds__(256) void cast_transpose_multi_kernel(CastGroup g) 
       v = *reinterpret_cast<const float4*>(d.s + (long)r * d.C + c);
       *reinterpret_cast<u32x2*>(d.d + (long)r * d.C + c) = u32x2{pack_bf16(v.x, v.y), pack_bf16(v.z, v.w)};
     }
+    if (d.sc && r < d.R) { const float f = d.sc[r]; v.x *= f; v.y *= f; v.z *= f; v.w *= f; }
     tile[ty + 16 * i][tx * 4 + 0] = v.x; tile[ty + 16 * i][tx * 4 + 1] = v.y;
     tile[ty + 16 * i][tx * 4 + 2] = v.z; tile[ty + 16 * i][tx * 4 + 3] = v.w;
   }
@@ -505,7 +574,7 @@ extern "C" int x2_cast_transpose_multi(const int64_t* desc, int count, void* str
     CastGroup g; g.count = count - i0 < CTM_MAX ? count - i0 : CTM_MAX;
     int blocks = 0;
     for (int i = 0; i < g.count; ++i) {
-      const int64_t* q = desc + (size_t)(i0 + i) * 7;
+      const int64_t* q = desc + (size_t)(i0 + i) * 8;
       CastDesc& d = g.e[i];
       d.R = (int)q[3]; d.C = (int)q[4]; d.ldt = (int)q[5];
       const int roff = (int)q[6];
@@ -514,6 +583,7 @@ extern "C" int x2_cast_transpose_multi(const int64_t* desc, int count, void* str
       d.s = (const float*)q[0];
       d.d = (bf16_t*)q[1] + (size_t)roff * d.C;
       d.dT = (bf16_t*)q[2] + roff;
+      d.sc = (const float*)q[7];
       d.blk0 = blocks;
       blocks += ((d.R + 63) / 64) * ((d.C + 63) / 64);
     }

@@ -38,6 +38,13 @@ def _tok(w):
     return t
 
 
+class TScale:
+    """Marks the scale vector of a (weight, TScale(gamma)) group handed to WeightBank.prepare."""
+
+    def __init__(self, g):
+        self.g = g
+
+
 class WeightBank:
     """bf16 (and transposed bf16) copies of the fp32 master weights.
 
@@ -73,17 +80,23 @@ class WeightBank:
         for k in dead:
             del self._c[k]
 
-    def linear(self, *ws):
-        """(W [N,K] bf16, W^T [K,N] bf16) of one weight or of several stacked along N."""
+    def linear(self, *ws, tscale=None):
+        """(W [N,K] bf16, W^T [K,N] bf16) of one weight or of several stacked along N.  tscale (fp32 [N] parameter): the
+        TRANSPOSED copy holds tscale[n] * W[n, k] - a layer scale folded into the weight its input-gradient GEMM reads
+        (rowwise.hip, layer-scale backward); the plain copy is W."""
         self._maybe_expire()
-        key = tuple(_tok(w) for w in ws)
-        vers = tuple((w._version, w.data_ptr()) for w in ws)
+        key = tuple(_tok(w) for w in ws) + ((("ts", _tok(tscale)),) if tscale is not None else ())
+        own = ws + ((tscale,) if tscale is not None else ())
+        vers = tuple((w._version, w.data_ptr()) for w in own)
 
         def build():
             w2 = [w.detach().reshape(w.shape[0], -1) for w in ws]
             src = w2[0] if len(w2) == 1 else torch.cat(w2, 0)
-            return K.cast_transpose_bf16(src.contiguous())
-        return self._get(key, vers, build, ws)
+            plain, tr = K.cast_transpose_bf16(src.contiguous())
+            if tscale is not None:
+                tr = K.cast_transpose_bf16((src * tscale.detach().reshape(-1, 1)).contiguous())[1]
+            return plain, tr
+        return self._get(key, vers, build, own)
 
     def prepare(self, groups):
         """Build every stale (W, W^T) pair of `groups` (tuples of weights, as `linear` takes them) with ONE
@@ -93,8 +106,13 @@ class WeightBank:
         self._purge()
         todo = []
         for ws in groups:
-            key = tuple(_tok(w) for w in ws)
-            vers = tuple((w._version, w.data_ptr()) for w in ws)
+            sc = None
+            if isinstance(ws[-1], TScale):                 # (weight, TScale(gamma)): see `linear(w, tscale=gamma)`
+                assert len(ws) == 2
+                sc, ws = ws[1].g, ws[:1]
+            key = tuple(_tok(w) for w in ws) + ((("ts", _tok(sc)),) if sc is not None else ())
+            own = tuple(ws) + ((sc,) if sc is not None else ())
+            vers = tuple((w._version, w.data_ptr()) for w in own)
             ent = self._c.get(key)
             if ent is not None and ent[0] == vers:
                 continue
@@ -102,21 +120,23 @@ class WeightBank:
             C_ = shapes[0][1]
             if any(c != C_ or (r | c) & 3 or w.dtype != F32 or not w.is_contiguous() for (r, c), w in zip(shapes, ws)):
                 continue                                   # left to the one-at-a-time path of `linear`
-            todo.append((key, vers, ws, sum(r for r, _ in shapes), C_))
+            if sc is not None and (sc.dtype != F32 or not sc.is_contiguous() or sc.numel() != shapes[0][0]):
+                continue
+            todo.append((key, vers, ws, sum(r for r, _ in shapes), C_, sc, own))
         if not todo:
             return
-        total = sum(2 * R * C_ for _, _, _, R, C_ in todo)
+        total = sum(2 * t[3] * t[4] for t in todo)
         flat = torch.empty(total, device=todo[0][2][0].device, dtype=BF16)
         desc, o = [], 0
-        for key, vers, ws, R, C_ in todo:
+        for key, vers, ws, R, C_, sc, own in todo:
             plain = flat[o:o + R * C_].view(R, C_)
             tr = flat[o + R * C_:o + 2 * R * C_].view(C_, R)
             o += 2 * R * C_
             roff = 0
             for w in ws:
-                desc.append((w.data_ptr(), plain.data_ptr(), tr.data_ptr(), w.shape[0], C_, R, roff))
+                desc.append((w.data_ptr(), plain.data_ptr(), tr.data_ptr(), w.shape[0], C_, R, roff, 0 if sc is None else sc.data_ptr()))
                 roff += w.shape[0]
-            self._c[key] = (vers, (plain, tr), tuple(weakref.ref(w) for w in ws))
+            self._c[key] = (vers, (plain, tr), tuple(weakref.ref(w) for w in own))
         K.cast_transpose_multi(desc)
 
     def prepare_vectors(self, groups):
@@ -331,18 +351,22 @@ class _LayerPairs:
     def __init__(self):
         self.pending = []
         self.extra = []
+        self.fin = []
 
-    def add(self, G, tn, param_only=()):
+    def add(self, G, tn, param_only=(), finish=()):
         """param_only: closures of further parameter-gradient-only kernels of this layer (bias column sums, the bias-table
         gradient), handed over only while WGRAD_QUEUE collects: they then run with the deferred work, off the input-gradient
-        chain's stream.  They must write through aliases (Tensor.detach()) of the arena views, see _launch."""
+        chain's stream.  They must write through aliases (Tensor.detach()) of the arena views, see _launch.
+        finish: K.layerscale_finish items of this layer: run behind its weight-gradient GEMMs (and the stage-2 reductions that
+        complete their column sums)."""
         deferred, K.DEFERRED = K.DEFERRED, None
         if len(tn) > 4 or not self.enabled:
             self.flush()
-            self._launch([(G, tn, deferred)], list(param_only))
+            self._launch([(G, tn, deferred)], list(param_only), list(finish))
             return
         self.pending.append((G, tn, deferred))
         self.extra += list(param_only)
+        self.fin += list(finish)
         if len(self.pending) == 2:
             self.flush()
 
@@ -350,10 +374,11 @@ class _LayerPairs:
         if self.pending:
             entries, self.pending = self.pending, []
             extra, self.extra = self.extra, []
-            self._launch(entries, extra)
+            fin, self.fin = self.fin, []
+            self._launch(entries, extra, fin)
 
     @staticmethod
-    def _launch(entries, extra=()):
+    def _launch(entries, extra=(), fin=()):
         deferred = [d for _, _, ds in entries for d in (ds or ())]
         tn = [pr for _, t, _ in entries for pr in t]
 
@@ -361,6 +386,8 @@ class _LayerPairs:
             if deferred:
                 K.reduce_partials_multi(deferred)
             K.gemm_tn_grouped(tn)
+            if fin:
+                K.layerscale_finish(fin)
         if WGRAD_QUEUE is not None:
             # the caller (graph.SegmentedStep) runs this layer's parameter-gradient work later, in a segment of its own on another
             # stream: the closure keeps the operands alive; the gradient views autograd receives now are filled then.  It must
@@ -368,6 +395,7 @@ class _LayerPairs:
             # references it, and would otherwise store a copy of the still empty arena): fresh aliases of the same memory instead.
             tn_a = [tuple(pr[:2]) + (pr[2].detach(),) + tuple(pr[3:]) for pr in tn]
             def_a = [(ws, nblk, nk, width, tuple(None if o is None else o.detach() for o in outs)) for ws, nblk, nk, width, outs in deferred]
+            fin_a = [tuple(t.detach() if (torch.is_tensor(t) and not isinstance(t, torch.nn.Parameter)) else t for t in it) for it in fin]
             pubs = [(G.flat, G.key, list(G.params)) for G, _, _ in entries]
 
             extra = list(extra)
@@ -378,6 +406,8 @@ class _LayerPairs:
                 if def_a:
                     K.reduce_partials_multi(def_a)
                 K.gemm_tn_grouped(tn_a)
+                if fin_a:
+                    K.layerscale_finish(fin_a)
                 if GRAD_READY_HOOK is not None:
                     for flat, key, params in pubs:
                         GRAD_READY_HOOK(flat, key, None, params)
@@ -487,8 +517,11 @@ class VisionEncoderFn(torch.autograd.Function):
         M = B * T
         assert D == 64 * H, "vision width %d / %d heads: the attention kernels are built for head dim 64" % (D, H)
         scale = (D // H) ** -0.5
+        # proj / fc2: the transposed copies (input-gradient GEMMs) carry the layer scale, see the backward
         BANK.prepare(([(p["patch_embed.proj.weight"],)] if stem else []) +
-                     [(p["blocks.%d.%s.weight" % (i, n)],) for i in range(lo, hi) for n in ("attn.qkv", "attn.proj", "mlp.fc1", "mlp.fc2")])
+                     [(p["blocks.%d.%s.weight" % (i, n)],) for i in range(lo, hi) for n in ("attn.qkv", "mlp.fc1")] +
+                     [(p["blocks.%d.%s.weight" % (i, n)], TScale(p["blocks.%d.%s" % (i, g_)])) for i in range(lo, hi)
+                      for n, g_ in (("attn.proj", "gamma_1"), ("mlp.fc2", "gamma_2"))])
         BANK.prepare_vectors([(p["blocks.%d.attn.q_bias" % i], D, p["blocks.%d.attn.v_bias" % i]) for i in range(lo, hi)])
         cols = None
         if stem:
@@ -512,19 +545,15 @@ class VisionEncoderFn(torch.autograd.Function):
             lse = torch.empty(B * H * T, device=x.device, dtype=F32)
             K.attn_fwd(K.view3(qkv, B, T, 0), K.view3(qkv, B, T, D), K.view3(qkv, B, T, 2 * D), B, B, H, T, T, scale,
                        K.view3(att, B, T), lse, bias=bias, bias_log2=True)
-            wproj, _ = BANK.linear(p[b + "attn.proj.weight"])
-            aux1 = torch.empty(M, D, device=x.device, dtype=BF16)
-            x1 = K.gemm_nt(att, wproj, bias=p[b + "attn.proj.bias"], gamma=p[b + "gamma_1"], resid=x, aux=aux1, out_dtype=F32,
-                           rowscale=rs1)
+            wproj, _ = BANK.linear(p[b + "attn.proj.weight"], tscale=p[b + "gamma_1"])
+            x1 = K.gemm_nt(att, wproj, bias=p[b + "attn.proj.bias"], gamma=p[b + "gamma_1"], resid=x, out_dtype=F32, rowscale=rs1)
             h2, _, mean2, rstd2 = K.layernorm_fwd(x1, p[b + "norm2.weight"], p[b + "norm2.bias"], meta["eps"])
             w1, _ = BANK.linear(p[b + "mlp.fc1.weight"])
-            w2, _ = BANK.linear(p[b + "mlp.fc2.weight"])
+            w2, _ = BANK.linear(p[b + "mlp.fc2.weight"], tscale=p[b + "gamma_2"])
             pre = torch.empty(M, w1.shape[0], device=x.device, dtype=BF16)
             act = K.gemm_nt(h2, w1, bias=p[b + "mlp.fc1.bias"], aux=pre, act=1)
-            aux2 = torch.empty(M, D, device=x.device, dtype=BF16)
-            x2 = K.gemm_nt(act, w2, bias=p[b + "mlp.fc2.bias"], gamma=p[b + "gamma_2"], resid=x1, aux=aux2, out_dtype=F32,
-                           rowscale=rs2)
-            saved.append((x, h1, mean1, rstd1, qkv, bias, biasT, att, lse, aux1, x1, h2, mean2, rstd2, pre, act, aux2))
+            x2 = K.gemm_nt(act, w2, bias=p[b + "mlp.fc2.bias"], gamma=p[b + "gamma_2"], resid=x1, out_dtype=F32, rowscale=rs2)
+            saved.append((x, h1, mean1, rstd1, qkv, bias, biasT, att, lse, x1, h2, mean2, rstd2, pre, act))
             x = x2
         final = None
         if head:
@@ -581,6 +610,7 @@ class VisionEncoderFn(torch.autograd.Function):
                                     ("qkv_bias", (3 * D,), True), ("attn.relative_position_bias_table", p[b + "attn.relative_position_bias_table"].shape, True),
                                     ("attn.proj.bias", (D,), True), ("norm2.weight", (D,), True), ("norm2.bias", (D,), True),
                                     ("mlp.fc1.bias", (F4,), True), ("mlp.fc2.bias", (D,), True),
+                                    ("_cs1", (D,), True), ("_cs2", (D,), True),     # column sums of the gradients entering the two layer scales
                                     ("attn.qkv.weight", (3 * D, D), False), ("attn.proj.weight", (D, D), False),
                                     ("mlp.fc1.weight", (F4, D), False), ("mlp.fc2.weight", (D, F4), False)], key=("vit", id(p[b + "gamma_1"])),
                               params=[p[n] for n in names if n.startswith(b)], zero=False)
@@ -589,27 +619,34 @@ class VisionEncoderFn(torch.autograd.Function):
             sn = ("cls_token", "patch_embed.proj.weight", "patch_embed.proj.bias")
             Gs = Grads(dev, [(n, p[n].shape, True) for n in sn], key=("vit-stem", id(p["cls_token"])), params=[p[n] for n in sn], zero=False)
         Grads.zero_all(list(arenas.values()) + ([Gs] if Gs is not None else []))
+        # Layer scale (x_out = x_in + r * gamma * u, u = A . W^T + b; r = DropPath factor): its backward never forms gamma * dX and
+        # never reads u.  With dX' = r * dX:  dA = dX' . (diag(gamma) W) (the bank's transposed copies of proj / fc2 carry gamma),
+        # G = dX'^T . A from the weight-gradient GEMM, then K.layerscale_finish: dgamma = rowdot(G, W) + b * colsum(dX'),
+        # db = gamma * colsum(dX'), dW = diag(gamma) G.  bf16(dX') and colsum(dX') are by-products of the LayerNorm backward that
+        # produces dX (post=...); only the gradient that enters this stage from outside needs a pass of its own.
+        dxb = None
         for i in reversed(range(lo, hi)):
             b = "blocks.%d." % i
             rs1, rs2 = dpath[i] if dpath is not None else (None, None)
-            (x, h1, mean1, rstd1, qkv, bias, biasT, att, lse, aux1, x1, h2, mean2, rstd2, pre, act, aux2) = ctx.saved[i - lo]
+            (x, h1, mean1, rstd1, qkv, bias, biasT, att, lse, x1, h2, mean2, rstd2, pre, act) = ctx.saved[i - lo]
             ctx.saved[i - lo] = None
             G = arenas.pop(i)
             _begin_layer_backward()
-            _, w2T = BANK.linear(p[b + "mlp.fc2.weight"])
+            _, w2T = BANK.linear(p[b + "mlp.fc2.weight"], tscale=p[b + "gamma_2"])
             _, w1T = BANK.linear(p[b + "mlp.fc1.weight"])
-            _, wprojT = BANK.linear(p[b + "attn.proj.weight"])
+            _, wprojT = BANK.linear(p[b + "attn.proj.weight"], tscale=p[b + "gamma_1"])
             _, wqkvT = BANK.linear(p[b + "attn.qkv.weight"])
-            dy2 = K.layerscale_bwd(dx, aux2, p[b + "gamma_2"], G["gamma_2"], G["mlp.fc2.bias"], rowscale=rs2)
+            if dxb is None:
+                dxb = K.rowscale_cast_colsum(dx, G["_cs2"], rowscale=rs2)
             if FUSE_DGELU_COLSUM:     # fc1's bias gradient as per-wave partial rows from the GEMM epilogue (no pass over dpre, no atomics)
-                dpre = K.gemm_nt_dgelu_colsum(dy2, w2T, pre, G["mlp.fc1.bias"])
+                dpre = K.gemm_nt_dgelu_colsum(dxb, w2T, pre, G["mlp.fc1.bias"])
             else:
-                dpre = K.gemm_nt(dy2, w2T, aux=pre, act=2)
+                dpre = K.gemm_nt(dxb, w2T, aux=pre, act=2)
                 K.colsum_bf16(dpre, G["mlp.fc1.bias"])    # two-stage sums: 20 us; fused into the GEMM epilogue with atomics: 30 us
             dh2 = K.gemm_nt(dpre, w1T)            # bf16, like the fp16 grad_input of the reference's O1 linears: half the bytes
-            dx1, _ = K.layernorm_bwd(dh2, x1, mean2, rstd2, p[b + "norm2.weight"], G["norm2.weight"], G["norm2.bias"], dres=dx)
-            dy1 = K.layerscale_bwd(dx1, aux1, p[b + "gamma_1"], G["gamma_1"], G["attn.proj.bias"], rowscale=rs1)
-            datt = K.gemm_nt(dy1, wprojT)
+            dx1, dx1b = K.layernorm_bwd(dh2, x1, mean2, rstd2, p[b + "norm2.weight"], G["norm2.weight"], G["norm2.bias"], dres=dx,
+                                        post=(rs1, G["_cs1"]))
+            datt = K.gemm_nt(dx1b, wprojT)
             dqkv = torch.empty_like(qkv)
             delta = torch.empty_like(lse)
             # parameter-only gradients of the block (bias table, q / v bias): with the deferred weight-gradient work when a queue
@@ -629,14 +666,21 @@ class VisionEncoderFn(torch.autograd.Function):
             G.alias("attn.q_bias", G["qkv_bias"][:D])
             G.alias("attn.v_bias", G["qkv_bias"][2 * D:])
             dh1 = K.gemm_nt(dqkv, wqkvT)
-            dxn, _ = K.layernorm_bwd(dh1, x, mean1, rstd1, p[b + "norm1.weight"], G["norm1.weight"], G["norm1.bias"], dres=dx1)
-            tn = [(dy2, act, G["mlp.fc2.weight"]), (dpre, h2, G["mlp.fc1.weight"]),
-                  (dy1, att, G["attn.proj.weight"]), (dqkv, h1, G["attn.qkv.weight"])]
-            pairs.add(G, tn, po)
+            if i > lo:      # the gradient leaving this block enters the MLP layer scale of the block below
+                below = (dpath[i - 1][1] if dpath is not None else None, arenas[i - 1]["_cs2"])
+                dxn, dxnb = K.layernorm_bwd(dh1, x, mean1, rstd1, p[b + "norm1.weight"], G["norm1.weight"], G["norm1.bias"], dres=dx1, post=below)
+            else:
+                dxn, dxnb = K.layernorm_bwd(dh1, x, mean1, rstd1, p[b + "norm1.weight"], G["norm1.weight"], G["norm1.bias"], dres=dx1)
+            tn = [(dxb, act, G["mlp.fc2.weight"]), (dpre, h2, G["mlp.fc1.weight"]),
+                  (dx1b, att, G["attn.proj.weight"]), (dqkv, h1, G["attn.qkv.weight"])]
+            fin = [(G["mlp.fc2.weight"], p[b + "mlp.fc2.weight"], p[b + "mlp.fc2.bias"], p[b + "gamma_2"], G["_cs2"], G["gamma_2"], G["mlp.fc2.bias"]),
+                   (G["attn.proj.weight"], p[b + "attn.proj.weight"], p[b + "attn.proj.bias"], p[b + "gamma_1"], G["_cs1"], G["gamma_1"],
+                    G["attn.proj.bias"])]
+            pairs.add(G, tn, po, fin)
             for n in names:
                 if n.startswith(b):
                     out[n] = G.g[n[len(b):]]
-            dx = dxn
+            dx, dxb = dxn, dxnb
         pairs.flush()
         if stem:
             dpatch = K.assemble_tokens_bwd(dx.view(B, T, D), Gs["cls_token"].view(-1))

@@ -116,8 +116,8 @@ def reduce_partials_multi(items):
 
 
 def cast_transpose_multi(desc):
-    """desc: tuples (src_ptr, dst_ptr, dstT_ptr, R, C, ldt, row_offset), see csrc/rowwise.hip."""
-    flat = [v for d in desc for v in d]
+    """desc: tuples (src_ptr, dst_ptr, dstT_ptr, R, C, ldt, row_offset[, tscale_ptr or 0]), see csrc/rowwise.hip."""
+    flat = [v for d in desc for v in (tuple(d) + (0,) if len(d) == 7 else d)]
     call("x2_cast_transpose_multi", (C.c_int64 * len(flat))(*flat), len(desc))
 
 
@@ -305,19 +305,27 @@ def layernorm_fwd(x, w, b, eps, *, rows=None, period=0, want_bf16=True, want_f32
 
 
 def layernorm_bwd(dy, x, mean, rstd, w, dw, db, *, dres=None, dcol=None, period=0, want_f32=True, want_bf16=False, dx=None,
-                  drop_in=NO_DROP, drop_out=NO_DROP):
-    """dcol (fp32 [D], accumulated): column sums of the LN-input gradient = bias gradient of the producing linear."""
+                  drop_in=NO_DROP, drop_out=NO_DROP, post=None):
+    """dcol (fp32 [D], accumulated): column sums of the LN-input gradient = bias gradient of the producing linear.
+    post = (rowscale or None, colsum fp32 [D]): the bf16 copy is rowscale[m] * (dx + dres) and `colsum` receives its column sums -
+    the two things the layer scale BELOW this LayerNorm needs of its incoming gradient (layerscale_finish)."""
     assert dy.dtype in (F32, BF16) and x.dtype == F32 and dy.is_contiguous() and x.is_contiguous()
     D = x.shape[-1]
     R = mean.numel()
     if want_f32 and dx is None:
         dx = torch.empty_like(x) if period == 0 else torch.zeros_like(x)
+    prs = None
+    if post is not None:
+        assert dcol is None and dy.dtype == BF16 and period == 0
+        prs, dcol = post
+        assert prs is None or (prs.dtype == F32 and prs.numel() == R and prs.is_contiguous())
+        want_bf16 = True
     dxb = torch.empty(x.shape, device=x.device, dtype=BF16) if want_bf16 else None
     nblk = (R + 15) // 16
     ws, defer = _ws_and_defer(x.device, nblk * 3 * D)
     call("x2_layernorm_bwd", ptr(dy), 1 if dy.dtype == BF16 else 0, ptr(x), ptr(mean), ptr(rstd), ptr(w), ptr(dres), ptr(dx), ptr(dxb), ptr(dw), ptr(db),
          ptr(dcol), R, D, period, drop_in[0], drop_in[1], drop_in[2], drop_out[0], drop_out[1], drop_out[2],
-         ptr(drop_in[3] if drop_in[3] is not None else drop_out[3]), ptr(ws), defer)
+         ptr(drop_in[3] if drop_in[3] is not None else drop_out[3]), ptr(ws), defer, 0 if post is None else 1, ptr(prs))
     if defer:
         DEFERRED.append((ws, nblk, 3, D, (dw, db, dcol)))
     return dx, dxb
@@ -331,15 +339,29 @@ def colsum_bf16(y, out):
         DEFERRED.append((ws, nblk, 1, y.shape[1], (out,)))
 
 
-def layerscale_bwd(dx, u, gamma, dgamma, dbias, rowscale=None):
-    du = torch.empty_like(u)
-    nblk = (u.shape[0] + 31) // 32
-    ws, defer = _ws_and_defer(u.device, nblk * 2 * u.shape[1])
-    call("x2_layerscale_bwd", ptr(dx), ptr(u), ptr(gamma), ptr(du), ptr(dgamma), ptr(dbias), ptr(rowscale), u.shape[0], u.shape[1],
-         ptr(ws), defer)
+def rowscale_cast_colsum(dx, colsum, rowscale=None):
+    """bf16(rowscale[m] * dx) and colsum += its column sums: what a layer scale's backward needs of its incoming gradient when no
+    LayerNorm backward of the same stage produced it (layernorm_bwd(post=...) otherwise)."""
+    assert dx.dtype == F32 and dx.is_contiguous() and dx.dim() == 2
+    dxb = torch.empty_like(dx, dtype=BF16)
+    nblk = (dx.shape[0] + 31) // 32
+    ws, defer = _ws_and_defer(dx.device, nblk * dx.shape[1])
+    call("x2_rowscale_cast_colsum", ptr(dx), ptr(rowscale), ptr(dxb), ptr(colsum), dx.shape[0], dx.shape[1], ptr(ws), defer)
     if defer:
-        DEFERRED.append((ws, nblk, 2, u.shape[1], (dgamma, dbias)))
-    return du
+        DEFERRED.append((ws, nblk, 1, dx.shape[1], (colsum,)))
+    return dxb
+
+
+def layerscale_finish(items):
+    """items: (G [N,K] fp32 = dX'^T . A as the weight-gradient GEMM left it, W [N,K] fp32, bias or None, gamma, cs, dgamma, dbias or
+    None).  dgamma += rowdot(G, W) + bias * cs, dbias += gamma * cs, G <- diag(gamma) G; one launch."""
+    flat = []
+    for G, W, bias, gamma, cs, dgamma, dbias in items:
+        N, Kd = G.shape
+        assert G.dtype == F32 and W.dtype == F32 and G.is_contiguous() and W.is_contiguous() and W.numel() == G.numel() and Kd % 4 == 0
+        flat += [G.data_ptr(), W.data_ptr(), 0 if bias is None else bias.data_ptr(), gamma.data_ptr(), cs.data_ptr(), dgamma.data_ptr(),
+                 0 if dbias is None else dbias.data_ptr(), N, Kd]
+    call("x2_layerscale_finish", (C.c_int64 * len(flat))(*flat), len(items))
 
 
 def cast_bf16(src, out=None):
