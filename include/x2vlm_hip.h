@@ -102,6 +102,8 @@ typedef struct X2AttnArgs {
   int head_dim;                                      /* hidden / heads of the caller: must be 64, checked */
   const unsigned* drop_epoch;                        /* device step counter mixed into drop_seed, or NULL */
   int grid_nx, grid_ny, grid_nz, grid_map;           /* written by the library (XCD-aware workgroup order of the bias kernels): pass 0 */
+  int phase;                                         /* x2_attn_bwd: 0 = dQ (+dS, Delta) then dK/dV; 1 = the dQ half only; 2 = the dK/dV half only
+                                                        (reads the Delta a phase-1 call wrote): the K/V-side gradients on another stream */
 } X2AttnArgs;
 int x2_attn_fwd(const X2AttnArgs* args, void* stream);
 int x2_attn_bwd(const X2AttnArgs* args, void* stream);   /* dQ (+dS, Delta) then dK/dV; no atomics */

@@ -48,6 +48,8 @@ struct AttnArgs {
   // filled by the entry points (callers pass zeros): logical grid (x = query / key tiles, y = heads, z = batches) and, when
   // grid_map > 0, the XCD-aware decode of a 1-D launch (attn_block below); grid_map = batch chunks per head
   int grid_nx, grid_ny, grid_nz, grid_map;
+  int phase;                           // x2_attn_bwd: 0 = dQ (+ dS, Delta) then dK / dV; 1 = dQ (+ dS, Delta) only; 2 = dK / dV only (Delta as a
+                                       // phase-1 call left it): lets a caller put the K/V-side gradients on another stream
 };
 
 // Workgroup -> (tile, head, batch).  grid_map == 0: the 3-D grid as launched.  grid_map = C > 0 (the kernels with a relative-
@@ -1084,8 +1086,10 @@ extern "C" int x2_attn_bwd(const AttnArgs* pa, void* stream) {
   X2_REQUIRE(!a.dS || (a.ds_ld % 64 == 0 && a.ds_ld >= a.Lk), "x2_attn_bwd: ds_ld must be a multiple of 64 covering Lk");
   X2_REQUIRE((a.kv_idx == nullptr) == (a.seq_off == nullptr), "x2_attn_bwd: kv_idx and seq_off/seq_ids come together");
   X2_REQUIRE(a.Bkv > 0, "x2_attn_bwd: Bkv");
+  X2_REQUIRE(a.phase >= 0 && a.phase <= 2, "x2_attn_bwd: phase=%d", a.phase);
   const hipStream_t st = (hipStream_t)stream;
-  if (a.seq_off && a.Lk <= 256 && !a.bias && !a.dS)      // rows sharing K/V: one workgroup per (K/V batch, head)
+  if (a.phase == 2) { /* the dQ half ran in an earlier call */ }
+  else if (a.seq_off && a.Lk <= 256 && !a.bias && !a.dS)      // rows sharing K/V: one workgroup per (K/V batch, head)
     hipLaunchKernelGGL((attn_bwd_dq_grouped_kernel<8>), dim3(1, a.H, a.Bkv), dim3(512), 0, st, a);
   else if (a.Lq <= 32 && a.Lk <= 64) hipLaunchKernelGGL((attn_bwd_dq_kernel<2, 1, true, 1>), dim3(1, a.H, a.B), dim3(128), 0, st, a);
   else if (a.Lq <= 32) hipLaunchKernelGGL((attn_bwd_dq_kernel<2, 1, false>), dim3(1, a.H, a.B), dim3(128), 0, st, a);
@@ -1098,6 +1102,7 @@ extern "C" int x2_attn_bwd(const AttnArgs* pa, void* stream) {
       else attn_launch(attn_bwd_dq_walk_kernel<4>, a, 1, a.H, a.B, 256, xm, st); }
   else attn_launch(attn_bwd_dq_kernel<8, 1, true>, a, (a.Lq + 127) / 128, a.H, a.B, 512, xm, st);
   if (int e = x2_check_launch("x2_attn_bwd(dq)")) return e;
+  if (a.phase == 1) return 0;
   const bool res = !a.seq_off && a.Lq > 64 && a.Lq <= 256;   // one sequence per K/V batch, 2..4 query tiles: resident Q/dO
   if (a.Lk <= 32 && !a.seq_off && a.Lq <= 64) {          // text self-attention: one sequence, one query tile, 17 KB of LDS
     hipLaunchKernelGGL((attn_bwd_dkv_kernel<2, 1, true, 1>), dim3(1, a.H, a.Bkv), dim3(128), 0, st, a);

@@ -330,6 +330,12 @@ class SideStream:
 
 
 SIDE = SideStream()
+# A second stream INSIDE the fusion stack's stage, for the work that hangs off its dependency chain: the cross-attention K/V
+# projections of all layers (forward: they depend on the image tokens only) and the K/V-side gradients (backward: dK / dV of every
+# cross-attention and their input-gradient GEMM feed the VISION tower, not the text chain).  graph.SegmentedStep switches it on
+# around its tail segment, where the GPU otherwise runs one 1.0-1.4-round launch of the M = 7680 chain at a time.
+AUX = SideStream()
+AUX.enabled = False
 
 
 def _begin_layer_backward():
@@ -772,6 +778,15 @@ class BertLayersFn(torch.autograd.Function):
             encb = K.cast_bf16(enc.contiguous().view(Bi * T, Dv))
         BertLayersFn.prepare_weights(p, meta["lo"], meta["hi"], meta["fusion_at"], cross)
         saved = []
+        kv_ahead = {}
+        if cross and AUX.enabled:
+            # every layer's K/V projection of the image tokens now, on the second stream: layer i waits for its event only
+            for i in range(max(meta["lo"], meta["fusion_at"]), meta["hi"]):
+                c = "layer.%d.crossattention." % i
+                wkv, _ = BANK.linear(p[c + "self.key.weight"], p[c + "self.value.weight"])
+                bkv = BANK.vector(p[c + "self.key.bias"], p[c + "self.value.bias"])
+                kv = torch.empty(Bi * T, wkv.shape[0], device=dev, dtype=BF16)
+                kv_ahead[i] = (kv, AUX.launch(lambda kv=kv, wkv=wkv, bkv=bkv: K.gemm_nt(encb, wkv, bias=bkv, out=kv), [encb, wkv, bkv, kv]))
         for i in range(meta["lo"], meta["hi"]):
             b = "layer.%d." % i
             a = b + "attention."
@@ -794,7 +809,12 @@ class BertLayersFn(torch.autograd.Function):
                 wkv, _ = BANK.linear(p[c + "self.key.weight"], p[c + "self.value.weight"])
                 bkv = BANK.vector(p[c + "self.key.bias"], p[c + "self.value.bias"])
                 q2 = K.gemm_nt(h1b, wq, bias=p[c + "self.query.bias"])
-                kv = K.gemm_nt(encb, wkv, bias=bkv)
+                if i in kv_ahead:
+                    kv, ev = kv_ahead.pop(i)
+                    if ev is not None:
+                        torch.cuda.current_stream().wait_event(ev)
+                else:
+                    kv = K.gemm_nt(encb, wkv, bias=bkv)
                 att2 = torch.empty(M, Hd, device=dev, dtype=BF16)
                 lse2 = torch.empty(S * H * L, device=dev, dtype=F32)
                 K.attn_fwd(K.view3(q2, S, L), K.view3(kv, Bi, T, 0), K.view3(kv, Bi, T, Hd), S, Bi, H, L, T, scale,
@@ -812,6 +832,7 @@ class BertLayersFn(torch.autograd.Function):
             h3b, h3, m3, r3 = K.layernorm_fwd(s3, p[b + "output.LayerNorm.weight"], p[b + "output.LayerNorm.bias"], eps, want_f32=True)
             saved.append((hb, qkv, att, lse, s1, m1, r1, h1b, cr, h2b, pre, act, s3, m3, r3))
             h, hb = h3, h3b
+        AUX.join()
         for i in range(meta["lo"], meta["hi"]):
             _count_call(("bert", id(p["layer.%d.attention.self.query.weight" % i])))
         ctx.meta, ctx.saved, ctx.params, ctx.encb = meta, saved, params, encb
@@ -883,10 +904,16 @@ class BertLayersFn(torch.autograd.Function):
                 dq2 = torch.empty_like(q2)
                 dkv = torch.empty_like(kv)
                 delta2 = torch.empty_like(lse2)
-                K.attn_bwd(K.view3(q2, S, L), K.view3(kv, Bi, T, 0), K.view3(kv, Bi, T, Hd), K.view3(att2, S, L), K.view3(datt2, S, L),
-                           S, Bi, H, L, T, scale, lse2, delta2, K.view3(dq2, S, L), K.view3(dkv, Bi, T, 0), K.view3(dkv, Bi, T, Hd),
-                           mask=meta["enc_mask"], kv_idx=meta["kv_idx"], seq_off=meta["seq_off"], seq_ids=meta["seq_ids"],
-                           drop=BertLayersFn._drop(meta, i, 2))
+                # the K/V side of this layer (dK / dV, then their input gradient into the image tokens) feeds the vision tower only:
+                # on the second stream when there is one and every reader of dkv in this stage is deferred past its join
+                aux = AUX.enabled and WGRAD_QUEUE is not None
+
+                def attn2(phase):
+                    K.attn_bwd(K.view3(q2, S, L), K.view3(kv, Bi, T, 0), K.view3(kv, Bi, T, Hd), K.view3(att2, S, L), K.view3(datt2, S, L),
+                               S, Bi, H, L, T, scale, lse2, delta2, K.view3(dq2, S, L), K.view3(dkv, Bi, T, 0), K.view3(dkv, Bi, T, Hd),
+                               mask=meta["enc_mask"], kv_idx=meta["kv_idx"], seq_off=meta["seq_off"], seq_ids=meta["seq_ids"],
+                               drop=BertLayersFn._drop(meta, i, 2), phase=phase)
+                attn2(1 if aux else 0)
                 _param_only(po, K.colsum_bf16, dq2, G["crossattention.self.query.bias"])
                 _param_only(po, K.colsum_bf16, dkv, G["c.kv_bias"])
                 G.alias("crossattention.self.key.bias", G["c.kv_bias"][:Hd])
@@ -896,7 +923,17 @@ class BertLayersFn(torch.autograd.Function):
                 _, wqT = BANK.linear(p[c + "self.query.weight"])
                 _, wkvT = BANK.linear(p[c + "self.key.weight"], p[c + "self.value.weight"])
                 dh1 = K.gemm_nt(dq2, wqT, resid=ds2, out_dtype=F32)
-                denc = K.gemm_nt(dkv, wkvT, resid=denc, out_dtype=F32)
+                if aux:
+                    first = denc is None
+                    if first:
+                        denc = torch.empty(Bi * T, Dv, device=dev, dtype=F32)       # one buffer, accumulated in place layer by layer
+
+                    def kv_side(attn2=attn2, dkv=dkv, wkvT=wkvT, first=first, denc=denc):
+                        attn2(2)
+                        K.gemm_nt(dkv, wkvT, resid=None if first else denc, out=denc)
+                    AUX.launch(kv_side, [q2, kv, att2, datt2, lse2, delta2, dq2, dkv, wkvT, denc])
+                else:
+                    denc = K.gemm_nt(dkv, wkvT, resid=denc, out_dtype=F32)
                 # longest contraction (image tokens) first: its tiles start in the first round of the grouped launch
                 tn = [(dkv, encb, G["c.kv_weight"])] + tn + [(ds2b, att2, G["crossattention.output.dense.weight"]),
                                                             (dq2, h1b, G["crossattention.self.query.weight"])]
@@ -925,6 +962,7 @@ class BertLayersFn(torch.autograd.Function):
                     out[n] = G.g[n[len(b):]]
         pairs.flush()
         SIDE.join()
+        AUX.join()
         d_enc = denc.view(enc_shape) if denc is not None else None
         return (dh.view(S, L, Hd), d_enc, None) + tuple(out[n] for n in names)
 

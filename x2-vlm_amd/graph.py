@@ -184,6 +184,8 @@ class SegmentedStep:
         # first's when it receives it, long before the queue fills either; the late TN GEMM then overwrites the sum with one
         # contribution (round 4: the replayed region iteration had lost the other one; the eager path was right).
         self.defer_tail_wgrad = os.environ.get("X2_SEG_TAIL_WGRAD", "1") == "1" and not ret_bbox_loss
+        # the tail segment forks a second stream for what hangs off the fusion stack's dependency chain (engine.AUX)
+        self.aux_overlap = os.environ.get("X2_AUX_OVERLAP", "1") == "1"
         self._queue = None
         # The vision tower as a chain of stages cut at these block numbers (beit2.VisionTransformer.chunk_at): its backward
         # becomes one segment per stage, top first; the weight gradients of every stage but the lowest run as segments of
@@ -498,7 +500,11 @@ class SegmentedStep:
             self._gather()
         if mode != "replay":
             eng.WGRAD_QUEUE = [] if self.defer_tail_wgrad else None
-        self._seg(mode, "F2", A, self._s_loss, pa)
+            eng.AUX.enabled, eng.AUX.only_from = self.aux_overlap, self.sA.cuda_stream
+        try:
+            self._seg(mode, "F2", A, self._s_loss, pa)
+        finally:
+            eng.AUX.enabled, eng.AUX.only_from = False, None
         if mode != "replay":
             self._queue, eng.WGRAD_QUEUE = eng.WGRAD_QUEUE, None
         Bs.wait_stream(A)

@@ -270,8 +270,10 @@ def attn_fwd(q, k, v, B, Bkv, H, Lq, Lk, scale, out, lse, **kw):
     call("x2_attn_fwd", C.byref(a))
 
 
-def attn_bwd(q, k, v, o, do, B, Bkv, H, Lq, Lk, scale, lse, delta, dq, dk, dv, dS=None, **kw):
+def attn_bwd(q, k, v, o, do, B, Bkv, H, Lq, Lk, scale, lse, delta, dq, dk, dv, dS=None, phase=0, **kw):
+    """phase: 0 both halves; 1 the dQ half (+ dS, delta); 2 the dK / dV half (needs the delta of a phase-1 call)."""
     a = _attn_args(q, k, v, B, Bkv, H, Lq, Lk, scale, **kw)
+    a.phase = phase
     a.O, a.o_bs, a.o_rs = o
     a.dO, a.do_bs, a.do_rs = do
     a.dQ, a.dq_bs, a.dq_rs = dq
