@@ -366,6 +366,16 @@ def run_attention(K, B, Bkv, H, Lq, Lk, use_bias, use_mask, kv_map, seed, bias_l
     assert relerr(dv.view(Bkv, Lk, H * d), v0.grad.permute(0, 2, 1, 3).reshape(Bkv, Lk, H * d)) < tol
     if use_bias:
         assert relerr(dS[..., :Lk].float().sum(0), bias_leaf.grad) < tol
+    # the two halves as separate calls (phase 1: dQ, dS, delta; phase 2: dK / dV from that delta) - what lets a caller put the
+    # K/V-side gradients on another stream - give the same bits as the one call
+    dq2, dk2, dv2, delta2 = torch.zeros_like(dq), torch.zeros_like(dk), torch.zeros_like(dv), torch.zeros_like(delta)
+    for phase in (1, 2):
+        K.attn_bwd(K.view3(qd, B, Lq), K.view3(kd, Bkv, Lk), K.view3(vd, Bkv, Lk), K.view3(od, B, Lq), K.view3(dod, B, Lq),
+                   B, Bkv, H, Lq, Lk, scale, lse, delta2, K.view3(dq2, B, Lq), K.view3(dk2, Bkv, Lk), K.view3(dv2, Bkv, Lk),
+                   dS=dS, phase=phase, **kw)
+        if phase == 1:
+            assert torch.equal(dq2, dq) and float(dk2.float().abs().max()) == 0.0 and float(dv2.float().abs().max()) == 0.0
+    assert torch.equal(dk2, dk) and torch.equal(dv2, dv) and torch.equal(delta2, delta)
 
 
 def test_attention_vision_bias(K):
