@@ -413,6 +413,10 @@ def main():
                          "gemm_tn256_kernel isolated (weight gradients; two layers per grouped launch)": summary(stat_iso, "gemm_tn"),
                          "whole_step_tflops": round(pairs_s / world * f_min / 1e3, 1),
                          "whole_step_frac": round(pairs_s / world * f_min / 1e3 / PEAK_TFLOPS, 4),
+                         # all kernels of one base step, from the same committed PMC passes as `traffic` (an upper bound of HBM bytes: the
+                         # fabric counters include Infinity-Cache hits), and the time that many bytes take at the HBM rates
+                         "whole_step_hbm_gb": PMC_TRAFFIC.get("whole_step_hbm_gb") if args.config == "base" else None,
+                         "whole_step_hbm_floor_ms": PMC_TRAFFIC.get("whole_step_hbm_floor_ms") if args.config == "base" else None,
                          "gflop_per_unit": round(f_min, 1), **({"f_min_note": f_note} if f_note else {})}}
     if world > 1:
         dist.barrier()

@@ -22,8 +22,13 @@ names = [n for n in fetch if n.startswith("gemm_nt_kernel") or n.startswith("gem
 calls = sum(fetch[n][0] for n in names)
 fb = sum(fetch[n][0] * fetch[n][1] for n in names) / calls * 1024 * 2
 wb = sum(write[n][0] * write[n][1] for n in names if n in write) / max(sum(write[n][0] for n in names if n in write), 1) * 1024
+# whole step: every kernel's fetch (x 2) + write bytes, per profiled step (patchify_kernel runs once per step)
+steps = max(fetch.get("patchify_kernel", (1, 0))[0], 1)
+total = (sum(c * a for c, a in fetch.values()) * 2 + sum(c * a for c, a in write.values())) * 1024 / steps
 out = {"kernel": "gemm_nt_kernel<*> + gemm_nt256_kernel<*>", "launches": calls, "fetch_bytes_per_launch": int(fb), "write_bytes_per_launch": int(wb),
        "hbm_bytes_per_launch": int(fb + wb),
+       "whole_step_hbm_gb": round(total / 1e9, 2), "whole_step_steps_profiled": steps,
+       "whole_step_hbm_floor_ms": {"at_6.3_TB/s_achievable": round(total / 6.3e9, 2), "at_8_TB/s_peak": round(total / 8e9, 2)},
        "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (probes/run_pmc.sh) over "
                  "`bench.py --serialize --no-graph --steps 2 --warmup 1` (base config); KB units; FETCH_SIZE doubled (gfx950 counts "
                  "128-B read requests at 64 B: MI355X_MICROARCH.md, HBM section)",

@@ -22,7 +22,7 @@ def family(n):
         return "attention fwd / dQ / dK,dV"
     if n.startswith("layernorm"):
         return "LayerNorm fwd / bwd"
-    if n.startswith("reduce_partials") or n.startswith("colsum") or n.startswith("layerscale"):
+    if n.startswith("reduce_partials") or n.startswith("colsum") or n.startswith("layerscale") or n.startswith("rowscale"):
         return "column sums, layer-scale bwd, stage-2 reductions"
     if n.startswith("relpos"):
         return "rel-pos bias gather / gradient"
