@@ -905,8 +905,10 @@ class BertLayersFn(torch.autograd.Function):
                 dkv = torch.empty_like(kv)
                 delta2 = torch.empty_like(lse2)
                 # the K/V side of this layer (dK / dV, then their input gradient into the image tokens) feeds the vision tower only:
-                # on the second stream when there is one and every reader of dkv in this stage is deferred past its join
-                aux = AUX.enabled and WGRAD_QUEUE is not None
+                # on the second stream when there is one.  Its readers inside this stage (bias sums, weight gradients) are either
+                # deferred past the stage's join (WGRAD_QUEUE) or wait for its event at the end of the layer (kv_done below).
+                aux = AUX.enabled
+                kv_done = None
 
                 def attn2(phase):
                     K.attn_bwd(K.view3(q2, S, L), K.view3(kv, Bi, T, 0), K.view3(kv, Bi, T, Hd), K.view3(att2, S, L), K.view3(datt2, S, L),
@@ -915,7 +917,6 @@ class BertLayersFn(torch.autograd.Function):
                                drop=BertLayersFn._drop(meta, i, 2), phase=phase)
                 attn2(1 if aux else 0)
                 _param_only(po, K.colsum_bf16, dq2, G["crossattention.self.query.bias"])
-                _param_only(po, K.colsum_bf16, dkv, G["c.kv_bias"])
                 G.alias("crossattention.self.key.bias", G["c.kv_bias"][:Hd])
                 G.alias("crossattention.self.value.bias", G["c.kv_bias"][Hd:])
                 G.alias("crossattention.self.key.weight", G["c.kv_weight"][:Hd])
@@ -931,7 +932,7 @@ class BertLayersFn(torch.autograd.Function):
                     def kv_side(attn2=attn2, dkv=dkv, wkvT=wkvT, first=first, denc=denc):
                         attn2(2)
                         K.gemm_nt(dkv, wkvT, resid=None if first else denc, out=denc)
-                    AUX.launch(kv_side, [q2, kv, att2, datt2, lse2, delta2, dq2, dkv, wkvT, denc])
+                    kv_done = AUX.launch(kv_side, [q2, kv, att2, datt2, lse2, delta2, dq2, dkv, wkvT, denc])
                 else:
                     denc = K.gemm_nt(dkv, wkvT, resid=denc, out_dtype=F32)
                 # longest contraction (image tokens) first: its tiles start in the first round of the grouped launch
@@ -956,6 +957,10 @@ class BertLayersFn(torch.autograd.Function):
             _, wqkvT = BANK.linear(p[a + "self.query.weight"], p[a + "self.key.weight"], p[a + "self.value.weight"])
             dh = K.gemm_nt(dqkv, wqkvT, resid=ds1, out_dtype=F32)
             tn += [(ds1b, att, G["attention.output.dense.weight"]), (dqkv, hb, G["a.qkv_weight"])]
+            if cr is not None:
+                if kv_done is not None and WGRAD_QUEUE is None:
+                    torch.cuda.current_stream().wait_event(kv_done)      # dkv is read below, in this stage
+                _param_only(po, K.colsum_bf16, dkv, G["c.kv_bias"])
             pairs.add(G, tn, po)
             for n in names:
                 if n.startswith(b):
