@@ -33,13 +33,13 @@ NT = [("fc1 fwd", 12608, 3072, 768, "gelu"), ("fc2 fwd", 12608, 768, 3072, "resi
 def nt_case(M, N, Kd, epi):
     A = torch.randn(M, Kd, device=dev).bfloat16(); B = (torch.randn(N, Kd, device=dev) * Kd ** -0.5).bfloat16()
     bias = torch.randn(N, device=dev); resid = torch.randn(M, N, device=dev) if epi == "resid" else None
-    aux = torch.empty(M, N, device=dev, dtype=torch.bfloat16) if epi in ("gelu", "resid") else None
+    aux = torch.empty(M, N, device=dev, dtype=torch.bfloat16) if epi == "gelu" else None
     out = torch.empty(M, N, device=dev, dtype=torch.float32 if epi in ("resid", "f32") else torch.bfloat16)
     kw = dict(bias=bias, out=out)
     if epi == "gelu":
         kw.update(aux=aux, act=1)
     if epi == "resid":
-        kw.update(resid=resid, gamma=bias, aux=aux)
+        kw.update(resid=resid, gamma=bias)
     return lambda: K.gemm_nt(A, B, **kw)
 
 

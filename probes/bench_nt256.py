@@ -67,7 +67,7 @@ def case(M, N, Kd, epi):
     if epi == "dgelu":
         kw.update(aux=torch.randn(M, N, device=dev).bfloat16(), act=2)
     if epi == "lscale":
-        kw.update(resid=torch.randn(M, N, device=dev), gamma=gamma, aux=torch.empty(M, N, device=dev, dtype=torch.bfloat16))
+        kw.update(resid=torch.randn(M, N, device=dev), gamma=gamma)      # feature set 6: nothing saved besides the output
     if epi in ("resid", "resid_drop"):
         kw.update(resid=torch.randn(M, N, device=dev))
     if epi == "resid_drop":

@@ -112,3 +112,28 @@ def test_copies_expire_after_a_backward_even_without_version_bump(bank):
     assert Probe.calls_in_backward["single"] == n_single     # served from the cache while the backward is running
     bank.linear(w)
     assert bank.calls["single"] == n_single + 1              # first use after it: rebuilt
+
+
+def test_scaled_transposed_copies_are_their_own_entries(bank, monkeypatch):
+    """linear(w, tscale=gamma) / prepare([(w, TScale(gamma))]): W^T carries gamma (the layer scale folded into the weight of the
+    input-gradient GEMM); keyed apart from the plain pair, rebuilt when either the weight or gamma moved, descriptor rows carry
+    the scale pointer in slot 7."""
+    descs = []
+    monkeypatch.setattr(eng.K, "cast_transpose_multi", lambda desc: (descs.append(list(desc)), bank.calls.__setitem__("multi", bank.calls["multi"] + 1)))
+    w, g = torch.nn.Parameter(torch.randn(8, 4)), torch.nn.Parameter(torch.rand(8) + 0.5)
+    bank.prepare([(w,), (w, eng.TScale(g))])
+    assert bank.calls["multi"] == 1 and len(bank._c) == 2 and len(descs[0]) == 2
+    plain_row, scaled_row = descs[0]
+    assert len(plain_row) == 8 and plain_row[7] == 0 and scaled_row[7] == g.data_ptr() and scaled_row[0] == w.data_ptr()
+    bank.linear(w, tscale=g)
+    bank.linear(w)
+    assert bank.calls["single"] == 0                          # both were built by prepare()
+    with torch.no_grad():
+        g.mul_(2.0)                                          # only gamma moved: the scaled entry is stale, the plain one is not
+    bank.prepare([(w,), (w, eng.TScale(g))])
+    assert bank.calls["multi"] == 2 and len(descs[1]) == 1 and descs[1][0][7] == g.data_ptr()
+    # one-at-a-time path (no multi-tensor launch possible): same values
+    odd, go = torch.nn.Parameter(torch.randn(6, 5)), torch.nn.Parameter(torch.rand(6) + 0.5)
+    plain, tr = bank.linear(odd, tscale=go)
+    assert torch.equal(plain, odd.detach().to(torch.bfloat16))
+    assert torch.equal(tr, (odd.detach() * go.detach()[:, None]).t().contiguous().to(torch.bfloat16))
