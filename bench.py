@@ -320,8 +320,6 @@ def main():
     # ~25 ms (base) / ~100 ms (large) of Python + ctypes launch time per step that bounded round 1.  The optimizer stays
     # outside the graph.  X2_GRAPH=0 / --no-graph: eager launches.
     graph = importlib.import_module("x2-vlm_amd.graph")
-    if os.environ.get("X2_HACK_NT_ABLATE"):           # timing experiment only (garbage outputs): NT GEMM ablation bits, gemm.hip
-        importlib.import_module("x2-vlm_amd._lib").lib().x2_tune(2, int(os.environ["X2_HACK_NT_ABLATE"]))
     use_graph = not args.no_graph and (world == 1 or args.graph == "segments")
     if use_graph and os.environ.get("X2_GRAPH_CANARY", "1") == "1" and not args.tiny and world == 1:
         # Stream capture leans on ROCm behaviour found by probing (graph.py): a runtime that breaks it tends to crash
@@ -437,6 +435,13 @@ def main():
                           "train (BERT dropout 0.1, attention dropout 0.1, DropPath 0..0.1)",
                           "losses": {k: round(float(v), 4) for k, v in loss.items()}},
                "roofline": roof}
+        # every kernel-variant knob that is not at its default (X2_TUNE / x2_tune) is part of the record: a line measured
+        # with a non-default variant says so.  (Work-skipping ablation bits do not exist in the shipped library at all:
+        # csrc/gemm.hip compiles them only with -DX2_PROBE, probes/build_probe.sh.)
+        h_ = importlib.import_module("x2-vlm_amd._lib").lib()
+        tuned = {str(k): h_.x2_tune_get(k) for k in range(13) if h_.x2_tune_get(k) > 0}
+        out["x2_tune_non_default"] = tuned
+        out["env_switches"] = {k: v for k, v in sorted(os.environ.items()) if k.startswith("X2_") and k not in ("X2_BENCH_BACKEND",)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(conf)
         if world == 1 and args.config == "base" and not (args.no_other_configs or args.tiny or args.serialize or args.eval_mode):

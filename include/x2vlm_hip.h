@@ -23,9 +23,12 @@ extern "C" {
 #endif
 
 const char* x2_last_error(void);
-int x2_abi_version(void);          /* == 9 */
+int x2_abi_version(void);          /* == 10 */
 int x2_device_cus(void);           /* compute units of the current HIP device, 0 if none */
-int x2_tune(int key, int value);   /* kernel-variant knobs for probes/ and tests (0 = automatic); keys listed in csrc/gemm.hip */
+int x2_tune(int key, int value);   /* kernel-variant knobs for probes/ and tests (0 = automatic); keys listed in csrc/gemm.hip.
+                                    * key 12 = compute units every tile plan leaves to RCCL's channel kernels (world > 1);
+                                    * key 2 (work-skipping ablation bits) is refused unless the library was built with -DX2_PROBE */
+int x2_tune_get(int key);          /* current value of a knob, -1 for an unknown key (bench.py reports the non-default ones) */
 
 /* ---- dense contractions (csrc/gemm.hip) -------------------------------------------------------------
  * F.linear of beit2.py:131 (fused qkv), :160 (proj), :62/:66 (MLP); xbert.py:338-350 (Q/K/V, cross K/V from

@@ -12,6 +12,14 @@ tests/golden/*.npz): losses, activations, logits, bbox coordinates and per-param
 Also here: rerank_scores (Retrieval.py:113-160), pinned by tests/golden/tiny_retrieval.npz.  NOT covered by any golden
 vector: the apex DDP / AMP semantics around the step (un-vendored third-party code): parity unpinned there, see DESIGN.md 6.
 
+Operand-rounding-aware mode (round 5): `xvlm_forward(..., round_operands=torch.bfloat16)` (or the `rounding(...)` context)
+runs the SAME program with the operands of every linear / attention product that the HIP path feeds to the matrix cores as
+bf16 rounded to bf16 at the same sites (and the tensors it stores as bf16 - qkv, contexts, GELU outputs, the gradients it
+hands on as bf16 - rounded where they are stored); accumulation and everything else stays fp32.  With the mode off (the
+default) every helper below is the identity and the program is bit-identical to the one the golden vectors pin
+(tests/test_oracle_golden.py asserts both).  The mode exists so that the model-level GPU tests can hold POINTWISE values and
+per-tensor gradients to ~1e-3 instead of the 1-3 % that bf16-vs-fp32 operand rounding through 36 GEMMs allows.
+
 Deviations from the pinned third-party stack, all result-neutral:
   * image (encoder) attention mask uses transformers==4.12.5's fp32 constant (1-m)*-1e9
     (modeling_utils.invert_attention_mask); the golden run used transformers 5's finfo.min.
@@ -140,6 +148,87 @@ def make_params(cfg, seed, synth_tensor, requires_grad=True):
     return sd
 
 
+# --------------------------------------------------------------------------- operand rounding (off by default)
+
+_ROUND = None       # None, or the dtype (torch.bfloat16) the matrix-core operands are rounded to
+
+
+class rounding:
+    """Context: `with rounding(torch.bfloat16): ...` - forward AND backward of everything built inside round at the sites
+    marked below (the backward rounding is fixed when the forward node is created)."""
+
+    def __init__(self, dtype):
+        self.dtype = dtype
+
+    def __enter__(self):
+        global _ROUND
+        self.prev, _ROUND = _ROUND, self.dtype
+        return self
+
+    def __exit__(self, *a):
+        global _ROUND
+        _ROUND = self.prev
+
+
+class _RoundFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, dtype, fwd, bwd):
+        ctx.dtype, ctx.bwd = dtype, bwd
+        return x.to(dtype).to(x.dtype) if fwd else x.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        return (g.to(ctx.dtype).to(g.dtype) if ctx.bwd else g), None, None, None
+
+
+def _q(x):
+    """A value the HIP path reads as a bf16 matrix operand while its gradient stays fp32 (weights, the fp32 hidden states'
+    bf16 copies, softmax probabilities): rounded in the forward, straight-through in the backward."""
+    return x if _ROUND is None else _RoundFn.apply(x, _ROUND, True, False)
+
+
+def _qg(x):
+    """An fp32 GEMM result whose incoming GRADIENT the HIP path consumes as a bf16 operand (dY of the input- and
+    weight-gradient GEMMs): identity in the forward, the gradient rounded in the backward."""
+    return x if _ROUND is None else _RoundFn.apply(x, _ROUND, False, True)
+
+
+def _qq(x):
+    """A tensor the HIP path STORES as bf16 and whose gradient it stores as bf16 too (qkv, attention contexts, the pre-LN
+    vision blocks' normalised rows): rounded both ways."""
+    return x if _ROUND is None else _RoundFn.apply(x, _ROUND, True, True)
+
+
+class _GeluSavedRounded(torch.autograd.Function):
+    """GELU whose forward sees the fp32 pre-activation (the GEMM epilogue applies it to the accumulators) and whose backward
+    evaluates GELU' at the bf16 copy of it that was saved (csrc/gemm.hip act = 1 / act = 2)."""
+
+    @staticmethod
+    def forward(ctx, v, dtype):
+        ctx.save_for_backward(v.to(dtype).to(v.dtype))
+        return 0.5 * v * (1.0 + torch.erf(v * (1.0 / math.sqrt(2.0))))
+
+    @staticmethod
+    def backward(ctx, g):
+        (v,) = ctx.saved_tensors
+        cdf = 0.5 * (1.0 + torch.erf(v * (1.0 / math.sqrt(2.0))))
+        pdf = torch.exp(-0.5 * v * v) * (1.0 / math.sqrt(2.0 * math.pi))
+        return g * (cdf + v * pdf), None
+
+
+def gelu_mm(v):
+    """GELU behind a matrix product (fc1 / intermediate / MLM transform)."""
+    return gelu(v) if _ROUND is None else _GeluSavedRounded.apply(v, _ROUND)
+
+
+def mm_linear(x, w, b=None, x_grad=False, out=None):
+    """A linear layer the HIP path runs on the matrix cores (bf16 operands, fp32 accumulation).  x_grad: the gradient w.r.t.
+    x is stored as bf16 (vision blocks); out: None = fp32 result whose gradient is consumed as a bf16 operand, "bf16" = the
+    result itself is stored as bf16 (qkv / q / kv projections), "raw" = fp32 result, gradient handled by the caller."""
+    y = linear(_qq(x) if x_grad else _q(x), _q(w), b)
+    return _qq(y) if out == "bf16" else y if out == "raw" else _qg(y)
+
+
 # --------------------------------------------------------------------------- primitive ops
 
 def gelu(x):
@@ -173,10 +262,11 @@ def attention_core(q, k, v, scale, add, pmul=None):
     s = (q @ k.transpose(-1, -2)) * scale
     if add is not None:
         s = s + add
+    s = _qg(s)                  # dS is a bf16 operand of the dQ / dK products (csrc/attention.hip)
     p = torch.softmax(s, dim=-1)
     if pmul is not None:
         p = p * pmul
-    return p @ v
+    return _qq(_q(p) @ v)       # P packed to bf16 for the PV product; the context is stored as bf16, and so is its gradient
 
 
 def cross_entropy(logits, labels, ignore_index=-100):
@@ -195,7 +285,7 @@ def patch_embed(sd, cfg, image):
     p, g = cfg.patch_size, image.shape[-1] // cfg.patch_size
     cols = image.view(B, 3, g, p, g, p).permute(0, 2, 4, 1, 3, 5).reshape(B, g * g, 3 * p * p)
     w = sd["vision_encoder.patch_embed.proj.weight"].reshape(cfg.vision_width, -1)
-    return linear(cols, w, sd["vision_encoder.patch_embed.proj.bias"])
+    return mm_linear(cols, w, sd["vision_encoder.patch_embed.proj.bias"])
 
 
 def vision_block(sd, cfg, i, x, rel_index, dp=None):
@@ -206,16 +296,17 @@ def vision_block(sd, cfg, i, x, rel_index, dp=None):
     D = cfg.vision_width
     h = layer_norm(x, sd[p + "norm1.weight"], sd[p + "norm1.bias"], 1e-6)
     qkv_bias = torch.cat([sd[p + "attn.q_bias"], torch.zeros(D), sd[p + "attn.v_bias"]])
-    qkv = linear(h, sd[p + "attn.qkv.weight"], qkv_bias)
+    qkv = mm_linear(h, sd[p + "attn.qkv.weight"], qkv_bias, x_grad=True, out="bf16")
     q, k, v = (split_heads(t, H) for t in qkv.split(D, dim=-1))
     N = x.shape[1]
     bias = sd[p + "attn.relative_position_bias_table"][rel_index.reshape(-1)].view(N, N, H).permute(2, 0, 1)
     ctx = merge_heads(attention_core(q, k, v, (D // H) ** -0.5, bias.unsqueeze(0)))
     m1, m2 = dp if dp is not None else (1.0, 1.0)
-    x = x + m1 * (sd[p + "gamma_1"] * linear(ctx, sd[p + "attn.proj.weight"], sd[p + "attn.proj.bias"]))
+    # layer scale: the gradient entering gamma * u (after the DropPath factor) is what the HIP backward rounds to bf16
+    x = x + m1 * _qg(sd[p + "gamma_1"] * mm_linear(ctx, sd[p + "attn.proj.weight"], sd[p + "attn.proj.bias"], out="raw"))
     h = layer_norm(x, sd[p + "norm2.weight"], sd[p + "norm2.bias"], 1e-6)
-    h = gelu(linear(h, sd[p + "mlp.fc1.weight"], sd[p + "mlp.fc1.bias"]))
-    return x + m2 * (sd[p + "gamma_2"] * linear(h, sd[p + "mlp.fc2.weight"], sd[p + "mlp.fc2.bias"]))
+    h = _q(gelu_mm(mm_linear(h, sd[p + "mlp.fc1.weight"], sd[p + "mlp.fc1.bias"], x_grad=True)))
+    return x + m2 * _qg(sd[p + "gamma_2"] * mm_linear(h, sd[p + "mlp.fc2.weight"], sd[p + "mlp.fc2.bias"], out="raw"))
 
 
 def vision_encoder(sd, cfg, image, idx_to_group_img=None, image_atts=None, drop_path=None):
@@ -259,12 +350,12 @@ def text_embeddings(sd, cfg, ids, drop=None):
 def bert_attention(sd, cfg, prefix, h, kv_src, add_mask, drop=None, site=""):
     """Self- or cross-attention sub-block with post-LN residual. xbert.py:322-431.
     drop(name) -> dropout multiplier tensor for site+".probs" / site+".out" (training mode) or None."""
-    q = split_heads(linear(h, sd[prefix + "self.query.weight"], sd[prefix + "self.query.bias"]), cfg.heads)
-    k = split_heads(linear(kv_src, sd[prefix + "self.key.weight"], sd[prefix + "self.key.bias"]), cfg.heads)
-    v = split_heads(linear(kv_src, sd[prefix + "self.value.weight"], sd[prefix + "self.value.bias"]), cfg.heads)
+    q = split_heads(mm_linear(h, sd[prefix + "self.query.weight"], sd[prefix + "self.query.bias"], out="bf16"), cfg.heads)
+    k = split_heads(mm_linear(kv_src, sd[prefix + "self.key.weight"], sd[prefix + "self.key.bias"], out="bf16"), cfg.heads)
+    v = split_heads(mm_linear(kv_src, sd[prefix + "self.value.weight"], sd[prefix + "self.value.bias"], out="bf16"), cfg.heads)
     ctx = merge_heads(attention_core(q, k, v, 1.0 / math.sqrt(cfg.hidden // cfg.heads), add_mask,
                                      drop(site + ".probs") if drop is not None else None))
-    o = linear(ctx, sd[prefix + "output.dense.weight"], sd[prefix + "output.dense.bias"])
+    o = mm_linear(ctx, sd[prefix + "output.dense.weight"], sd[prefix + "output.dense.bias"])
     if drop is not None:
         o = o * drop(site + ".out")
     return layer_norm(o + h, sd[prefix + "output.LayerNorm.weight"], sd[prefix + "output.LayerNorm.bias"], 1e-12)
@@ -276,8 +367,8 @@ def bert_layer(sd, cfg, i, h, self_mask, enc, enc_mask, drop=None):
     h = bert_attention(sd, cfg, p + "attention.", h, h, self_mask, drop, "L%d.self" % i)
     if i >= cfg.fusion_at and enc is not None:
         h = bert_attention(sd, cfg, p + "crossattention.", h, enc, enc_mask, drop, "L%d.cross" % i)
-    f = gelu(linear(h, sd[p + "intermediate.dense.weight"], sd[p + "intermediate.dense.bias"]))
-    o = linear(f, sd[p + "output.dense.weight"], sd[p + "output.dense.bias"])
+    f = _q(gelu_mm(mm_linear(h, sd[p + "intermediate.dense.weight"], sd[p + "intermediate.dense.bias"])))
+    o = mm_linear(f, sd[p + "output.dense.weight"], sd[p + "output.dense.bias"])
     if drop is not None:
         o = o * drop("L%d.ffn.out" % i)
     return layer_norm(o + h, sd[p + "output.LayerNorm.weight"], sd[p + "output.LayerNorm.bias"], 1e-12)
@@ -336,7 +427,9 @@ def rerank_scores(sd, cfg, image_feats, image_embeds, text_feats, text_atts, tex
 
 def head_mlp(sd, name, x):
     """build_mlp: Linear -> LayerNorm(1e-5) -> GELU -> Linear. xvlm.py:163-169."""
-    h = linear(x, sd[name + ".0.weight"], sd[name + ".0.bias"])
+    w0 = sd[name + ".0.weight"]
+    on_mfma = w0.shape[1] % 64 == 0 and w0.shape[0] % 8 == 0 and x.numel() % 4 == 0      # ops.mlp_head's own rule
+    h = (mm_linear if on_mfma else linear)(x, w0, sd[name + ".0.bias"])
     h = gelu(layer_norm(h, sd[name + ".1.weight"], sd[name + ".1.bias"], 1e-5))
     return linear(h, sd[name + ".3.weight"], sd[name + ".3.bias"])
 
@@ -371,14 +464,20 @@ def matching_loss(sd, cfg, image_embeds, image_atts, text_embeds_, text_atts, ne
     return cross_entropy(logits, labels), logits
 
 
-def mlm_logits(sd, cfg, ids_masked, text_atts, image_embeds, image_atts, masked_pos):
+def mlm_logits(sd, cfg, ids_masked, text_atts, image_embeds, image_atts, masked_pos, return_hidden=False):
     """xbert.py:1591-1661: full multi_modal pass, gather masked positions, transform, tied decoder."""
-    h = cross_embeds(sd, cfg, image_embeds, image_atts, text_atts, text_ids=ids_masked)
+    seq = cross_embeds(sd, cfg, image_embeds, image_atts, text_atts, text_ids=ids_masked)
+    if return_hidden:
+        return mlm_logits_from_hidden(sd, seq, masked_pos), seq
+    return mlm_logits_from_hidden(sd, seq, masked_pos)
+
+
+def mlm_logits_from_hidden(sd, h, masked_pos):
     h = h.gather(1, masked_pos.unsqueeze(-1).expand(-1, -1, h.shape[-1]))
     p = "text_encoder.cls.predictions."
-    h = gelu(linear(h, sd[p + "transform.dense.weight"], sd[p + "transform.dense.bias"]))
+    h = gelu_mm(mm_linear(h, sd[p + "transform.dense.weight"], sd[p + "transform.dense.bias"]))
     h = layer_norm(h, sd[p + "transform.LayerNorm.weight"], sd[p + "transform.LayerNorm.bias"], 1e-12)
-    return linear(h, sd["text_encoder.bert.embeddings.word_embeddings.weight"], sd[p + "bias"])
+    return mm_linear(h, sd["text_encoder.bert.embeddings.word_embeddings.weight"], sd[p + "bias"])
 
 
 def box_cxcywh_to_xyxy(b):
@@ -413,10 +512,25 @@ def bbox_loss(coord, target, is_image):
 
 # --------------------------------------------------------------------------- the step
 
-def xvlm_forward(sd, cfg, batch, neg_idx, ret_bbox_loss=False, ret_match_loss=True, gather=None):
-    """model_pretrain.py:30-88 (XVLM.forward / forward_multimodal).  Returns (losses, extras).
-    `gather(t)` stands in for the ITC all-gather (identity when None)."""
-    image = batch["image"]
+def xvlm_forward_text(sd, cfg, batch):
+    """model_pretrain.py:67-72 (XVLM.forward_text, the image=None branch of forward: Pretrain.run_text_iter): the masked ids
+    through all text_layers layers WITHOUT cross-attention (xbert.py:595: no encoder states), MLM head, {'loss_mlm'}."""
+    logits, seq = mlm_logits(sd, cfg, batch["text_ids_masked"], batch["text_atts"], None, None, batch["masked_pos"], return_hidden=True)
+    # text_embeds: what the reference's bert forward hook sees in this iteration - the full-depth sequence output
+    ex = {"mlm_logits": logits, "mlm_lse": torch.logsumexp(logits.double(), dim=-1).float(), "text_embeds": seq}
+    return {"loss_mlm": cross_entropy(logits.reshape(-1, cfg.vocab), batch["masked_ids"].reshape(-1))}, ex
+
+
+def xvlm_forward(sd, cfg, batch, neg_idx, ret_bbox_loss=False, ret_match_loss=True, gather=None, round_operands=None):
+    """model_pretrain.py:30-88 (XVLM.forward / forward_multimodal; image absent or None: forward_text).  Returns (losses, extras).
+    `gather(t)` stands in for the ITC all-gather (identity when None).  round_operands=torch.bfloat16: the operand-rounding-aware
+    mode (module docstring)."""
+    if round_operands is not None:
+        with rounding(round_operands):
+            return xvlm_forward(sd, cfg, batch, neg_idx, ret_bbox_loss, ret_match_loss, gather)
+    image = batch.get("image")
+    if image is None:
+        return xvlm_forward_text(sd, cfg, batch)
     ex = {}
     if ret_bbox_loss:
         image_embeds, full = vision_encoder(sd, cfg, image, batch["idx_to_group_img"], batch["image_atts"])

@@ -1,6 +1,7 @@
 """NT GEMM: the 128-column kernels (automatic tile choice) against the 8-wave 256-column kernel at its four tile heights,
 on every (shape, epilogue feature set) the X2VLM-base and -large steps launch.  Interleaved rounds in ONE process, minimum of
-three.  `noepi` = the same launch with the epilogue compiled out (x2_tune(2, 4)): main loops alone.
+three.  `noepi` = the same launch with the epilogue compiled out (x2_tune(2, 4)): main loops alone - needs the probe build
+(bash probes/build_probe.sh; X2VLM_HIP_LIB=probes/_probe/libx2vlm_hip_probe.so), the shipped library refuses the switch.
     python probes/bench_nt256.py [base|large|all]"""
 import importlib
 import os

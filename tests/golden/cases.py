@@ -54,7 +54,52 @@ CASES = {
     "video_full": dict(image_res=224, vision_layers=12, hidden=768, heads=12, ffn=3072, vocab=30522,
                        max_pos=512, text_layers=18, fusion_at=12, embed_dim=256, batch=2, seq_len=30,
                        max_masks=12, ragged=True, region=False, frames=8, wseed=81, bseed=82),
+    # ---- API branches of XVLM.forward that the headline iteration does not take (round 5) ------------------------------------
+    # image=None: Pretrain.run_text_iter -> XVLM.forward_text (model_pretrain.py:67-72): the 18-layer multi_modal pass WITHOUT
+    # cross-attention + MLM head; only loss_mlm, no vision tower, no ITC / ITM
+    "tiny_text": dict(image_res=32, vision_layers=2, hidden=128, heads=2, ffn=256, vocab=512, max_pos=64,
+                      text_layers=4, fusion_at=2, embed_dim=32, batch=4, seq_len=8, max_masks=3,
+                      ragged=True, region=False, frames=0, wseed=17, bseed=18, text_only=True),
+    "base_shallow_text": dict(image_res=224, vision_layers=2, hidden=768, heads=12, ffn=3072, vocab=30522,
+                              max_pos=512, text_layers=3, fusion_at=2, embed_dim=256, batch=4, seq_len=30,
+                              max_masks=12, ragged=True, region=False, frames=0, wseed=23, bseed=24, text_only=True),
+    # ret_match_loss=False (model_pretrain.py:49-52): loss_itm = tensor(0.0), the fusion batch is B rows (MLM only), not 4B
+    "tiny_nomatch": dict(image_res=32, vision_layers=2, hidden=128, heads=2, ffn=256, vocab=512, max_pos=64,
+                         text_layers=4, fusion_at=2, embed_dim=32, batch=4, seq_len=8, max_masks=3,
+                         ragged=True, region=False, frames=0, wseed=19, bseed=20, match=False),
+    "base_shallow_nomatch": dict(image_res=224, vision_layers=2, hidden=768, heads=12, ffn=3072, vocab=30522,
+                                 max_pos=512, text_layers=3, fusion_at=2, embed_dim=256, batch=4, seq_len=30,
+                                 max_masks=12, ragged=True, region=False, frames=0, wseed=25, bseed=26, match=False),
+    # a degenerate TARGET box (negative width) in a region batch: the reference's early-out zeroes every row's GIoU term and
+    # never evaluates generalized_box_iou (xvlm.py:940-946); L1 and all other losses unchanged
+    "tiny_region_degenerate": dict(image_res=32, vision_layers=2, hidden=128, heads=2, ffn=256, vocab=512, max_pos=64,
+                                   text_layers=4, fusion_at=2, embed_dim=32, batch=6, n_images=3, seq_len=8,
+                                   max_masks=3, ragged=True, region=True, frames=0, wseed=13, bseed=14, degenerate=True),
 }
+
+
+def make_batch(synthetic, c):
+    """The seeded batch of a case (CPU tensors), incl. the case's own twists (degenerate target box)."""
+    if c["region"]:
+        b = synthetic.synth_region_batch(c["bseed"], c["n_images"], c["batch"], c["seq_len"], c["image_res"], 16, c["vocab"],
+                                         c["max_masks"])
+        if c.get("degenerate"):
+            b["target_bbox"][1, 2] = -0.25          # row 1 is a region row (is_image == 0): negative width
+    else:
+        b = synthetic.synth_batch(c["bseed"], c["batch"], c["seq_len"], c["image_res"], c["vocab"], c["max_masks"],
+                                  ragged=c["ragged"], frames=c["frames"])
+    return b
+
+
+def forward_kwargs(c, batch):
+    """Keyword arguments of XVLM.forward for a case (reference and HIP model take the same ones)."""
+    kw = dict(text_ids_masked=batch["text_ids_masked"], masked_pos=batch["masked_pos"], masked_ids=batch["masked_ids"])
+    if c["region"]:
+        kw.update(image_atts=batch["image_atts"], idx_to_group_img=batch["idx_to_group_img"],
+                  target_bbox=batch["target_bbox"], is_image=batch["is_image"], ret_bbox_loss=True)
+    if not c.get("match", True):
+        kw.update(ret_match_loss=False)
+    return kw
 
 
 def model_config(case, workdir):

@@ -25,7 +25,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, HERE)
 
 import reference_shims  # noqa: E402
-from cases import CASES, SMALL, model_config, reduce_out  # noqa: E402
+from cases import CASES, SMALL, forward_kwargs, make_batch, model_config, reduce_out  # noqa: E402
 
 synthetic = importlib.import_module("x2-vlm_amd.synthetic")
 
@@ -45,12 +45,7 @@ def run_case(name):
         for blk in model.vision_encoder.blocks:
             blk.forward = (lambda *a, _f=blk.forward, **k: checkpoint(_f, *a, use_reentrant=False, **k))
 
-    if c["region"]:
-        batch = synthetic.synth_region_batch(c["bseed"], c["n_images"], c["batch"], c["seq_len"],
-                                             c["image_res"], 16, c["vocab"], c["max_masks"])
-    else:
-        batch = synthetic.synth_batch(c["bseed"], c["batch"], c["seq_len"], c["image_res"], c["vocab"],
-                                      c["max_masks"], ragged=c["ragged"], frames=c["frames"])
+    batch = make_batch(synthetic, c)
     neg = synthetic.synth_negatives(c["bseed"], c["batch"])
     model.get_hard_negatives = lambda *a, **k: neg
 
@@ -73,12 +68,9 @@ def run_case(name):
     model.bbox_head.register_forward_hook(hook("bbox_logits"))
 
     t0 = time.time()
-    kw = dict(text_ids_masked=batch["text_ids_masked"], masked_pos=batch["masked_pos"],
-              masked_ids=batch["masked_ids"])
-    if c["region"]:
-        kw.update(image_atts=batch["image_atts"], idx_to_group_img=batch["idx_to_group_img"],
-                  target_bbox=batch["target_bbox"], is_image=batch["is_image"], ret_bbox_loss=True)
-    loss = model(batch["image"], batch["text_ids"], batch["text_atts"], **kw)
+    kw = forward_kwargs(c, batch)
+    # image=None: Pretrain.run_text_iter's call (Pretrain.py:143)
+    loss = model(None if c.get("text_only") else batch["image"], batch["text_ids"], batch["text_atts"], **kw)
     total = sum(loss.values())
     total.backward()
     dt = time.time() - t0
@@ -86,11 +78,12 @@ def run_case(name):
     out = {}
     for k, v in loss.items():
         out[k] = np.array(v.item(), dtype=np.float64)
-    img_feat = torch.nn.functional.normalize(cap["vision_proj"], dim=-1)
-    txt_feat = torch.nn.functional.normalize(cap["text_proj"], dim=-1)
-    cap["image_feat"], cap["text_feat"] = img_feat, txt_feat
-    cap["itc_logits"] = img_feat @ txt_feat.t() / model.temp.detach()
-    del cap["vision_proj"], cap["text_proj"]
+    if "vision_proj" in cap:                     # absent in a text-only iteration
+        img_feat = torch.nn.functional.normalize(cap["vision_proj"], dim=-1)
+        txt_feat = torch.nn.functional.normalize(cap["text_proj"], dim=-1)
+        cap["image_feat"], cap["text_feat"] = img_feat, txt_feat
+        cap["itc_logits"] = img_feat @ txt_feat.t() / model.temp.detach()
+        del cap["vision_proj"], cap["text_proj"]
     if "bbox_logits" in cap:
         cap["bbox_coord"] = cap.pop("bbox_logits").sigmoid()
     if "mlm_logits" in cap:

@@ -237,6 +237,11 @@ def test_file_rendezvous_ignores_leftovers_of_a_crashed_launch(tmp_path):
         f.write(stale)
     open(path + ".hello1", "w").close()
     open(path + ".ack2", "w").close()
+    open(path + ".hello0", "w").close()                  # rank 0's own leftovers are removed as well
+    open(path + ".ack0", "w").close()
+    # timestamps must not matter (coarse mtime granularity / clock skew on shared file systems): the stale id "from the future"
+    future = time.time() + 3600
+    os.utime(path, (future, future))
     world, got, errs = 3, {}, []
 
     def run(rank, delay):

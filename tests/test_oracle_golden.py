@@ -8,17 +8,28 @@ import pytest
 import torch
 
 from cases import CASES, reduce_out
+from cases import make_batch as case_batch
 from oracle import x2vlm_oracle as O
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
 
 def make_batch(synthetic, c):
-    if c["region"]:
-        return synthetic.synth_region_batch(c["bseed"], c["n_images"], c["batch"], c["seq_len"],
-                                            c["image_res"], 16, c["vocab"], c["max_masks"])
-    return synthetic.synth_batch(c["bseed"], c["batch"], c["seq_len"], c["image_res"], c["vocab"],
-                                 c["max_masks"], ragged=c["ragged"], frames=c["frames"])
+    b = case_batch(synthetic, c)
+    if c.get("text_only"):
+        b = {k: v for k, v in b.items() if k != "image"}          # Pretrain.run_text_iter: model(None, text_ids, ...)
+    return b
+
+
+def oracle_step(c, synthetic, round_operands=None):
+    cfg = O.config_from_case(c)
+    sd = O.make_params(cfg, c["wseed"], synthetic.synth_tensor)
+    batch = make_batch(synthetic, c)
+    neg = synthetic.synth_negatives(c["bseed"], c["batch"])
+    losses, ex = O.xvlm_forward(sd, cfg, batch, neg, ret_bbox_loss=c["region"], ret_match_loss=c.get("match", True),
+                                round_operands=round_operands)
+    sum(losses.values()).backward()
+    return sd, losses, ex, neg
 
 
 def close(a, b, rtol, what, floor=1e-6):
@@ -29,6 +40,7 @@ def close(a, b, rtol, what, floor=1e-6):
 
 
 @pytest.mark.parametrize("case", ["tiny", "tiny_region", "tiny_video", "base_shallow", "large_shallow", "base_region",
+                                  "tiny_text", "base_shallow_text", "tiny_nomatch", "base_shallow_nomatch", "tiny_region_degenerate",
                                   pytest.param("base_full", marks=pytest.mark.slow),
                                   pytest.param("base_full_b64", marks=pytest.mark.slow),
                                   pytest.param("large_full", marks=pytest.mark.slow),
@@ -36,14 +48,14 @@ def close(a, b, rtol, what, floor=1e-6):
 def test_oracle_matches_reference(case, synthetic):
     c = CASES[case]
     gold = np.load(os.path.join(GOLD, case + ".npz"))
-    cfg = O.config_from_case(c)
-    sd = O.make_params(cfg, c["wseed"], synthetic.synth_tensor)
-    batch = make_batch(synthetic, c)
-    neg = synthetic.synth_negatives(c["bseed"], c["batch"])
-    assert np.array_equal(np.array(neg), gold["neg_idx"])
     torch.set_num_threads(8)
-    losses, ex = O.xvlm_forward(sd, cfg, batch, neg, ret_bbox_loss=c["region"])
-    sum(losses.values()).backward()
+    sd, losses, ex, neg = oracle_step(c, synthetic)
+    assert np.array_equal(np.array(neg), gold["neg_idx"])
+    assert sorted(losses) == sorted(k for k in gold.files if k.startswith("loss_"))
+    if c.get("degenerate"):
+        assert float(gold["loss_giou"]) == 0.0 and float(losses["loss_giou"]) == 0.0        # the reference's early-out, xvlm.py:943-946
+    if not c.get("match", True):
+        assert float(gold["loss_itm"]) == 0.0 and float(losses["loss_itm"]) == 0.0          # model_pretrain.py:52
     for k, v in losses.items():
         assert abs(v.item() - float(gold[k])) <= 1e-5 * max(1.0, abs(float(gold[k]))), (k, v.item(), float(gold[k]))
     full = case.startswith("tiny")
@@ -55,7 +67,7 @@ def test_oracle_matches_reference(case, synthetic):
         got = reduce_out(ex[name], full)[kind]
         close(got, gold[k], 2e-5 if kind != "moments" else 1e-4, k)
         checked += 1
-    assert checked >= 8
+    assert checked >= (2 if c.get("text_only") else 6)
     sq = 0.0
     # key biases have an analytically zero gradient (softmax shift invariance): their stored
     # grads are ~1e-8 rounding noise, so every grad is compared on a floor tied to the total norm
@@ -77,3 +89,36 @@ def test_oracle_matches_reference(case, synthetic):
             name = k[len("grad/"):]
             close(sd[name].grad.numpy(), gold[k], 5e-5, k, floor=gfloor)
     assert abs(sq ** 0.5 - float(gold["total_grad_norm"])) <= 2e-5 * float(gold["total_grad_norm"])
+
+
+@pytest.mark.parametrize("case", ["tiny", "tiny_region", "tiny_text"])
+def test_operand_rounding_mode(case, synthetic):
+    """The rounded mode is the SAME program with bf16 roundings at the HIP path's operand sites: switched off (the default, or
+    an explicit rounding(None)) it is bit-identical to the pinned fp32 program; switched on it moves every loss by a
+    bf16-sized amount (not zero, not large) and leaves finite gradients for the same parameters."""
+    c = CASES[case]
+    torch.set_num_threads(8)
+    sd0, l0, _, _ = oracle_step(c, synthetic)
+    with O.rounding(None):
+        sd1, l1, _, _ = oracle_step(c, synthetic)
+    for k in l0:
+        assert float(l0[k]) == float(l1[k])
+    for n in sd0:
+        assert (sd0[n].grad is None) == (sd1[n].grad is None)
+        if sd0[n].grad is not None:
+            assert torch.equal(sd0[n].grad, sd1[n].grad), n
+    sd2, l2, _, _ = oracle_step(c, synthetic, round_operands=torch.bfloat16)
+    assert O._ROUND is None                                  # the context restored the default
+    moved = 0
+    for k in l0:
+        a, b = float(l0[k]), float(l2[k])
+        assert abs(a - b) <= 2e-2 * max(abs(a), 1e-3), (k, a, b)
+        moved += a != b
+    assert moved >= 1
+    for n in sd0:
+        if sd0[n].grad is not None:
+            g = sd2[n].grad
+            assert g is not None and bool(torch.isfinite(g).all()), n
+    tot0 = sum(float(t.grad.double().pow(2).sum()) for t in sd0.values() if t.grad is not None) ** 0.5
+    tot2 = sum(float(t.grad.double().pow(2).sum()) for t in sd2.values() if t.grad is not None) ** 0.5
+    assert 0 < abs(tot0 - tot2) <= 3e-2 * tot0

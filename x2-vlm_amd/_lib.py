@@ -85,7 +85,7 @@ _COMM_SIGS = {
     "x2_comm_broadcast": [P, P, L, I, I, P, P],
     "x2_comm_destroy": [P],
 }
-EXPORTS = sorted(list(_SIGS) + list(_COMM_SIGS) + ["x2_last_error", "x2_abi_version", "x2_device_cus", "x2_tune"])
+EXPORTS = sorted(list(_SIGS) + list(_COMM_SIGS) + ["x2_last_error", "x2_abi_version", "x2_device_cus", "x2_tune", "x2_tune_get"])
 
 _lib = None
 
@@ -112,9 +112,11 @@ def lib():
         h.x2_abi_version.restype = I
         h.x2_device_cus.restype = I
         h.x2_tune.argtypes, h.x2_tune.restype = [I, I], I
+        h.x2_tune_get.argtypes, h.x2_tune_get.restype = [I], I
         for kv in filter(None, os.environ.get("X2_TUNE", "").split(",")):      # probes: "key=value,..." kernel-variant knobs (csrc/gemm.hip)
             k, v = kv.split("=")
-            h.x2_tune(int(k), int(v))
+            if h.x2_tune(int(k), int(v)) != 0:
+                raise X2HipError("X2_TUNE=%s: %s" % (kv, h.x2_last_error().decode()))
         _lib = h
     return _lib
 

@@ -63,17 +63,29 @@ class X2Comm:
 
     @classmethod
     def _from_file(cls, path, rank, world, timeout=120.0):
-        """File rendezvous that survives leftovers of a crashed launch with the same name (default port, same sequence number):
-        every rank announces itself (`path.hello<r>`), rank 0 first removes whatever it finds under this name, waits for all
-        announcements and only THEN publishes the id - so the id of this launch is newer than every announcement, and a rank
-        accepts nothing older than its own first announcement.  A rank whose announcement rank 0's clean-up removed writes it
-        again.  Time-outs raise; rank 0 removes the files once every rank has joined and acknowledged."""
+        """File rendezvous that survives leftovers of a crashed launch with the same name (default port, same sequence number)
+        WITHOUT trusting file timestamps (coarse mtime granularity / clock skew on shared file systems): every rank r > 0 draws
+        a random 16-byte token and announces it (`path.hello<r>`); rank 0 first removes whatever it finds under this name
+        (its own leftovers included), waits for all announcements, and publishes the RCCL id FOLLOWED BY the tokens it
+        collected.  A rank accepts an id file only if it carries the rank's own token at the rank's position - an id left behind
+        by an earlier launch cannot (fresh random token), however new its timestamp looks.  A rank whose announcement rank 0's
+        clean-up removed writes it again (same token).  Time-outs raise; rank 0 removes the files once every rank has joined
+        and acknowledged."""
         hello, ack = "%s.hello%d" % (path, rank), "%s.ack%d" % (path, rank)
+        TOK = 16
 
-        def touch(p):
-            with open(p, "w"):
-                pass
-            return os.stat(p).st_mtime_ns
+        def put(p, data=b""):
+            with open(p + ".tmp%d" % rank, "wb") as f:
+                f.write(data)
+            os.replace(p + ".tmp%d" % rank, p)      # readers never see a half-written file
+
+        def get(p, n):
+            try:
+                with open(p, "rb") as f:
+                    d = f.read()
+                return d if len(d) == n else None
+            except OSError:
+                return None
 
         def wait(cond, what):
             t0 = time.time()
@@ -85,32 +97,40 @@ class X2Comm:
         if rank == 0:
             for r in range(world):
                 for f in ("%s.hello%d" % (path, r), "%s.ack%d" % (path, r)):
-                    if r != 0 and os.path.exists(f):
+                    if os.path.exists(f):
                         os.remove(f)
-            for f in (path, path + ".tmp"):
+            for f in (path, path + ".tmp0"):
                 if os.path.exists(f):
                     os.remove(f)
-            wait(lambda: all(os.path.exists("%s.hello%d" % (path, r)) for r in range(1, world)), "every rank's announcement")
-            with open(path + ".tmp", "wb") as f:
-                f.write(cls.unique_id())
-            os.replace(path + ".tmp", path)
-            with open(path, "rb") as f:
-                ident = f.read()
-        else:
-            first = touch(hello)
+            tokens = {}
 
-            def fresh():
+            def all_announced():
+                for r in range(1, world):
+                    if r not in tokens:
+                        t = get("%s.hello%d" % (path, r), TOK)
+                        if t is not None:
+                            tokens[r] = t
+                return len(tokens) == world - 1
+            wait(all_announced, "every rank's announcement")
+            ident = cls.unique_id()
+            put(path, ident + b"".join(tokens[r] for r in range(1, world)))
+        else:
+            token = os.urandom(TOK)
+            put(hello, token)
+            found = {}
+
+            def mine():
                 if not os.path.exists(hello):
-                    touch(hello)                  # removed by rank 0's clean-up: announce again
-                try:
-                    return os.stat(path).st_mtime_ns >= first
-                except OSError:
-                    return False
-            wait(fresh, "rank 0's RCCL id")
-            with open(path, "rb") as f:
-                ident = f.read()
+                    put(hello, token)             # removed by rank 0's clean-up: announce again
+                d = get(path, 128 + TOK * (world - 1))
+                if d is not None and d[128 + TOK * (rank - 1): 128 + TOK * rank] == token:
+                    found["id"] = d[:128]
+                    return True
+                return False
+            wait(mine, "rank 0's RCCL id carrying this rank's token")
+            ident = found["id"]
         comm = cls(ident, rank, world)            # x2_comm_init returns once every rank has joined: all have read the id
-        touch(ack)
+        put(ack)
         if rank == 0:
             wait(lambda: all(os.path.exists("%s.ack%d" % (path, r)) for r in range(world)), "every rank's acknowledgement")
             for r in range(world):

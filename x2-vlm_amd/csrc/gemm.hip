@@ -34,7 +34,8 @@ struct GemmNT {
   const uint32_t* drop_epoch;  // device step counter mixed into drop.seed, or NULL (x2_common.h drop_at_epoch)
   const float* rowscale;    // [M] per-row factor before the residual add: DropPath keep/(1-p) per sample (beit2.py:206-207)
   float* colsum;            // [N] += column sums of the stored C (bias gradient of the layer below, fused)
-  int dbg;                  // ablation switches for probes: 4 = no epilogue, 16 = sc1 output stores
+  int dbg;                  // ablation switches, -DX2_PROBE builds only (probes/build_probe.sh): 4 = no epilogue, 16 = sc1 output stores;
+                            // the shipped library compiles both out (NT_DBG below) and x2_tune(2, v != 0) is refused
   int ksplit;               // split-contraction launches (epilogue variant 7): columns of A / B per blockIdx.y slice
   // fused MLM cross-entropy (epilogue variants 8 / 9, x2_mlm_ce_fwd / _bwd): the logits never leave the accumulators
   const long* ce_labels;    // [M] target column or < 0 (ignored row)
@@ -88,6 +89,11 @@ __device__ __forceinline__ void st16(void* p, u32x4 v, bool wt) {
 //     partial row colsum[2 * row tile + wave row][N]; the caller reduces the partial rows (x2_reduce_partials*): replaces a
 //     stand-alone pass over the [M, 4D] gradient (x2_colsum_bf16: 77 MB read per vision block) without the atomics that
 //     made the first fused form slower than that pass
+#ifdef X2_PROBE
+#define NT_DBG(p, bit) (((p).dbg & (bit)) != 0)
+#else
+#define NT_DBG(p, bit) false
+#endif
 template <int V> struct EpiTraits {
   static constexpr bool generic = V == 4;
   static constexpr int act = V == 2 ? 1 : (V == 3 || V == 10) ? 2 : 0;
@@ -124,7 +130,7 @@ __device__ __forceinline__ void nt_epilogue(const GemmNT& p, f32x4 (&acc)[TM][4]
   if (nok && has_scale && p.gamma) { const float4 g0 = *reinterpret_cast<const float4*>(p.gamma + n), g1 = *reinterpret_cast<const float4*>(p.gamma + n + 4);
     gg[0] = g0.x; gg[1] = g0.y; gg[2] = g0.z; gg[3] = g0.w; gg[4] = g1.x; gg[5] = g1.y; gg[6] = g1.z; gg[7] = g1.w; }
   float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  const bool wt = (p.dbg & 16) != 0;
+  const bool wt = NT_DBG(p, 16);
   const DropSpec drop_ = drop_at_epoch(p.drop, p.drop_epoch);
 #pragma unroll
   for (int half = 0; half < (TM + 1) / 2; ++half) {
@@ -440,7 +446,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNT p) {
     nt_epilogue_f4<TM, VAR>(p, acc, smem, wave, lane, m0 + wm * 16 * TM, n0 + wn * 64);
     return;
   }
-  if (p.dbg & 4) { if (acc[0][0][0] == 12345.678f) reinterpret_cast<float*>(p.C)[0] = acc[1][1][1] + acc[2][2][2] + acc[3][3][3]; return; }
+  if (NT_DBG(p, 4)) { if (acc[0][0][0] == 12345.678f) reinterpret_cast<float*>(p.C)[0] = acc[1][1][1] + acc[2][2][2] + acc[3][3][3]; return; }
   nt_epilogue<TM, VAR>(p, acc, smem, wave, lane, m0 + wm * 16 * TM, n0 + wn * 64, tm * 2 + wm);
 }
 
@@ -584,30 +590,48 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmNT p) {
   ktile(kt, std::false_type{}, std::false_type{});
 #undef N2_FENCE
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");       // every wave is done reading operand tiles
-  if (p.dbg & 4) { if (acc[0][0][0] == 12345.678f) reinterpret_cast<float*>(p.C)[0] = acc[1][1][1] + acc[2][2][2] + acc[3][3][3]; return; }
+  if (NT_DBG(p, 4)) { if (acc[0][0][0] == 12345.678f) reinterpret_cast<float*>(p.C)[0] = acc[1][1][1] + acc[2][2][2] + acc[3][3][3]; return; }
   nt_epilogue<TMW, VAR>(p, acc, smem, wave, lane, m0 + wr * HROWS, n0 + wc * 64);
 }
 
 // knobs for A/B measurements and for the tests that pin a kernel variant (0 = automatic everywhere)
 //   [0] GROUP_M of the NT tile raster            [1] 0: automatic, 1: 128-column kernels only, 3: always the 256-column kernel
-//   [2] NT ablation bits (4 no epilogue, 16 sc1 stores)          [6] 1: always the generic (run-time flags) NT epilogue
+//   [2] NT ablation bits (4 no epilogue, 16 sc1 stores): -DX2_PROBE builds only, refused by the shipped library
+//   [6] 1: always the generic (run-time flags) NT epilogue
 //   [3] NT tile: 1 = 128x128, 2 = 192x128, 3 = 64x128, 4 = 160x128; 5..8 = rows / 32 of the 256-column kernel        [7] 1: no 160x128 NT tiles
 //   [5] TN: 1 = always 128x128 tiles, 2 = 256x256 tiles whenever the contraction lengths allow
 //   [9] percent of perfect CU fill the 256-column NT kernel's plan must reach to be chosen automatically (0 = 80)
+//   [12] compute units every tile plan leaves out (0 = none): with more than one rank RCCL's channel kernels are resident on
+//        some CUs during the backward, and a plan that fills "whole rounds of the 256 CUs" becomes two rounds when a few of
+//        them are taken - graph.SegmentedStep sets it to the channel count it caps RCCL at (X2_RESERVED_CUS)
 static int g_tune[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-static int g_tune_x[4] = {0, 0, 0, 0};          // keys 8.. : [1] = key 9
+static int g_tune_x[5] = {0, 0, 0, 0, 0};       // keys 8.. : [1] = key 9, [4] = key 12
 extern "C" int x2_device_cus(void);
 // compute units of the current device (256 on MI355X), asked once: grid-fill decisions below are made in units of it
 static int x2_cus() {
   static int n = 0;
   if (n <= 0) { n = x2_device_cus(); if (n <= 0) n = 256; }
-  return n;
+  const int left = n - g_tune_x[4];
+  return left >= 16 ? left : 16;
 }
 extern "C" int x2_tune(int key, int value) {
-  if (key >= 9 && key < 12) { g_tune_x[key - 8] = value; return X2_OK; }
-  if (key < 0 || key >= 8) return X2_ERR_ARG;
+  if (key >= 9 && key <= 12) {
+    X2_REQUIRE(key != 12 || value >= 0, "x2_tune: reserved compute units = %d", value);
+    g_tune_x[key - 8] = value;
+    return X2_OK;
+  }
+  X2_REQUIRE(key >= 0 && key < 8, "x2_tune: no key %d", key);
+#ifndef X2_PROBE
+  X2_REQUIRE(key != 2 || value == 0, "x2_tune: NT ablation bits (key 2, value %d) exist in -DX2_PROBE builds only", value);
+#endif
   g_tune[key] = value;
   return X2_OK;
+}
+// current value of a knob (bench.py reports every non-default one in its JSON line); -1 for a key that does not exist
+extern "C" int x2_tune_get(int key) {
+  if (key >= 9 && key <= 12) return g_tune_x[key - 8];
+  if (key < 0 || key >= 8) return -1;
+  return g_tune[key];
 }
 
 // 256-column kernel: tile height for this problem.  A launch is a few rounds of one workgroup per CU, each round as long as

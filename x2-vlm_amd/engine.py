@@ -150,6 +150,8 @@ class WeightBank:
             ent = self._c.get(key)
             if ent is not None and ent[0] == vers:
                 continue
+            if any(not isinstance(it, int) and (it.dtype != F32 or not it.is_contiguous() or not it.is_cuda) for it in items):
+                continue                                   # raw-address copy below: left to `vector`'s reshape + cat build
             n = sum(it if isinstance(it, int) else it.numel() for it in items)
             todo.append((key, vers, items, n))
             total += (n + 3) // 4 * 4
@@ -176,12 +178,15 @@ class WeightBank:
 
         ent = self._c.get(key)
         if ent is None or ent[0] != vers:
-            if next(it for it in items if not isinstance(it, int)).is_cuda:
+            tens = [it for it in items if not isinstance(it, int)]
+            # the multi-tensor launch copies numel() floats from the raw address: only fp32, contiguous items qualify
+            # (anything else - a sliced or half-precision bias - takes the reshape + cat build below, which handles both)
+            if tens[0].is_cuda and all(it.dtype == F32 and it.is_contiguous() for it in tens):
                 self.prepare_vectors([items])          # one multi-tensor launch (zeros included) instead of zeros + cat
                 ent = self._c[key]
             else:
                 dev = next(it for it in items if not isinstance(it, int)).device
-                val = torch.cat([torch.zeros(it, device=dev, dtype=F32) if isinstance(it, int) else it.detach().reshape(-1) for it in items])
+                val = torch.cat([torch.zeros(it, device=dev, dtype=F32) if isinstance(it, int) else it.detach().reshape(-1).to(F32) for it in items])
                 ent = self._c[key] = (vers, val, tuple(weakref.ref(it) for it in items if not isinstance(it, int)))
         return ent[1]
 

@@ -74,18 +74,24 @@ def dropout_keep(spec, index):
 
 _WS = {}
 _WS_RETIRED = []
+_WS_CAPTURED = set()        # data_ptr of every workspace a stream capture has been handed
 
 
 def workspace(device, nfloats):
     """Scratch for the two-stage column reductions: one growing fp32 buffer per (device, stream); kernels on one
-    stream use it strictly in order (stage 1 writes, stage 2 reads, next kernel overwrites)."""
+    stream use it strictly in order (stage 1 writes, stage 2 reads, next kernel overwrites).
+    Growth is geometric (a run whose shapes creep upwards - variable batch / caption length, several configurations in one
+    process - re-allocates O(log) times, not once per new size), and an outgrown buffer is kept alive only if a stream
+    capture has seen it (a captured hipGraph has its address baked in); otherwise the caching allocator gets it back."""
     key = (device, raw_stream())
     buf = _WS.get(key)
     if buf is None or buf.numel() < nfloats:
-        if buf is not None:
-            _WS_RETIRED.append(buf)        # a captured hipGraph may have this address baked in: a retired buffer is never freed
-        buf = torch.empty(max(nfloats, 1 << 22), device=device, dtype=F32)
+        if buf is not None and buf.data_ptr() in _WS_CAPTURED:
+            _WS_RETIRED.append(buf)
+        buf = torch.empty(max(nfloats, 1 << 22, 0 if buf is None else 2 * buf.numel()), device=device, dtype=F32)
         _WS[key] = buf
+    if buf.is_cuda and torch.cuda.is_current_stream_capturing():
+        _WS_CAPTURED.add(buf.data_ptr())
     return buf
 
 
