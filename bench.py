@@ -198,6 +198,12 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
+        if backend == "nccl":
+            # RCCL's channel kernels are resident on one CU each for most of the backward (the all-reduces run under it): cap
+            # them, and let every GEMM tile plan leave that many CUs out (graph.SegmentedStep -> x2_tune(12, n)) - a plan
+            # that fills "one round of 256 CUs" becomes two rounds when a few are taken.  1 GB per step under an 11 ms
+            # backward needs ~100 GB/s: well within 16 channels over 7 xGMI links.  X2_RCCL_CHANNELS / NCCL_MAX_NCHANNELS override.
+            os.environ.setdefault("NCCL_MAX_NCHANNELS", os.environ.get("X2_RCCL_CHANNELS", "16"))
         dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
 
     K = importlib.import_module("x2-vlm_amd.kernels")

@@ -151,8 +151,9 @@ def test_two_ranks_match_oracle_ddp_semantics(case, synthetic):
         assert torch.allclose(out[0]["g2"][n], out[1]["g2"][n], rtol=1e-5, atol=1e-7), n
 
 
-def _two_rank_segmented_worker(rank, world, port, case, ret):
+def _two_rank_segmented_worker(rank, world, port, case, ret, env=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), X2_DIST_BACKEND="gloo")
+    os.environ.update(env or {})
     synthetic = importlib.import_module("x2-vlm_amd.synthetic")
     mp_ = importlib.import_module("x2-vlm_amd.model_pretrain")
     acc = importlib.import_module("x2-vlm_amd.accelerator")
@@ -171,6 +172,7 @@ def _two_rank_segmented_worker(rank, world, port, case, ret):
         model.injected_negatives = tuple(neg)
         step = a.segmented_step(ddp, static, clamp_temp=False)
         out["mode"], out["error"] = step.mode, step.error
+        out["aux"], out["bf16"], out["reserved"] = step.aux_overlap, step.grad_bf16, step.reserved_cus
         loss = step()
         torch.cuda.synchronize()
         out["loss1"] = {k: float(v) for k, v in loss.items()}
@@ -215,26 +217,35 @@ def test_two_ranks_replayed_segments_match_oracle_ddp_semantics(case, synthetic)
         assert torch.allclose(out[0]["g2"][n], out[1]["g2"][n], rtol=1e-5, atol=1e-7), n
 
 
-@pytest.mark.parametrize("world", [4, 8])
-def test_many_ranks_replayed_segments_match_oracle_ddp_semantics(world, synthetic):
+@pytest.mark.parametrize("world,case,bf16", [(4, "tiny", False), (8, "tiny", False), (8, "base_shallow", False),
+                                             (2, "tiny", True), (8, "tiny", True)])
+def test_many_ranks_replayed_segments_match_oracle_ddp_semantics(world, case, bf16, synthetic):
     """BASELINE.json configs[2] is 8 ranks: the replayed step at 4 and 8 ranks sharing this GPU over gloo (RCCL refuses two ranks
-    on one device).  Every rank derives its reduction plan from its own capture - SegmentedStep compares the plans' digests at
-    set-up and raises on a mismatch instead of hanging; here: mode, message count equal on all ranks, losses and averaged
-    gradients equal to the oracle's W-rank semantics (global ITC loss over W * B gathered pairs, local rows attached)."""
+    on one device) - on the toy model and, at 8 ranks, at the real token geometry (base_shallow: N = 197, V = 30522).  Every rank
+    derives its reduction plan from its own capture - SegmentedStep compares the plans' digests at set-up and raises on a
+    mismatch instead of hanging; here: mode, message count equal on all ranks, losses and averaged gradients equal to the
+    oracle's W-rank semantics (global ITC loss over W * B gathered pairs, local rows attached).
+    bf16: X2_GRAD_BF16=1, the gradient arenas travel as bf16 (0.51 GB per step) and are averaged in bf16, fp32 at both
+    ends - same bounds (one more bf16 rounding per hop on top of the bf16 operands' noise), replicas still bit-identical.
+    With collectives in the step the tail segment's forked stream is off by default (host thread free for the collectives)."""
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_two_rank_segmented_worker, args=(world, _free_port(), "tiny", ret), nprocs=world, join=True)
+    env = dict(X2_GRAD_BF16="1" if bf16 else "0")
+    mp.spawn(_two_rank_segmented_worker, args=(world, _free_port(), case, ret, env), nprocs=world, join=True)
     out = [ret[r] for r in range(world)]
-    c = CASES["tiny"]
+    c = CASES[case]
     g_a, loss_a = _oracle_ddp(synthetic, c, world, 0)
-    g_b, _ = _oracle_ddp(synthetic, c, world, 1000)
+    big = case != "tiny"
+    g_b = None if big else _oracle_ddp(synthetic, c, world, 1000)[0]       # real geometry: the oracle's 8 ranks once (CPU time)
     assert len(set(o["messages"] for o in out)) == 1
     for r in range(world):
         assert out[r]["mode"] == "hipgraph-segments", out[r]["error"]
+        assert out[r]["aux"] is False and out[r]["bf16"] is bf16
         for k, v in loss_a[r].items():
             assert abs(out[r]["loss1"][k] - v) <= 5e-3 * max(abs(v), 1e-6), (r, k, out[r]["loss1"][k], v)
         _compare(out[r]["g1"], g_a, "rank %d of %d, first replay" % (r, world))
-        _compare(out[r]["g2"], g_b, "rank %d of %d, second replay (new data)" % (r, world))
+        if g_b is not None:
+            _compare(out[r]["g2"], g_b, "rank %d of %d, second replay (new data)" % (r, world))
     for r in range(1, world):
         for n in out[0]["g2"]:
             assert torch.allclose(out[0]["g2"][n], out[r]["g2"][n], rtol=1e-5, atol=1e-7), (r, n)

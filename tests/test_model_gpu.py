@@ -1,9 +1,11 @@
 """End-to-end GPU parity of the HIP training step (x2-vlm_amd.model_pretrain.XVLM, same call as
-Pretrain.py:59 / :90) against the golden vectors the REAL reference produced (tests/golden/*.npz),
+Pretrain.py:59 / :90 / :143) against the golden vectors the REAL reference produced (tests/golden/*.npz),
 on identical seeded weights, batches and injected hard negatives.
 
-Tolerances (bf16 GEMM/attention operands, fp32 everything else, vs the reference's fp32 CPU run): each bound is ~1.3-2x the worst
-deviation measured over the ten cases on MI355X (profiles/r03d_parity_worst.txt), so that a regression shows:
+Two sets of bounds per case:
+
+(A) against the reference's fp32 CPU run (the golden vectors: the pin).  bf16 GEMM / attention operands against fp32 ones through
+    ~36 GEMMs: each bound is ~1.3-2x the worst deviation measured on MI355X (profiles/*_parity_worst.txt), so that a regression shows:
   losses              1e-3 relative at the configurations' own per-GPU batches (cases base_full_b64 = BASELINE.json configs[1] and
                       large_full_b32 = configs[3]: the north-star tolerance; measured 6e-5 at B = 64); 5e-3 for the 2..8-sample toy batches, whose losses average the same per-sample
                       bf16 operand-rounding noise over 16x fewer samples (measured 4.7e-3, tiny_video)
@@ -16,6 +18,12 @@ deviation measured over the ten cases on MI355X (profiles/r03d_parity_worst.txt)
                       3e-4 of the total norm instead of to their own norm; small tensors stored in full: 4.5e-2 pointwise (3.0e-2);
                       total gradient norm: 2e-3 at batch 64 (8.8e-4), 3e-3 for the other full-geometry cases (1.8e-3), 6e-3 for
                       X2VLM-large at batch 32 (4.0e-3: 24 + 18 layers deep), 1.2e-2 for the 32-px toy models (8.7e-3)
+
+(B) against the oracle in its OPERAND-ROUNDING-AWARE mode (oracle.xvlm_forward(round_operands=torch.bfloat16): the same fp32
+    program with the matrix-core operands and the bf16-stored tensors rounded at the HIP path's sites), run on this box's host cores
+    for the CPU-cheap cases (ROUNDED below).  What is left between the two is accumulation order and second-order placement of
+    roundings, so the bounds are an order of magnitude tighter - a wrong epsilon, a dropped bias or a one-position mask slip in
+    one of 42 layers moves a tensor by far more than these (RB below; ~2x the measured worst, profiles/r09_parity_worst.txt).
 """
 import importlib
 import os
@@ -24,13 +32,20 @@ import numpy as np
 import pytest
 import torch
 
-from cases import CASES, model_config, reduce_out
+from cases import CASES, forward_kwargs, make_batch, model_config, reduce_out
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
-# pointwise bounds per tensor, as a fraction of its max-abs (see the table above)
+# (A) pointwise bounds per tensor against the fp32 goldens, as a fraction of its max-abs (see the table above)
 POINTWISE = dict(mlm_lse=2e-4, bbox_coord=5e-3, image_embeds=8e-3, image_feat=8e-3, text_embeds=1.6e-2, text_feat=1.6e-2,
                  itc_logits=2e-2, mlm_logits=2e-2, itm_logits=2.5e-2)
+# (B) bounds against the operand-rounding-aware oracle
+ROUNDED = ("tiny", "tiny_region", "tiny_video", "tiny_text", "tiny_nomatch", "tiny_region_degenerate", "base_shallow",
+           "base_shallow_text", "base_shallow_nomatch", "large_shallow", "base_region")
+RB = dict(loss=float(os.environ.get("X2_RB_LOSS", 1e-3)), pointwise=float(os.environ.get("X2_RB_POINT", 4e-3)),
+          moments=float(os.environ.get("X2_RB_MOM", 5e-4)), mlm_lse=float(os.environ.get("X2_RB_LSE", 1e-4)),
+          gradnorm=float(os.environ.get("X2_RB_GN", 8e-3)), grad=float(os.environ.get("X2_RB_GRAD", 1.5e-2)),
+          total=float(os.environ.get("X2_RB_TOTAL", 2e-3)))
 
 
 def run_case(case, tmpdir, synthetic):
@@ -41,43 +56,27 @@ def run_case(case, tmpdir, synthetic):
     model = mp.XVLM(config=cfg, load_vision_params=False, load_text_params=False, pretraining=True)
     synthetic.synth_state_dict(model, c["wseed"])
     model = model.cuda().eval()
-    if c["region"]:
-        batch = synthetic.synth_region_batch(c["bseed"], c["n_images"], c["batch"], c["seq_len"], c["image_res"], 16,
-                                             c["vocab"], c["max_masks"])
-    else:
-        batch = synthetic.synth_batch(c["bseed"], c["batch"], c["seq_len"], c["image_res"], c["vocab"], c["max_masks"],
-                                      ragged=c["ragged"], frames=c["frames"])
-    batch = {k: v.cuda() for k, v in batch.items()}
+    cpu_batch = make_batch(synthetic, c)
+    batch = {k: v.cuda() for k, v in cpu_batch.items()}
     model.injected_negatives = synthetic.synth_negatives(c["bseed"], c["batch"])
-    kw = dict(text_ids_masked=batch["text_ids_masked"], masked_pos=batch["masked_pos"], masked_ids=batch["masked_ids"])
-    if c["region"]:
-        kw.update(image_atts=batch["image_atts"], idx_to_group_img=batch["idx_to_group_img"],
-                  target_bbox=batch["target_bbox"], is_image=batch["is_image"], ret_bbox_loss=True)
+    kw = forward_kwargs(c, batch)
     eng = importlib.import_module("x2-vlm_amd.engine")
     eng.KEEP_MLM_LOGITS = True          # inspection copy of the MLM logits; the loss and its gradient still take the fused path
     try:
-        loss = model(batch["image"], batch["text_ids"], batch["text_atts"], **kw)
+        loss = model(None if c.get("text_only") else batch["image"], batch["text_ids"], batch["text_atts"], **kw)
     finally:
         eng.KEEP_MLM_LOGITS = False
     sum(loss.values()).backward()
     torch.cuda.synchronize()
-    return model, loss, c
+    return model, loss, c, cpu_batch
 
 
-@pytest.mark.parametrize("case", ["tiny", "tiny_region", "tiny_video", "base_shallow", "large_shallow", "base_full", "base_full_b64",
-                                  "large_full", "large_full_b32", "video_full", "base_region"])
-def test_step_matches_reference(case, tmp_path, synthetic):
-    gold = np.load(os.path.join(GOLD, case + ".npz"))
-    model, loss, c = run_case(case, tmp_path, synthetic)
-    report = []
-    for k, v in loss.items():
-        ref = float(gold[k])
-        # north_star's 1e-3 at the configurations' own per-GPU batches (base: 64, large: 32); 5e-3 for the toy batches
-        report.append(("loss " + k, abs(v.item() - ref) / max(abs(ref), 1e-6), 1e-3 if c["batch"] >= 32 else 5e-3))
-    full = case.startswith("tiny")
+def model_acts(model, c):
     acts = dict(model.last)
-    acts["itc_logits"] = acts["image_feat"] @ acts["text_feat"].t() / model.temp.detach()
-    acts["itm_logits"] = model.last_itm_logits
+    if "image_feat" in acts:
+        acts["itc_logits"] = acts["image_feat"] @ acts["text_feat"].t() / model.temp.detach()
+    if c.get("match", True) and not c.get("text_only"):
+        acts["itm_logits"] = model.last_itm_logits
     V = c["vocab"]
     ml = model.last_mlm_logits[:, :V].reshape(c["batch"], c["max_masks"], V)
     acts["mlm_logits"] = ml
@@ -86,6 +85,75 @@ def test_step_matches_reference(case, tmp_path, synthetic):
     assert float((acts["mlm_lse"].double() - torch.logsumexp(ml.double(), dim=-1)).abs().max()) < 2e-4
     if c["frames"]:
         acts.pop("image_embeds")        # fixture holds the per-frame encoder output; pooled output is checked via the losses
+    return acts
+
+
+def rounded_oracle_report(case, c, synthetic, cpu_batch, model, loss, acts):
+    """(B): the HIP step against the oracle with bf16 roundings at the same operand sites, on this box's host cores."""
+    from oracle import x2vlm_oracle as O
+    cfg = O.config_from_case(c)
+    torch.set_num_threads(min(os.cpu_count() or 8, 64))
+    osd = O.make_params(cfg, c["wseed"], synthetic.synth_tensor)
+    ob = {k: v for k, v in cpu_batch.items() if not (c.get("text_only") and k == "image")}
+    neg = synthetic.synth_negatives(c["bseed"], c["batch"])
+    ol, ex = O.xvlm_forward(osd, cfg, ob, neg, ret_bbox_loss=c["region"], ret_match_loss=c.get("match", True),
+                            round_operands=torch.bfloat16)
+    sum(ol.values()).backward()
+    rep = []
+    for k, v in loss.items():
+        ref = float(ol[k])
+        rep.append(("R loss " + k, abs(float(v) - ref) / max(abs(ref), 1e-6) if ref != 0.0 else abs(float(v)), RB["loss"]))
+    for name, got in acts.items():
+        if name not in ex:
+            continue
+        ref = ex[name].detach().double()
+        g = got.detach().cpu().double().reshape(ref.shape)
+        scale = max(float(ref.abs().max()), 1e-6)
+        rep.append(("R act " + name, float((g - ref).abs().max()) / scale, RB["mlm_lse"] if name == "mlm_lse" else RB["pointwise"]))
+        if ref.numel() > 4096:
+            mg, mr = (np.array([t.sum().item(), t.abs().sum().item(), (t * t).sum().item()]) for t in (g, ref))
+            rep.append(("R act " + name + "/moments", float(np.abs(mg - mr).max() / max(np.abs(mr).max(), 1e-6)), RB["moments"]))
+    sd = dict(model.named_parameters())
+    sq_m = sq_o = 0.0
+    norms = {}
+    for name, t in osd.items():
+        if t.grad is not None:
+            norms[name] = float(t.grad.double().norm())
+            sq_o += norms[name] ** 2
+    total = sq_o ** 0.5
+    for name, t in osd.items():
+        g = sd[name].grad
+        if t.grad is None or float(t.grad.abs().max()) == 0.0:
+            assert g is None or float(g.abs().max()) == 0.0, name
+            continue
+        assert g is not None, "no gradient for " + name
+        gd = g.detach().cpu().double()
+        n = float(gd.norm())
+        sq_m += n * n
+        rep.append(("R gradnorm " + name, abs(n - norms[name]) / max(norms[name], 1e-2 * total), RB["gradnorm"]))
+        # every gradient pointwise (the fixtures only keep the small ones in full): error of the whole tensor relative to its norm
+        rep.append(("R grad " + name, float((gd - t.grad.double()).norm()) / max(norms[name], 1e-2 * total), RB["grad"]))
+    rep.append(("R total_grad_norm", abs(sq_m ** 0.5 - total) / total, RB["total"]))
+    return rep
+
+
+@pytest.mark.parametrize("case", ["tiny", "tiny_region", "tiny_video", "tiny_text", "tiny_nomatch", "tiny_region_degenerate",
+                                  "base_shallow", "base_shallow_text", "base_shallow_nomatch", "large_shallow", "base_full",
+                                  "base_full_b64", "large_full", "large_full_b32", "video_full", "base_region"])
+def test_step_matches_reference(case, tmp_path, synthetic):
+    gold = np.load(os.path.join(GOLD, case + ".npz"))
+    model, loss, c, cpu_batch = run_case(case, tmp_path, synthetic)
+    assert sorted(loss) == sorted(k for k in gold.files if k.startswith("loss_")), sorted(loss)
+    report = []
+    for k, v in loss.items():
+        ref = float(gold[k])
+        if ref == 0.0:            # loss_itm with ret_match_loss=False (model_pretrain.py:52), loss_giou of a degenerate batch (xvlm.py:945)
+            assert float(v) == 0.0, (k, float(v))
+            continue
+        # north_star's 1e-3 at the configurations' own per-GPU batches (base: 64, large: 32); 5e-3 for the toy batches
+        report.append(("loss " + k, abs(v.item() - ref) / max(abs(ref), 1e-6), 1e-3 if c["batch"] >= 32 else 5e-3))
+    full = case.startswith("tiny")
+    acts = model_acts(model, c)
     for k in gold.files:
         if not k.startswith("act/"):
             continue
@@ -110,10 +178,11 @@ def test_step_matches_reference(case, tmp_path, synthetic):
             continue
         ref = float(gold[k])
         g = sd[name].grad
-        if ref < 0:
+        if ref <= 0:              # no gradient in the reference (-1), or an exactly zero one
             assert g is None or float(g.abs().max()) == 0.0, name
             continue
         assert g is not None, "no gradient for " + name
+        assert bool(torch.isfinite(g).all()), "non-finite gradient for " + name
         n = float(g.double().norm())
         sq += n * n
         report.append(("gradnorm " + name, abs(n - ref) / max(ref, 1e-2 * total), 3e-2))
@@ -121,11 +190,16 @@ def test_step_matches_reference(case, tmp_path, synthetic):
         if k.startswith("grad/"):
             name = k[len("grad/"):]
             ref = gold[k].astype(np.float64)
+            if sd[name].grad is None:
+                assert float(np.abs(ref).max()) == 0.0, name
+                continue
             got = sd[name].grad.detach().cpu().double().numpy()
             report.append(("grad " + name, float(np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-2 * total / max(ref.size, 1) ** 0.5)), 4.5e-2))
     # the 42-layer X2VLM-large at batch 32 measured 4.0e-3 (profiles/r05e_parity_large_b32.txt): its own bound, 6e-3
     gtol = 2e-3 if c["batch"] >= 64 else 1.2e-2 if c["image_res"] < 64 else 6e-3 if case == "large_full_b32" else 3e-3
     report.append(("total_grad_norm", abs(sq ** 0.5 - total) / total, gtol))
+    if case in ROUNDED and os.environ.get("X2_ROUNDED_ORACLE", "1") == "1":
+        report += rounded_oracle_report(case, c, synthetic, cpu_batch, model, loss, acts)
     worst = sorted(report, key=lambda r: -r[1] / r[2])[:12]
     print("\n[%s] worst deviations (value / tolerance):" % case)
     for name, err, tol in worst:
@@ -137,4 +211,6 @@ def test_step_matches_reference(case, tmp_path, synthetic):
                 ref = float(gold["gradnorm/" + name.split(" ", 1)[1]]) if name.startswith("gradnorm ") else float("nan")
                 f.write("%-80s %.4e  tol %.1e  ref %.4e\n" % (name, err, tol, ref))
     bad = [(n, e, t) for n, e, t in report if not (e <= t)]
+    if os.environ.get("X2_PARITY_NO_ASSERT") == "1":      # measuring run (profiles/*_parity_worst.txt): report, do not gate
+        return
     assert not bad, "%d checks out of tolerance, worst: %s" % (len(bad), bad[:5])

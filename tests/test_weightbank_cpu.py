@@ -137,3 +137,17 @@ def test_scaled_transposed_copies_are_their_own_entries(bank, monkeypatch):
     plain, tr = bank.linear(odd, tscale=go)
     assert torch.equal(plain, odd.detach().to(torch.bfloat16))
     assert torch.equal(tr, (odd.detach() * go.detach()[:, None]).t().contiguous().to(torch.bfloat16))
+
+
+def test_vector_of_a_non_contiguous_or_half_precision_bias_is_packed_by_value(bank):
+    """The multi-tensor vector build copies numel() floats from the raw address; an item that is not fp32 + contiguous must take the
+    reshape + cat build instead (advisor finding, round 4): a strided slice or a bf16 bias packed by address would be silently wrong."""
+    base = torch.nn.Parameter(torch.arange(8.0))
+    strided = base[::2]                                       # 4 elements, stride 2
+    got = bank.vector(strided, 2)
+    assert torch.equal(got, torch.tensor([0., 2, 4, 6, 0, 0])) and bank.calls["vec"] == 0
+    half = torch.nn.Parameter(torch.arange(4.0).to(torch.bfloat16))
+    got = bank.vector(half, 1)
+    assert got.dtype == torch.float32 and torch.equal(got, torch.tensor([0., 1, 2, 3, 0]))
+    bank.prepare_vectors([(strided, 2), (half, 1)])            # nothing for the raw-address launch
+    assert bank.calls["vec"] == 0

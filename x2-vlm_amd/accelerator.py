@@ -169,6 +169,10 @@ class RocmDDPAccelerator(Accelerator):
             port = int(os.environ.get("MASTER_PORT", 34171))
             # X2_DIST_BACKEND=gloo: several ranks sharing one GPU (tests on a 1-GPU box); RCCL refuses duplicate devices
             backend = os.environ.get("X2_DIST_BACKEND", "nccl" if on_gpu else "gloo")
+            if backend == "nccl" and world_size > 1:
+                # cap RCCL's channel kernels (one CU each, resident under the backward); graph.SegmentedStep makes every GEMM
+                # tile plan leave the same number of CUs out (x2_tune key 12).  X2_RCCL_CHANNELS / NCCL_MAX_NCHANNELS override.
+                os.environ.setdefault("NCCL_MAX_NCHANNELS", os.environ.get("X2_RCCL_CHANNELS", "16"))
             dist.init_process_group(backend=backend, init_method="tcp://%s:%d" % (addr, port), world_size=world_size, rank=rank,
                                     **({"device_id": torch.device("cuda", local_rank)} if backend == "nccl" else {}))
         self.world_size = world_size

@@ -150,7 +150,7 @@ class WeightBank:
             ent = self._c.get(key)
             if ent is not None and ent[0] == vers:
                 continue
-            if any(not isinstance(it, int) and (it.dtype != F32 or not it.is_contiguous() or not it.is_cuda) for it in items):
+            if any(not isinstance(it, int) and (it.dtype != F32 or not it.is_contiguous()) for it in items):
                 continue                                   # raw-address copy below: left to `vector`'s reshape + cat build
             n = sum(it if isinstance(it, int) else it.numel() for it in items)
             todo.append((key, vers, items, n))

@@ -184,8 +184,30 @@ class SegmentedStep:
         # first's when it receives it, long before the queue fills either; the late TN GEMM then overwrites the sum with one
         # contribution (round 4: the replayed region iteration had lost the other one; the eager path was right).
         self.defer_tail_wgrad = os.environ.get("X2_SEG_TAIL_WGRAD", "1") == "1" and not ret_bbox_loss
-        # the tail segment forks a second stream for what hangs off the fusion stack's dependency chain (engine.AUX)
-        self.aux_overlap = os.environ.get("X2_AUX_OVERLAP", "1") == "1"
+        # the tail segment forks a second stream for what hangs off the fusion stack's dependency chain (engine.AUX).  ROCm replays
+        # a segment that contains a fork node by node and keeps ONE such replay in flight: the host thread then sits inside
+        # hipGraphLaunch for a good part of the step (base 5 ms, region 25 ms per step at 20 enqueued steps).  One GPU: the step stays
+        # GPU-bound and keeps the -0.5 % (base) / -4 % (X2VLM-large).  More than one rank: the same thread issues the ~40
+        # collectives between the segments, and a collective issued late is an all-reduce that no longer hides under the vision
+        # backward - so the fork is OFF by default when collectives are issued (X2_AUX_OVERLAP=1 forces it on, =0 off).
+        env_aux = os.environ.get("X2_AUX_OVERLAP")
+        self.aux_overlap = (env_aux == "1") if env_aux is not None else not self.coll
+        # bf16 payload for the gradient all-reduces (0.51 GB per step instead of 1.02 GB): the arena is cast to a static
+        # bf16 buffer, averaged there, and written back to the fp32 arena on arrival.  Off by default (parity-tested at 2 and
+        # 8 gloo ranks; never measured on xGMI): X2_GRAD_BF16=1
+        self.grad_bf16 = os.environ.get("X2_GRAD_BF16", "0") == "1"
+        self._bf16_buf = {}
+        # compute units every GEMM tile plan leaves to RCCL's channel kernels (x2_tune key 12) when collectives run beside
+        # the backward: X2_RESERVED_CUS, default 0 at one rank, the channel cap below otherwise.  NCCL_MAX_NCHANNELS is only a
+        # request to RCCL made before the communicator exists (accelerator.set_up / bench.py export it from the same number).
+        self.reserved_cus = int(os.environ.get("X2_RESERVED_CUS", "-1"))
+        if self.reserved_cus < 0:
+            self.reserved_cus = int(os.environ.get("NCCL_MAX_NCHANNELS", "0") or 0) if world > 1 else 0
+        from ._lib import lib as _x2lib
+        self._lib = _x2lib() if batch["text_ids"].is_cuda else None
+        if self._lib is not None and self.reserved_cus != self._lib.x2_tune_get(12):
+            if self._lib.x2_tune(12, self.reserved_cus) != 0:
+                raise RuntimeError("x2_tune(12, %d): %s" % (self.reserved_cus, self._lib.x2_last_error().decode()))
         self._queue = None
         # The vision tower as a chain of stages cut at these block numbers (beit2.VisionTransformer.chunk_at): its backward
         # becomes one segment per stage, top first; the weight gradients of every stage but the lowest run as segments of
@@ -603,6 +625,18 @@ class SegmentedStep:
 
     def _all_reduce(self, flat):
         self.messages += 1
+        if self.grad_bf16 and flat.dtype == torch.float32:
+            # bf16 on the wire, fp32 at both ends: cast -> average -> write back (the arena keeps fp32 for the optimizer)
+            buf = self._bf16_buf.get(flat.data_ptr())
+            if buf is None or buf.numel() != flat.numel():
+                buf = self._bf16_buf[flat.data_ptr()] = torch.empty(flat.numel(), device=flat.device, dtype=torch.bfloat16)
+            buf.copy_(flat.view(-1))
+            self._all_reduce_raw(buf)
+            flat.view(-1).copy_(buf)
+            return
+        self._all_reduce_raw(flat)
+
+    def _all_reduce_raw(self, flat):
         if self.comm is not None:
             self.comm.allreduce_bucket(flat, average=True)
             return
@@ -695,6 +729,64 @@ class SegmentedStep:
     copy_inputs = staticmethod(GraphedStep.copy_inputs)
 
 
+class TextOnlyStep(SegmentedStep):
+    """Pretrain.run_text_iter (Pretrain.py:139-157; XVLM.forward(image=None) -> forward_text, model_pretrain.py:67-72) as three
+    linear hipGraph segments: the masked ids through the text layers on stream B (XT), the upper layers WITHOUT cross-attention +
+    MLM head + loss + their backward on stream A (XF), the text layers' backward on stream B (XTb) - every parameter's gradient
+    is produced on the stream its AccumulateGrad node is pinned to by the image step (text layers and embeddings: B; fusion
+    layers and the MLM head: A), so no segment contains a fork, and the tied word-embedding / decoder gradient takes the
+    same single-buffer route (engine.TIE_WORD_GRAD).  batch: text_ids_masked, text_atts, masked_pos, masked_ids (+ text_ids,
+    unused by the loss, kept for copy_inputs).  A part of a MixedStep (the reference adds t_loss['loss_mlm'] * iter_perc to the
+    iteration's one backward, Pretrain.py:232-235), or a step of its own."""
+
+    def _s_xt(self):
+        b = self.batch
+        self.t["xt"] = self.model.get_text_embeds(b["text_ids_masked"], b["text_atts"])
+
+    def _s_xf(self):
+        m, b = self.model, self.batch
+        leaf = self.t["xt_leaf"] = self.t["xt"].detach().requires_grad_()
+        seq = m._bert(encoder_embeds=leaf, attention_mask=b["text_atts"], mode="fusion").last_hidden_state
+        loss, m.last_mlm_lse, m.last_mlm_logits = m.text_encoder.mlm_loss_from_hidden(seq, b["masked_pos"], b["masked_ids"])
+        losses = {"loss_mlm": loss}
+        self.total_loss(losses).backward()
+        self.t["loss"] = {k: v.detach() for k, v in losses.items()}
+
+    def _s_xtb(self):
+        torch.autograd.backward([self.t["xt"]], [self.t["xt_leaf"].grad])
+
+    def _run(self, mode):
+        eng, A, Bs = self.engine, self.sA, self.sB
+        pa = pb = None
+        if mode == "capture":
+            pa, pb = self._pools
+        if mode != "replay":
+            eng.SIDE.enabled = False
+            eng.SIDE.only_from = A.cuda_stream
+            eng.TIE_WORD_GRAD = True              # the embedding lookup of the tied parameter is part of this pass (XT)
+            eng.WGRAD_QUEUE = None
+            if self.recast_weights:
+                eng.BANK.invalidate()
+            else:
+                eng.BANK.backward_seen = False
+            for p in self.params:
+                p.grad = None
+        with torch.cuda.stream(A):
+            self._epoch.add_(1)
+        Bs.wait_stream(A)
+        self._seg(mode, "XT", Bs, self._s_xt, pb)
+        A.wait_stream(Bs)
+        self._seg(mode, "XF", A, self._s_xf, pa)
+        Bs.wait_stream(A)
+        self._reduce("XF", A)
+        self._seg(mode, "XTb", Bs, self._s_xtb, pb)
+        self._reduce("XTb", Bs)
+        A.wait_stream(Bs)
+        if self.sC is not None:
+            A.wait_stream(self.sC)
+        self._held = []
+
+
 class MixedStep:
     """Pretrain.run_mixed_iter (Pretrain.py:189-252) as replayed hipGraph segments: several sub-iterations of ONE optimizer step -
     the image batch, the region batch, a video batch - whose gradients accumulate (the reference sums the losses of the image and
@@ -707,27 +799,48 @@ class MixedStep:
     message per layer arena, as for a single iteration.  p.grad of every parameter is a static tensor afterwards.
 
     parts: list of dict(batch=static device tensors, weight=iter_perc (1.0), ret_bbox_loss=False, ret_match_loss=True,
-                        negatives=None (tests: injected hard negatives, static int32 device tensors)).
+                        negatives=None (tests: injected hard negatives, static int32 device tensors),
+                        loss_keys=None (the losses of this part that enter the backward; None = all it returns - e.g.
+                                        ("loss_bbox", "loss_giou") for the region part under the reference's regions_use_bbox_only,
+                                        Pretrain.py:220-222), total_loss=None (or any callable losses -> scalar, instead of
+                                        weight / loss_keys), text_only=False (Pretrain.run_text_iter's part: batch without an
+                                        image, TextOnlyStep)).
+    The first part must be an image / region / video part (it owns the reduction plan).  Not expressible here: the mtext
+    sub-iteration (Pretrain.py:237-245) - XVLM.forward has no text_ids_2 arguments, that is XVLMPlus (out of scope) -
+    and a video part with a backward_step of its own (Pretrain.py:193-201) is simply one more part: the optimizer sees the
+    same sum of gradients either way.
     Returns the list of the parts' loss dicts (unweighted, as the reference logs them)."""
 
     def __init__(self, model, parts, world=1, rank=0, process_group=None, comm=None, warmup=1, enabled=True, verbose=False, **kw):
         self.model, self.world, self.rank = model, world, rank
         self.parts, self.steps = parts, []
-        for i, part in enumerate(parts):
-            w = float(part.get("weight", 1.0))
-            if "negatives" in part:
-                model.injected_negatives = part["negatives"]
-            self.steps.append(SegmentedStep(model, part["batch"], world=world, rank=rank, process_group=process_group, comm=comm,
-                                            warmup=warmup, enabled=enabled, verbose=verbose,
-                                            ret_bbox_loss=part.get("ret_bbox_loss", False), ret_match_loss=part.get("ret_match_loss", True),
-                                            # every part re-casts inside its own graphs: a later part may use weights the first does
-                                            # not (bbox head after an image part), and a copy cached from a part's eager warm-up would
-                                            # never be refreshed after optimizer steps (0.4 ms per extra part)
-                                            recast_weights=kw.get("recast_weights", True),
-                                            clamp_temp=(i == 0) and kw.get("clamp_temp", True),
-                                            total_loss=(lambda losses, w=w: w * sum(losses.values())),
-                                            reduce_grads=(i == 0), defer_reduce=True,
-                                            **{k: v for k, v in kw.items() if k not in ("recast_weights", "clamp_temp")}))
+        # what a part decides for itself must not arrive a second time through **kw (accelerator.mixed_step(**kw) passes it on)
+        for k in ("total_loss", "reduce_grads", "defer_reduce", "ret_bbox_loss", "ret_match_loss"):
+            if k in kw:
+                raise TypeError("MixedStep: %r is a per-part setting (parts[i][%r]), not a keyword of the whole iteration" % (k, k))
+        assert not parts[0].get("text_only"), "MixedStep: the first part owns the reduction plan and must not be text-only"
+        kept = model.injected_negatives
+        try:
+            for i, part in enumerate(parts):
+                w = float(part.get("weight", 1.0))
+                keys = part.get("loss_keys")
+                total = part.get("total_loss") or (lambda losses, w=w, keys=keys: w * sum(v for k, v in losses.items() if keys is None or k in keys))
+                # a part's injected negatives (tests) are that part's only: the model gets its own back afterwards, and the eager
+                # fallback of __call__ sets them per part again
+                model.injected_negatives = part.get("negatives", kept)
+                cls = TextOnlyStep if part.get("text_only") else SegmentedStep
+                self.steps.append(cls(model, part["batch"], world=world, rank=rank, process_group=process_group, comm=comm,
+                                      warmup=warmup, enabled=enabled, verbose=verbose,
+                                      ret_bbox_loss=part.get("ret_bbox_loss", False), ret_match_loss=part.get("ret_match_loss", True),
+                                      # every part re-casts inside its own graphs: a later part may use weights the first does
+                                      # not (bbox head after an image part), and a copy cached from a part's eager warm-up would
+                                      # never be refreshed after optimizer steps (0.4 ms per extra part)
+                                      recast_weights=kw.get("recast_weights", True),
+                                      clamp_temp=(i == 0) and kw.get("clamp_temp", True),
+                                      total_loss=total, reduce_grads=(i == 0), defer_reduce=True,
+                                      **{k: v for k, v in kw.items() if k not in ("recast_weights", "clamp_temp")}))
+        finally:
+            model.injected_negatives = kept
         first = self.steps[0]
         self.params = first.params
         self.coll = first.coll
@@ -795,8 +908,13 @@ class MixedStep:
             return losses
         # eager fallback (capture disabled or failed): every part launches its kernels from Python and starts from p.grad = None
         total, losses = {}, []
-        for s_ in self.steps:
-            losses.append(s_())
+        kept = self.model.injected_negatives
+        for s_, part in zip(self.steps, self.parts):
+            self.model.injected_negatives = part.get("negatives", kept)
+            try:
+                losses.append(s_())
+            finally:
+                self.model.injected_negatives = kept
             for p in self.params:
                 if p.grad is not None:
                     total[id(p)] = p.grad if id(p) not in total else total[id(p)] + p.grad

@@ -100,7 +100,13 @@ class XVLM(XVLMBase):
                                 ret_bbox_loss=ret_bbox_loss, ret_match_loss=ret_match_loss)
 
     def forward_text(self, text_ids=None, text_atts=None, text_ids_masked=None, masked_pos=None, masked_ids=None):
-        return {"loss_mlm": self.get_mlm_loss(text_ids_masked, text_atts, None, None, masked_pos, masked_ids)}
+        """model_pretrain.py:67-72 (Pretrain.run_text_iter): the masked ids through every text layer WITHOUT cross-attention
+        (no encoder states: xbert.py:595), MLM head.  = get_mlm_loss(text_ids_masked, text_atts, None, None, ...), spelled out so
+        that the inspection copies the parity tests read (last_mlm_lse / last_mlm_logits / last) exist for this branch too."""
+        seq = self._bert(text_ids_masked, attention_mask=text_atts, mode="multi_modal").last_hidden_state
+        loss, self.last_mlm_lse, self.last_mlm_logits = self.text_encoder.mlm_loss_from_hidden(seq, masked_pos, masked_ids)
+        self.last = dict(text_embeds=seq.detach())
+        return {"loss_mlm": loss}
 
     def forward(self, image=None, text_ids=None, text_atts=None, text_ids_masked=None, masked_pos=None, masked_ids=None,
                 image_atts=None, idx_to_group_img=None, target_bbox=None, is_image=None, ret_bbox_loss=False,

@@ -299,9 +299,14 @@ class XVLMBase(nn.Module):
         """xvlm.py:927-957 ((B,4) elementwise maths; GIoU of matched pairs only)."""
         loss_bbox = (output_coord - target_bbox).abs()
         b1, b2 = box_ops.box_cxcywh_to_xyxy(output_coord), box_ops.box_cxcywh_to_xyxy(target_bbox)
+        # The reference's early-out (xvlm.py:943-946: any degenerate box -> every row's GIoU term is 0 and generalized_box_iou is
+        # NEVER evaluated), without its host sync: the GIoU runs on boxes made safe under the flag - a unit box for every row
+        # when the batch is degenerate - so the branch that is not selected holds no 0/0 whose NaN would poison the backward
+        # (torch.where passes a zero gradient into it, and 0 x NaN = NaN through the division).
         degenerate = ((b1[:, 2:] < b1[:, :2]).any() | (b2[:, 2:] < b2[:, :2]).any())
-        giou = 1 - box_ops.generalized_box_iou_pairs(b1, b2)
-        loss_giou = torch.where(degenerate, torch.zeros_like(giou), giou)     # early-out of the reference, sync-free
+        unit = torch.tensor([0.0, 0.0, 1.0, 1.0], device=b1.device, dtype=b1.dtype).expand_as(b1)
+        giou = 1 - box_ops.generalized_box_iou_pairs(torch.where(degenerate, unit, b1), torch.where(degenerate, unit, b2))
+        loss_giou = torch.where(degenerate, torch.zeros_like(giou), giou)
         if is_image is None:
             num_boxes = target_bbox.size(0)
         else:
