@@ -445,7 +445,7 @@ def main():
         # with a non-default variant says so.  (Work-skipping ablation bits do not exist in the shipped library at all:
         # csrc/gemm.hip compiles them only with -DX2_PROBE, probes/build_probe.sh.)
         h_ = importlib.import_module("x2-vlm_amd._lib").lib()
-        tuned = {str(k): h_.x2_tune_get(k) for k in range(13) if h_.x2_tune_get(k) > 0}
+        tuned = {str(k): h_.x2_tune_get(k) for k in range(16) if h_.x2_tune_get(k) > 0}
         out["x2_tune_non_default"] = tuned
         out["env_switches"] = {k: v for k, v in sorted(os.environ.items()) if k.startswith("X2_") and k not in ("X2_BENCH_BACKEND",)}
         if world == 1 and not args.no_cpu_baseline:

@@ -216,6 +216,67 @@ class _GeluSavedRounded(torch.autograd.Function):
         return g * (cdf + v * pdf), None
 
 
+class _AttentionRounded(torch.autograd.Function):
+    """Attention with the roundings of csrc/attention.hip, forward AND backward (the generic helpers cannot place them: the kernels
+    round P BEFORE normalising, and their backward is not the autograd of their forward):
+      forward   keys in tiles of 64 with a running maximum m_t; P_t = bf16(exp(s - m_t) [x dropout]) - the largest probability of a
+                row is exactly 1, whatever the partition sum -; O = sum_t exp(m_t - m) (P_t V_t) / l, l from the unrounded, undropped
+                exponentials; O stored as bf16.
+      backward  p = exp(s - lse) recomputed in fp32; dV = bf16(p [x dropout])^T dO; dP = dO V^T; Delta = sum_d dO x O with the STORED
+                bf16 O; dS = p (dP - Delta) rounded to bf16 for dQ = dS K, dK = dS^T Q (both x scale, stored as bf16) and for the
+                gradient of the additive term (the relative-position bias is reduced from the bf16 dS stream)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, add, scale, pmul, dtype):
+        rd = lambda t: t.to(dtype).to(t.dtype)
+        s = (q @ k.transpose(-1, -2)) * scale
+        if add is not None:
+            s = s + add
+        m = s.max(-1, keepdim=True).values
+        l = torch.exp(s - m).sum(-1, keepdim=True)
+        o = torch.zeros(q.shape[:-1] + (v.shape[-1],), dtype=q.dtype)
+        m_run = torch.full_like(m, -float("inf"))
+        for t0 in range(0, s.shape[-1], 64):
+            st = s[..., t0:t0 + 64]
+            m_run = torch.maximum(m_run, st.max(-1, keepdim=True).values)
+            p = torch.exp(st - m_run)
+            if pmul is not None:
+                p = p * pmul[..., t0:t0 + 64]
+            o = o + torch.exp(m_run - m) * (rd(p) @ v[..., t0:t0 + 64, :])
+        out = rd(o / l)
+        ctx.save_for_backward(q, k, v, add if add is not None else torch.zeros(()), out, m + torch.log(l),
+                              pmul if pmul is not None else torch.zeros(()))
+        ctx.meta = (scale, dtype, add is not None, pmul is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        q, k, v, add, out, lse, pmul = ctx.saved_tensors
+        scale, dtype, has_add, has_drop = ctx.meta
+        rd = lambda t: t.to(dtype).to(t.dtype)
+        s = (q @ k.transpose(-1, -2)) * scale
+        if has_add:
+            s = s + add
+        p = torch.exp(s - lse)
+        do = rd(g)
+        dv = rd(p * pmul if has_drop else p).transpose(-1, -2) @ do
+        dp = do @ v.transpose(-1, -2)
+        if has_drop:
+            dp = dp * pmul
+        ds = rd(p * (dp - (do * out).sum(-1, keepdim=True)))
+        dq = rd((ds @ k) * scale)
+        dk = rd((ds.transpose(-1, -2) @ q) * scale)
+        dadd = None
+        if has_add and ctx.needs_input_grad[3]:
+            dadd = ds
+            while dadd.dim() > add.dim():
+                dadd = dadd.sum(0)
+            for d in range(add.dim()):
+                if add.shape[d] == 1 and dadd.shape[d] != 1:
+                    dadd = dadd.sum(d, keepdim=True)
+        return dq, dk, rd(dv), dadd, None, None, None
+
+
 def gelu_mm(v):
     """GELU behind a matrix product (fc1 / intermediate / MLM transform)."""
     return gelu(v) if _ROUND is None else _GeluSavedRounded.apply(v, _ROUND)
@@ -259,14 +320,15 @@ def merge_heads(x):
 def attention_core(q, k, v, scale, add, pmul=None):
     """softmax(q k^T * scale + add) v over (B,H,Lq,d)/(B,H,Lk,d); `add` broadcastable or None.
     pmul: training-mode dropout multiplier (0 or 1/(1-p)) on the probabilities (xbert.py:399)."""
+    if _ROUND is not None:      # the kernels' own rounding sites, forward and backward
+        return _AttentionRounded.apply(q, k, v, add, scale, pmul, _ROUND)
     s = (q @ k.transpose(-1, -2)) * scale
     if add is not None:
         s = s + add
-    s = _qg(s)                  # dS is a bf16 operand of the dQ / dK products (csrc/attention.hip)
     p = torch.softmax(s, dim=-1)
     if pmul is not None:
         p = p * pmul
-    return _qq(_q(p) @ v)       # P packed to bf16 for the PV product; the context is stored as bf16, and so is its gradient
+    return p @ v
 
 
 def cross_entropy(logits, labels, ignore_index=-100):

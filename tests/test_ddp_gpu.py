@@ -217,8 +217,7 @@ def test_two_ranks_replayed_segments_match_oracle_ddp_semantics(case, synthetic)
         assert torch.allclose(out[0]["g2"][n], out[1]["g2"][n], rtol=1e-5, atol=1e-7), n
 
 
-@pytest.mark.parametrize("world,case,bf16", [(4, "tiny", False), (8, "tiny", False), (8, "base_shallow", False),
-                                             (2, "tiny", True), (8, "tiny", True)])
+@pytest.mark.parametrize("world,case,bf16", [(4, "tiny", False), (8, "base_shallow", False), (2, "tiny", True), (8, "tiny", True)])
 def test_many_ranks_replayed_segments_match_oracle_ddp_semantics(world, case, bf16, synthetic):
     """BASELINE.json configs[2] is 8 ranks: the replayed step at 4 and 8 ranks sharing this GPU over gloo (RCCL refuses two ranks
     on one device) - on the toy model and, at 8 ranks, at the real token geometry (base_shallow: N = 197, V = 30522).  Every rank

@@ -91,8 +91,14 @@ __device__ __forceinline__ void st16(void* p, u32x4 v, bool wt) {
 //     made the first fused form slower than that pass
 #ifdef X2_PROBE
 #define NT_DBG(p, bit) (((p).dbg & (bit)) != 0)
+// per-phase time stamps of gemm_nt256_kernel (probe builds only): wave 0 of every workgroup writes wall_clock64() (100 MHz) at
+// kernel entry, after the prologue's first barrier (operands of step 0 landed), after the last contraction step and after the
+// epilogue to g_nt_probe[blockIdx.x][4]; probes/nt_phase_times.py sets the buffer through x2_probe_set_buffer
+static __device__ unsigned long long* g_nt_probe = nullptr;
+#define NT_STAMP(i) do { if (g_nt_probe && threadIdx.x == 0) g_nt_probe[(size_t)blockIdx.x * 4 + (i)] = wall_clock64(); } while (0)
 #else
 #define NT_DBG(p, bit) false
+#define NT_STAMP(i) do { } while (0)
 #endif
 template <int V> struct EpiTraits {
   static constexpr bool generic = V == 4;
@@ -581,17 +587,25 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmNT p) {
     }
   };
   const int nk = p.K / BK;
+  NT_STAMP(0);
   issue(0, S0{}); issue(0, S1{}); issue(0, S2{}); issue(0, S3{});
   if (nk > 1) { issue(1, S2{}); issue(1, S3{}); asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory"); }
   else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+  NT_STAMP(1);
   int kt = 0;
   for (; kt + 2 < nk; ++kt) ktile(kt, std::true_type{}, std::true_type{});
   if (kt + 1 < nk) { ktile(kt, std::true_type{}, std::false_type{}); ++kt; }
   ktile(kt, std::false_type{}, std::false_type{});
 #undef N2_FENCE
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");       // every wave is done reading operand tiles
+  NT_STAMP(2);
   if (NT_DBG(p, 4)) { if (acc[0][0][0] == 12345.678f) reinterpret_cast<float*>(p.C)[0] = acc[1][1][1] + acc[2][2][2] + acc[3][3][3]; return; }
   nt_epilogue<TMW, VAR>(p, acc, smem, wave, lane, m0 + wr * HROWS, n0 + wc * 64);
+#ifdef X2_PROBE
+  __builtin_amdgcn_s_waitcnt(0);                                         // the wave's stores have left before the last stamp
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  NT_STAMP(3);
+#endif
 }
 
 // knobs for A/B measurements and for the tests that pin a kernel variant (0 = automatic everywhere)
@@ -605,7 +619,8 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmNT p) {
 //        some CUs during the backward, and a plan that fills "whole rounds of the 256 CUs" becomes two rounds when a few of
 //        them are taken - graph.SegmentedStep sets it to the channel count it caps RCCL at (X2_RESERVED_CUS)
 static int g_tune[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-static int g_tune_x[5] = {0, 0, 0, 0, 0};       // keys 8.. : [1] = key 9, [4] = key 12
+//   [13] LayerNorm forward rows per wave (rowwise.hip): 0 automatic, 1 / 2 / 4
+static int g_tune_x[8] = {0, 0, 0, 0, 0, 0, 0, 0};       // keys 8.. : [1] = key 9, [4] = key 12
 extern "C" int x2_device_cus(void);
 // compute units of the current device (256 on MI355X), asked once: grid-fill decisions below are made in units of it
 static int x2_cus() {
@@ -615,7 +630,7 @@ static int x2_cus() {
   return left >= 16 ? left : 16;
 }
 extern "C" int x2_tune(int key, int value) {
-  if (key >= 9 && key <= 12) {
+  if (key >= 9 && key <= 15) {
     X2_REQUIRE(key != 12 || value >= 0, "x2_tune: reserved compute units = %d", value);
     g_tune_x[key - 8] = value;
     return X2_OK;
@@ -627,9 +642,15 @@ extern "C" int x2_tune(int key, int value) {
   g_tune[key] = value;
   return X2_OK;
 }
+#ifdef X2_PROBE
+extern "C" int x2_probe_set_buffer(void* buf) {      // probe builds only: not in include/x2vlm_hip.h
+  unsigned long long* b = (unsigned long long*)buf;
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_nt_probe), &b, sizeof(b)) == hipSuccess ? X2_OK : X2_ERR_LAUNCH;
+}
+#endif
 // current value of a knob (bench.py reports every non-default one in its JSON line); -1 for a key that does not exist
 extern "C" int x2_tune_get(int key) {
-  if (key >= 9 && key <= 12) return g_tune_x[key - 8];
+  if (key >= 9 && key <= 15) return g_tune_x[key - 8];
   if (key < 0 || key >= 8) return -1;
   return g_tune[key];
 }

@@ -62,13 +62,86 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
   }
 }
 
+// Several rows per wave (RPW = 2 or 4), all their loads issued before the first reduction: a wave has RPW x NV 16-byte loads in
+// flight instead of NV, a launch has 1 / RPW of the workgroups (a 12608-row LayerNorm was 3152 workgroups of ~1 us each: the
+// dispatcher and the ramp-up / drain of a 10-17 us kernel, not HBM, set its time - 3.4 TB/s).  Same arithmetic per row, same
+// summation order inside a row (bit-identical outputs to the one-row form).
+template <int NV, int RPW>
+__global__ __launch_bounds__(256) void layernorm_fwd_rows_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                 const float* __restrict__ bsh, bf16_t* yb, float* yf,
+                                                                 float* mean, float* rstd, int rows, int D, float eps, int period,
+                                                                 DropSpec drop_in_, const uint32_t* __restrict__ epoch) {
+  const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW, lane = threadIdx.x & 63;
+  if (row0 >= rows) return;
+  const DropSpec drop = drop_at_epoch(drop_in_, epoch);
+  const int nv = D >> 2;
+  float4 v[RPW][NV];
+  long gr[RPW];
+#pragma unroll
+  for (int r = 0; r < RPW; ++r) {
+    const int row = min(row0 + r, rows - 1);          // rows past the end re-read the last row (results discarded)
+    gr[r] = remap_row(row, period);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = lane + i * 64;
+      v[r][i] = c < nv ? *reinterpret_cast<const float4*>(x + gr[r] * D + c * 4) : float4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  float4 ww[NV], bb[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = lane + i * 64;
+    ww[i] = c < nv ? *reinterpret_cast<const float4*>(w + c * 4) : float4{0.f, 0.f, 0.f, 0.f};
+    bb[i] = c < nv ? *reinterpret_cast<const float4*>(bsh + c * 4) : float4{0.f, 0.f, 0.f, 0.f};
+  }
+#pragma unroll
+  for (int r = 0; r < RPW; ++r) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) if (lane + i * 64 < nv) s += v[r][i].x + v[r][i].y + v[r][i].z + v[r][i].w;
+    const float mu = wave_sum(s) / D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+      if (lane + i * 64 < nv) { const float a = v[r][i].x - mu, b = v[r][i].y - mu, cc = v[r][i].z - mu, d = v[r][i].w - mu; q += a * a + b * b + cc * cc + d * d; }
+    const float rs = rsqrtf(wave_sum(q) / D + eps);
+    if (row0 + r >= rows) continue;
+    if (lane == 0) { mean[row0 + r] = mu; rstd[row0 + r] = rs; }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = lane + i * 64;
+      if (c < nv) {
+        float4 o{(v[r][i].x - mu) * rs * ww[i].x + bb[i].x, (v[r][i].y - mu) * rs * ww[i].y + bb[i].y,
+                 (v[r][i].z - mu) * rs * ww[i].z + bb[i].z, (v[r][i].w - mu) * rs * ww[i].w + bb[i].w};
+        if (drop.thr16) {       // dropout on the LN output (BertEmbeddings, xbert.py:215)
+          float dm[4];
+          drop_mul4(drop, (uint32_t)gr[r] * (uint32_t)D + (uint32_t)(c * 4), dm);
+          o.x *= dm[0]; o.y *= dm[1]; o.z *= dm[2]; o.w *= dm[3];
+        }
+        if (yf) *reinterpret_cast<float4*>(yf + gr[r] * D + c * 4) = o;
+        if (yb) *reinterpret_cast<u32x2*>(yb + gr[r] * D + c * 4) = u32x2{pack_bf16(o.x, o.y), pack_bf16(o.z, o.w)};
+      }
+    }
+  }
+}
+
+extern "C" int x2_tune_get(int key);
 extern "C" int x2_layernorm_fwd(const float* x, const float* w, const float* b, void* y_bf16, float* y_f32, float* mean,
                                 float* rstd, int rows, int D, float eps, int period, unsigned drop_thr16, unsigned drop_seed,
                                 float drop_scale, const unsigned* drop_epoch, void* stream) {
   X2_REQUIRE(rows > 0 && D > 0 && D % 4 == 0 && D <= 256 * LN_MAXV, "x2_layernorm_fwd: rows=%d D=%d (D%%4==0, D<=2048)", rows, D);
 #define X2_LNF(NV) hipLaunchKernelGGL(layernorm_fwd_kernel<NV>, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, w, b, \
                      (bf16_t*)y_bf16, y_f32, mean, rstd, rows, D, eps, period, DropSpec{drop_thr16, drop_seed, drop_scale}, drop_epoch)
-  LN_DISPATCH(D, X2_LNF);
+#define X2_LNF_R(NV, RPW) hipLaunchKernelGGL((layernorm_fwd_rows_kernel<NV, RPW>), dim3((rows + 4 * RPW - 1) / (4 * RPW)), dim3(256), 0, (hipStream_t)stream, \
+                     x, w, b, (bf16_t*)y_bf16, y_f32, mean, rstd, rows, D, eps, period, DropSpec{drop_thr16, drop_seed, drop_scale}, drop_epoch)
+  // rows per wave: x2_tune(13, v): 0 = automatic, 1 = one (the round-1 form), 2, 4.  Automatic: 2 when the launch still has >= 4
+  // workgroups per CU that way, else 1 (short launches keep every CU busy)
+  const int knob = x2_tune_get(13), nvv = (D + 255) / 256;
+  int rpw = knob == 1 || knob == 2 || knob == 4 ? knob : (rows >= 8 * 4 * 256 ? 2 : 1);
+  if (nvv > 4) rpw = 1;                               // D > 1024: the one-row form's register footprint is already the limit
+  if (rpw == 4 && nvv <= 3) { if (nvv <= 1) X2_LNF_R(1, 4); else if (nvv == 2) X2_LNF_R(2, 4); else X2_LNF_R(3, 4); }
+  else if (rpw >= 2) { if (nvv <= 1) X2_LNF_R(1, 2); else if (nvv == 2) X2_LNF_R(2, 2); else if (nvv == 3) X2_LNF_R(3, 2); else X2_LNF_R(4, 2); }
+  else LN_DISPATCH(D, X2_LNF);
   return x2_check_launch("x2_layernorm_fwd");
 }
 

@@ -304,7 +304,7 @@ class XVLMBase(nn.Module):
         # when the batch is degenerate - so the branch that is not selected holds no 0/0 whose NaN would poison the backward
         # (torch.where passes a zero gradient into it, and 0 x NaN = NaN through the division).
         degenerate = ((b1[:, 2:] < b1[:, :2]).any() | (b2[:, 2:] < b2[:, :2]).any())
-        unit = torch.tensor([0.0, 0.0, 1.0, 1.0], device=b1.device, dtype=b1.dtype).expand_as(b1)
+        unit = torch.cat([torch.zeros_like(b1[:, :2]), torch.ones_like(b1[:, 2:])], dim=-1)    # device-side fills only: capturable
         giou = 1 - box_ops.generalized_box_iou_pairs(torch.where(degenerate, unit, b1), torch.where(degenerate, unit, b2))
         loss_giou = torch.where(degenerate, torch.zeros_like(giou), giou)
         if is_image is None:
