@@ -453,25 +453,35 @@ class SegmentedStep:
                              image_embeds_fullatts=t["full"], target_bbox=b.get("target_bbox"), is_image=b.get("is_image"),
                              ret_bbox_loss=self.ret_bbox_loss, ret_match_loss=self.ret_match_loss,
                              gathered=(t["fi_all"], t["ft_all"]))
-        self.total_loss(loss).backward()
+        self._backward(loss)
         # backward of the all-gather: the local rows of the gathered features' gradient (xvlm.py:156-160), on through the
         # projection heads into the tower-output leaves
         B = fi.shape[0]
         sl = slice(self.rank * B, (self.rank + 1) * B)
-        torch.autograd.backward([fi, ft], [t["fi_all"].grad[sl], t["ft_all"].grad[sl]])
+        if t["fi_all"].grad is not None:          # None: the ITC loss is not part of this step's backward (a part's loss_keys)
+            torch.autograd.backward([fi, ft], [t["fi_all"].grad[sl], t["ft_all"].grad[sl]])
         t["loss"] = {k: v.detach() for k, v in loss.items()}
+
+    def _backward(self, losses):
+        """total_loss(losses).backward() - unless no loss of the dict takes part in the backward (a part's loss_keys)."""
+        tot = self.total_loss(losses)
+        if torch.is_tensor(tot) and tot.requires_grad:
+            tot.backward()
 
     def _s_vision_bwd(self, ci=0):
         """Backward of the ci-th vision stage counted from the top."""
+        # a tower output without a gradient (a part whose loss_keys leave a branch out of the backward) is simply not fed
         if ci == 0:
             ie_out, _, full_out = self.t["vis"]
-            outs, grads = [ie_out], [self.t["ie"].grad]
-            if full_out is not None and self.t["full"].grad is not None:
-                outs.append(full_out); grads.append(self.t["full"].grad)
+            pairs = [(ie_out, self.t["ie"].grad)]
+            if full_out is not None:
+                pairs.append((full_out, self.t["full"].grad))
         else:
             x, leaf = self.t["vmid"][len(self.vcuts) - ci]
-            outs, grads = [x], [leaf.grad]
-        torch.autograd.backward(outs, grads)
+            pairs = [(x, leaf.grad)]
+        pairs = [(o, g) for o, g in pairs if g is not None]
+        if pairs:
+            torch.autograd.backward([o for o, _ in pairs], [g for _, g in pairs])
 
     def _s_vision_wgrad(self, ci):
         work = self._vq.pop(ci, None)
@@ -480,7 +490,8 @@ class SegmentedStep:
             fn()
 
     def _s_text_bwd(self):
-        torch.autograd.backward([self.t["both"]], [self.t["both_leaf"].grad])
+        if self.t["both_leaf"].grad is not None:
+            torch.autograd.backward([self.t["both"]], [self.t["both_leaf"].grad])
 
     def _s_tail_wgrad(self):
         # The closures' operands were allocated on stream A and are read here on stream B: they stay referenced (self._held)
@@ -749,7 +760,7 @@ class TextOnlyStep(SegmentedStep):
         seq = m._bert(encoder_embeds=leaf, attention_mask=b["text_atts"], mode="fusion").last_hidden_state
         loss, m.last_mlm_lse, m.last_mlm_logits = m.text_encoder.mlm_loss_from_hidden(seq, b["masked_pos"], b["masked_ids"])
         losses = {"loss_mlm": loss}
-        self.total_loss(losses).backward()
+        self._backward(losses)
         self.t["loss"] = {k: v.detach() for k, v in losses.items()}
 
     def _s_xtb(self):
