@@ -265,7 +265,7 @@ __device__ __forceinline__ void nt_epilogue(const GemmNT& p, f32x4 (&acc)[TM][4]
   }
 }
 
-// ---- staged epilogue for fp32 outputs with ROW-CONTIGUOUS stores (x2_tune(2, 64); staged for measurement) ----
+// ---- staged epilogue for fp32 outputs with ROW-CONTIGUOUS stores (the only form of feature sets 1, 5, 6 since round 4) ----
 // nt_epilogue gives a lane 8 consecutive columns of one row; for fp32 outputs that is two 16-byte stores per lane whose
 // pieces interleave at a 32-byte stride: every store instruction half-fills 16 lines (8 rows x 2).  Here a lane takes 4
 // columns of TWO rows (r and r + 4): a store instruction writes 4 rows x 256 contiguous bytes = 8 full lines; the residual
@@ -1284,8 +1284,8 @@ extern "C" int x2_gemm_tn_grouped(const int64_t* problems, int count, int accumu
     while (sp > 1 && (sp > min_steps || !ws || (long)sp * t * 65536 > ws_floats)) --sp;
     static bool attr = false;
     if (!attr) {
-      hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn256_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, T2_LDS_BYTES);
-      hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn256_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, T2_LDS_BYTES);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn256_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, T2_LDS_BYTES);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn256_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, T2_LDS_BYTES);
       attr = true;
     }
     bool ragged = false;
