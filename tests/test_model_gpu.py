@@ -186,7 +186,10 @@ def test_step_matches_reference(case, tmp_path, synthetic):
         assert bool(torch.isfinite(g).all()), "non-finite gradient for " + name
         n = float(g.double().norm())
         sq += n * n
-        report.append(("gradnorm " + name, abs(n - ref) / max(ref, 1e-2 * total), 3e-2))
+        # `temp`: d loss_itc / d temp sums the B x B similarity matrix with weights of both signs amplified by 1 / temp^2 = 200 - at some
+        # (weights, batch) it all but cancels (base_shallow_nomatch: 0.016 of a total norm of 22.1) and what is left is noise: held to 6e-4
+        # of the total norm (measured 4.3e-4) instead of 3e-4 like the other cancellation-dominated tensors
+        report.append(("gradnorm " + name, abs(n - ref) / max(ref, (2e-2 if name == "temp" else 1e-2) * total), 3e-2))
     for k in gold.files:
         if k.startswith("grad/"):
             name = k[len("grad/"):]
@@ -195,9 +198,12 @@ def test_step_matches_reference(case, tmp_path, synthetic):
                 assert float(np.abs(ref).max()) == 0.0, name
                 continue
             got = sd[name].grad.detach().cpu().double().numpy()
-            report.append(("grad " + name, float(np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-2 * total / max(ref.size, 1) ** 0.5)), 4.5e-2))
+            fl = (2e-2 if name == "temp" else 1e-2) * total / max(ref.size, 1) ** 0.5
+            report.append(("grad " + name, float(np.abs(got - ref).max() / max(np.abs(ref).max(), fl)), 4.5e-2))
     # the 42-layer X2VLM-large at batch 32 measured 4.0e-3 (profiles/r05e_parity_large_b32.txt): its own bound, 6e-3
-    gtol = 2e-3 if c["batch"] >= 64 else 1.2e-2 if c["image_res"] < 64 else 6e-3 if case == "large_full_b32" else 3e-3
+    # ret_match_loss=False at the real geometry (round 5): two loss terms instead of three feed the total - 3.2e-3 measured, bound 5e-3
+    gtol = (2e-3 if c["batch"] >= 64 else 1.2e-2 if c["image_res"] < 64 else 6e-3 if case == "large_full_b32" else
+            5e-3 if not c.get("match", True) else 3e-3)
     report.append(("total_grad_norm", abs(sq ** 0.5 - total) / total, gtol))
     if case in ROUNDED and os.environ.get("X2_ROUNDED_ORACLE", "1") == "1":
         report += rounded_oracle_report(case, c, synthetic, cpu_batch, model, loss, acts)
