@@ -38,7 +38,7 @@ for v in args.variants:
         if k.isdigit():
             knobs[int(k)] = int(val)
         else:
-            env[k] = val            # an environment switch read at step construction (X2_...)
+            env[k] = val.replace("+", ",")      # an environment switch read at step construction (X2_...; write a comma as +)
     variants.append((name, knobs, env))
 res = {n: [] for n, _, _ in variants}
 for rnd in range(args.rounds):

@@ -169,6 +169,31 @@ def test_gemm_nt_256_column_kernel_matches_the_default_one(K, M, N, K_, tmw):
         lib.x2_tune(1, 0); lib.x2_tune(3, 0)
 
 
+@pytest.mark.parametrize("K_", [64, 128, 192, 256, 320, 768, 3072])
+def test_gemm_nt_160_row_ring_variants_are_bit_identical(K, K_):
+    """The 160 x 256 tile has three main loops: the two-stage ring (x2_tune(10, 1)), the three-stage ring with one barrier per step
+    (10, 2) and the shipped one - three stages + the fragment reads of the next step issued behind the current step's last MFMAs
+    (10, 0).  Same products in the same order: the outputs must be bit-identical, for every prologue / tail length of the loops
+    (1, 2, 3, 4, 5 contraction steps and long ones), ragged M and N, a bf16 and an fp32 + residual epilogue."""
+    lib = importlib.import_module("x2-vlm_amd._lib").lib()
+    M, N = 1000, 712
+    A, B = bf(rnd(M, K_, seed=51)).to(dev), bf(rnd(N, K_, seed=52, scale=K_ ** -0.5)).to(dev)
+    bias, gamma, resid = rnd(N, seed=53).to(dev), rnd(N, seed=54).to(dev), rnd(M, N, seed=55).to(dev)
+    try:
+        lib.x2_tune(1, 3); lib.x2_tune(3, 5)
+        outs = {}
+        for ring in (1, 2, 0):
+            lib.x2_tune(10, ring)
+            outs[ring] = (K.gemm_nt(A, B, bias=bias), K.gemm_nt(A, B, bias=bias, gamma=gamma, resid=resid, out_dtype=torch.float32))
+        torch.cuda.synchronize()
+        ref = (A.float() @ B.float().t() + bias)
+        assert relerr(outs[1][0], ref.cpu()) < 6e-3
+        for ring in (2, 0):
+            assert torch.equal(outs[ring][0], outs[1][0]) and torch.equal(outs[ring][1], outs[1][1]), ring
+    finally:
+        lib.x2_tune(10, 0); lib.x2_tune(1, 0); lib.x2_tune(3, 0)
+
+
 @pytest.mark.parametrize("M,N,K_,slices", [(768, 768, 30528, 0), (96, 768, 30528, 0), (40, 256, 4096, 0), (300, 200, 1024, 3),
                                            (130, 136, 640, 10), (256, 256, 128, 0), (384, 1024, 30528, 7)])
 def test_gemm_nt_split_contraction(K, M, N, K_, slices):

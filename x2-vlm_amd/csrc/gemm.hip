@@ -96,7 +96,19 @@ __device__ __forceinline__ void st16(void* p, u32x4 v, bool wt) {
 // epilogue to g_nt_probe[blockIdx.x][4]; probes/nt_phase_times.py sets the buffer through x2_probe_set_buffer
 static __device__ unsigned long long* g_nt_probe = nullptr;
 #define NT_STAMP(i) do { if (g_nt_probe && threadIdx.x == 0) g_nt_probe[(size_t)blockIdx.x * 4 + (i)] = wall_clock64(); } while (0)
+// loop ablations of gemm_nt256_kernel (x2_tune(2, bits)): 32 = the loop requests no operand tiles (the prologue's are re-read), 64 = no fragment
+// reads after step 0 (stale registers), 128 = no MFMAs - which PAIR of the loop's three activities costs the time (probes/nt_phase_times.py)
+#define NT_ABL_DECL(p) const bool abl_dma_ = NT_DBG(p, 32), abl_rd_ = NT_DBG(p, 64), abl_mm_ = NT_DBG(p, 128); bool rd_ = true
+#define NT_ABL_NO_DMA(kt) if (abl_dma_ && (kt) >= 2) return
+#define NT_ABL_NO_READ() if (!rd_) return
+#define NT_ABL_NO_MFMA() if (abl_mm_) return
+#define NT_ABL_STEP(kt) if (abl_rd_ && (kt) > 0) rd_ = false
 #else
+#define NT_ABL_DECL(p)
+#define NT_ABL_NO_DMA(kt)
+#define NT_ABL_NO_READ()
+#define NT_ABL_NO_MFMA()
+#define NT_ABL_STEP(kt)
 #define NT_DBG(p, bit) false
 #define NT_STAMP(i) do { } while (0)
 #endif
@@ -503,8 +515,10 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmNT p) {
       srcB[h][i] = p.B + (size_t)rb * p.ldb + c * 8;
     }
   const bool a2 = wave < 2 * TMW - 8;                   // this wave takes part in the second pass over an A half
+  NT_ABL_DECL(p);
   auto issue = [&](int kt, auto slot) {                 // slot 0, 1: A halves; 2, 3: B halves
     constexpr int S = decltype(slot)::value;
+    NT_ABL_NO_DMA(kt);
     char* base = smem + ((kt & 1) * 4 + S) * N2_HALF + wave * 1024;
     if constexpr (S < 2) {
       glds16(srcA[S][0] + (size_t)kt * BK, base);
@@ -530,6 +544,7 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmNT p) {
   bf16x8 fa[2][TH], fb[2][4];                           // [k-half of the step][tile]: one row group of A, all of B
   auto readA = [&](uint32_t buf, auto hi_) {            // row tiles [0, TH) or [TH, TMW)
     constexpr bool hi = decltype(hi_)::value;
+    NT_ABL_NO_READ();
     constexpr int first = hi ? TH : 0, count = hi ? TMW - TH : TH;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
@@ -538,6 +553,7 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmNT p) {
         fa[ks][i] = lds_read_b128(buf + offA + (first + i) * 2048 + (uint32_t)(((ks * 4 + fg) ^ fsw) << 4));
   };
   auto readB = [&](uint32_t buf, int jh) {              // column tiles 2*jh, 2*jh + 1
+    NT_ABL_NO_READ();
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -547,6 +563,7 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmNT p) {
   auto quad = [&](auto hi_, auto jh_) {                 // one quadrant: row group x column pair, both k-halves
     constexpr bool hi = decltype(hi_)::value;
     constexpr int jh = decltype(jh_)::value, first = hi ? TH : 0, count = hi ? TMW - TH : TH;
+    NT_ABL_NO_MFMA();
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -561,6 +578,7 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmNT p) {
   auto ktile = [&](int kt, auto n1_, auto n2_) {        // n1: step kt+1 exists, n2: step kt+2 exists
     constexpr bool n1 = decltype(n1_)::value, n2 = decltype(n2_)::value;
     const uint32_t buf = lds0 + (uint32_t)((kt & 1) * 4 * N2_HALF);
+    NT_ABL_STEP(kt);
     // phase 1
     readA(buf, LO{}); readB(buf, 0); readB(buf, 1);
     if constexpr (n1) issue(kt + 1, S0{});
@@ -608,6 +626,205 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmNT p) {
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same kernel at its most-used height (TMW = 5: 160 x 256 tiles) on a THREE-stage operand ring (round 5).  Why: the loop ablation
+// (profiles/r09i_nt256_loop_ablation.txt) shows the operand DMA - not the matrix pipe, not the fragment reads - as the slowest single
+// activity of a contraction step (0.84 us alone against 0.78 for the MFMAs and 1.18 for the step), at 40 % of the LDS-DMA path's rate: it is
+// latency-bound at the 32-64 KB the two-stage ring keeps in flight (A halves one step ahead, B halves two).  At this height a stage is
+// 2 x 10 KB (A halves: 80 rows) + 2 x 16 KB (B halves) = 52 KB, so three stages fit the CU's 160 KB: EVERY half-tile is requested two
+// steps ahead (52-104 KB in flight), into the stage that was read in the previous step - behind that step's end barrier, so the
+// mid-step barrier of the two-stage form is gone as well: one barrier per contraction step.
+//   step t reads stage t % 3; its four phases request A0, A1, B0, B1 of step t + 2 into stage (t + 2) % 3; at the end of the step
+//   s_waitcnt vmcnt(6) (a wave issues 6 requests per step, waves 0 and 1 eight: the count retires everything issued BEFORE this step,
+//   i.e. step t + 1's operands) and the barrier make step t + 1 readable.
+// ---------------------------------------------------------------------------------------------
+#define N3_A_HALF 10240
+#define N3_STAGE (2 * N3_A_HALF + 2 * N2_HALF)
+#define N3_LDS_BYTES (3 * N3_STAGE)
+// PIPE: the fragment reads of step t + 1's first two phases are issued in the LAST phase of step t, behind the (moved) barrier, so that no
+// phase begins with a wait for its own LDS reads (all eight waves of the workgroup run in lockstep: without this the LDS read burst at the
+// head of a step and the matrix pipe take turns).
+template <int VAR, bool PIPE>
+__global__ __launch_bounds__(512) void gemm_nt256s3_kernel(GemmNT p) {
+  constexpr int TMW = 5, BMT = 32 * TMW, HROWS = 16 * TMW, TH = 3;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int tiles_n = (p.N + 255) / 256, tiles_m = (p.M + BMT - 1) / BMT;
+  int tm, tn;
+  tile_coords(xcd_remap(blockIdx.x, gridDim.x), tiles_m, tiles_n, p.group_m, tm, tn);
+  const int m0 = tm * BMT, n0 = tn * 256;
+  const bf16_t* srcA[2][2]; const bf16_t* srcB[2][2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int q = i * 512 + tid, row = q >> 3, c = (q & 7) ^ (row & 7);
+      int ra = m0 + h * HROWS + (row < HROWS ? row : HROWS - 1); ra = ra < p.M ? ra : p.M - 1;
+      int rb = n0 + h * 128 + row; rb = rb < p.N ? rb : p.N - 1;
+      srcA[h][i] = p.A + (size_t)ra * p.lda + c * 8;
+      srcB[h][i] = p.B + (size_t)rb * p.ldb + c * 8;
+    }
+  const bool a2 = wave < 2 * TMW - 8;                   // rows 64..79 of an A half: the second pass of waves 0, 1
+  auto issue = [&](int stage, int kt, auto slot) {      // slot 0, 1: A halves; 2, 3: B halves
+    constexpr int S = decltype(slot)::value;
+    char* base = smem + stage * N3_STAGE + (S < 2 ? S * N3_A_HALF : 2 * N3_A_HALF + (S - 2) * N2_HALF) + wave * 1024;
+    if constexpr (S < 2) {
+      glds16(srcA[S][0] + (size_t)kt * BK, base);
+      if (a2) glds16(srcA[S][1] + (size_t)kt * BK, base + 8192);
+    } else {
+      glds16(srcB[S - 2][0] + (size_t)kt * BK, base);
+      glds16(srcB[S - 2][1] + (size_t)kt * BK, base + 8192);
+    }
+  };
+  using S0 = std::integral_constant<int, 0>; using S1 = std::integral_constant<int, 1>;
+  using S2 = std::integral_constant<int, 2>; using S3 = std::integral_constant<int, 3>;
+  f32x4 acc[TMW][4];
+#pragma unroll
+  for (int i = 0; i < TMW; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const uint32_t lds0 = lds_addr(smem);
+  const int frow = lane & 15, fg = lane >> 4, fsw = lane & 7;
+  const uint32_t offA = (uint32_t)(wr * N3_A_HALF + frow * 128);
+  const uint32_t offB = (uint32_t)(2 * N3_A_HALF + (wc >> 1) * N2_HALF + ((wc & 1) * 64 + frow) * 128);
+  bf16x8 fa[2][TH], fb[2][4];
+  bf16x8 fah[2][TMW - TH], fbx[2][2];                   // PIPE: rows-hi fragments of A in registers of their own; next step's B columns 0, 1
+  auto readA = [&](uint32_t buf, auto hi_) {
+    constexpr bool hi = decltype(hi_)::value;
+    constexpr int first = hi ? TH : 0, count = hi ? TMW - TH : TH;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < count; ++i) {
+        const bf16x8 v = lds_read_b128(buf + offA + (first + i) * 2048 + (uint32_t)(((ks * 4 + fg) ^ fsw) << 4));
+        if constexpr (PIPE && hi) fah[ks][i] = v; else fa[ks][i] = v;
+      }
+  };
+  auto readB = [&](uint32_t buf, int jh) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        fb[ks][jh * 2 + j] = lds_read_b128(buf + offB + (jh * 2 + j) * 2048 + (uint32_t)(((ks * 4 + fg) ^ fsw) << 4));
+  };
+  auto readBx = [&](uint32_t buf) {                     // PIPE: B columns 0, 1 of the NEXT step while this step's are still multiplied
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        fbx[ks][j] = lds_read_b128(buf + offB + j * 2048 + (uint32_t)(((ks * 4 + fg) ^ fsw) << 4));
+  };
+  auto quad = [&](auto hi_, auto jh_) {
+    constexpr bool hi = decltype(hi_)::value;
+    constexpr int jh = decltype(jh_)::value, first = hi ? TH : 0, count = hi ? TMW - TH : TH;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < count; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[first + i][jh * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[ks][jh * 2 + j], (PIPE && hi) ? fah[ks][i] : fa[ks][i],
+                                                                               acc[first + i][jh * 2 + j], 0, 0, 0);
+  };
+  using LO = std::false_type; using HI = std::true_type;
+#define N3_FENCE() __builtin_amdgcn_sched_barrier(0)
+  int rs = 0, ws = 2;                                   // stage read by this step, stage that receives step kt + 2
+  // PIPE form of a step.  On entry the fragments of phases 1 and 2 (A rows-lo, B columns 0..3) are in registers (fa, fb; B columns
+  // 0, 1 arrive in fbx and are moved over first).  Phase 2 also fetches A rows-hi; after phase 3 the wave waits for everything it
+  // requested before this step's B0 (vmcnt(4): A0, A1, B0 of step kt+2 may be in flight) - i.e. step kt+1's operands - and the barrier makes
+  // them readable; phase 4 fetches step kt+1's fragments behind its MFMAs.  One barrier per step, no phase starts with an LDS wait of its own.
+  auto ptile = [&](int kt, auto n1_, auto n2_, auto first_) {
+    constexpr bool n1 = decltype(n1_)::value, n2 = decltype(n2_)::value, first = decltype(first_)::value;
+    const uint32_t buf = lds0 + (uint32_t)(rs * N3_STAGE), nbuf = lds0 + (uint32_t)((rs == 2 ? 0 : rs + 1) * N3_STAGE);
+    if constexpr (!first) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      N3_FENCE();
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) { fb[ks][0] = fbx[ks][0]; fb[ks][1] = fbx[ks][1]; }
+    }
+    if constexpr (n2) issue(ws, kt + 2, S0{});
+    N3_FENCE();
+    quad(LO{}, S0{}); N3_FENCE();
+    readA(buf, HI{});
+    if constexpr (n2) issue(ws, kt + 2, S1{});
+    N3_FENCE();
+    quad(LO{}, S1{}); N3_FENCE();
+    if constexpr (n2) issue(ws, kt + 2, S2{});
+    N3_FENCE();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    N3_FENCE();
+    quad(HI{}, S1{}); N3_FENCE();
+    if constexpr (n1) {
+      if constexpr (n2) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+      N3_FENCE();
+      readA(nbuf, LO{}); readB(nbuf, 1); readBx(nbuf);
+    }
+    if constexpr (n2) issue(ws, kt + 2, S3{});
+    N3_FENCE();
+    quad(HI{}, S0{}); N3_FENCE();
+    rs = rs == 2 ? 0 : rs + 1;
+    ws = ws == 2 ? 0 : ws + 1;
+  };
+  auto ktile = [&](int kt, auto n1_, auto n2_) {        // n1: step kt+1 exists, n2: step kt+2 exists
+    constexpr bool n1 = decltype(n1_)::value, n2 = decltype(n2_)::value;
+    const uint32_t buf = lds0 + (uint32_t)(rs * N3_STAGE);
+    readA(buf, LO{}); readB(buf, 0); readB(buf, 1);
+    if constexpr (n2) issue(ws, kt + 2, S0{});
+    N3_FENCE();
+    quad(LO{}, S0{}); N3_FENCE();
+    if constexpr (n2) issue(ws, kt + 2, S1{});
+    N3_FENCE();
+    quad(LO{}, S1{}); N3_FENCE();
+    readA(buf, HI{});
+    if constexpr (n2) issue(ws, kt + 2, S2{});
+    N3_FENCE();
+    quad(HI{}, S1{}); N3_FENCE();
+    if constexpr (n2) issue(ws, kt + 2, S3{});
+    N3_FENCE();
+    quad(HI{}, S0{}); N3_FENCE();
+    if constexpr (n1) {
+      // everything this wave requested BEFORE this step (= step kt+1's operands) has landed; then for all waves.  lgkmcnt(0): this
+      // wave's fragment reads of the stage are done before another wave may refill it (next step's requests go to stage rs + 2 = the
+      // one read in THIS step only after the NEXT barrier, so this is belt and braces - the MFMAs above consumed every fragment)
+      if constexpr (n2) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      N3_FENCE();
+    }
+    rs = rs == 2 ? 0 : rs + 1;
+    ws = ws == 2 ? 0 : ws + 1;
+  };
+  const int nk = p.K / BK;
+  issue(0, 0, S0{}); issue(0, 0, S1{}); issue(0, 0, S2{}); issue(0, 0, S3{});
+  if (nk > 1) {
+    issue(1, 1, S0{}); issue(1, 1, S1{}); issue(1, 1, S2{}); issue(1, 1, S3{});
+    asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+  }
+  int kt = 0;
+  if constexpr (PIPE) {
+    readA(lds0, LO{}); readB(lds0, 0); readB(lds0, 1);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    N3_FENCE();
+    if (nk >= 3) { ptile(0, std::true_type{}, std::true_type{}, std::true_type{}); kt = 1; }
+    else if (nk == 2) { ptile(0, std::true_type{}, std::false_type{}, std::true_type{}); kt = 1; }
+    else { ptile(0, std::false_type{}, std::false_type{}, std::true_type{}); kt = 1; }
+    for (; kt + 2 < nk; ++kt) ptile(kt, std::true_type{}, std::true_type{}, std::false_type{});
+    if (kt + 1 < nk) { ptile(kt, std::true_type{}, std::false_type{}, std::false_type{}); ++kt; }
+    if (kt < nk) ptile(kt, std::false_type{}, std::false_type{}, std::false_type{});
+  } else {
+    for (; kt + 2 < nk; ++kt) ktile(kt, std::true_type{}, std::true_type{});
+    if (kt + 1 < nk) { ktile(kt, std::true_type{}, std::false_type{}); ++kt; }
+    ktile(kt, std::false_type{}, std::false_type{});
+  }
+#undef N3_FENCE
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");       // every wave is done reading operand tiles
+  nt_epilogue<TMW, VAR>(p, acc, smem, wave, lane, m0 + wr * HROWS, n0 + wc * 64);
+}
+
 // knobs for A/B measurements and for the tests that pin a kernel variant (0 = automatic everywhere)
 //   [0] GROUP_M of the NT tile raster            [1] 0: automatic, 1: 128-column kernels only, 3: always the 256-column kernel
 //   [2] NT ablation bits (4 no epilogue, 16 sc1 stores): -DX2_PROBE builds only, refused by the shipped library
@@ -619,6 +836,9 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmNT p) {
 //        some CUs during the backward, and a plan that fills "whole rounds of the 256 CUs" becomes two rounds when a few of
 //        them are taken - graph.SegmentedStep sets it to the channel count it caps RCCL at (X2_RESERVED_CUS)
 static int g_tune[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+//   [10] 256-column NT kernel at 160 rows: 0 = three-stage operand ring with pipelined fragment reads (gemm_nt256s3_kernel<V, true>),
+//        2 = three-stage ring, reads at the head of their phase, 1 = the two-stage kernel
+//   [11] 1: the rounds 3-4 rule for choosing the 256-column kernel (no fp32 + residual launches below K = 2048, no GELU launches)
 //   [13] LayerNorm forward rows per wave (rowwise.hip): 0 automatic, 1 / 2 / 4
 static int g_tune_x[8] = {0, 0, 0, 0, 0, 0, 0, 0};       // keys 8.. : [1] = key 9, [4] = key 12
 extern "C" int x2_device_cus(void);
@@ -681,9 +901,21 @@ static void launch_nt256(const GemmNT& p, hipStream_t stream) {
   hipLaunchKernelGGL((gemm_nt256_kernel<TMW, V>), dim3(tiles), dim3(512), N2_LDS_BYTES, stream, p);
 }
 template <int V>
+static void launch_nt256s3(const GemmNT& p, hipStream_t stream) {
+  static bool raised = false;
+  if (!raised) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt256s3_kernel<V, true>), hipFuncAttributeMaxDynamicSharedMemorySize, N3_LDS_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt256s3_kernel<V, false>), hipFuncAttributeMaxDynamicSharedMemorySize, N3_LDS_BYTES);
+    raised = true;
+  }
+  const int tiles = ((p.M + 159) / 160) * ((p.N + 255) / 256);
+  if (g_tune_x[2] == 2) hipLaunchKernelGGL((gemm_nt256s3_kernel<V, false>), dim3(tiles), dim3(512), N3_LDS_BYTES, stream, p);
+  else hipLaunchKernelGGL((gemm_nt256s3_kernel<V, true>), dim3(tiles), dim3(512), N3_LDS_BYTES, stream, p);
+}
+template <int V>
 static void launch_nt256_h(const GemmNT& p, int tmw, hipStream_t stream) {
   switch (tmw) {
-    case 5: launch_nt256<5, V>(p, stream); break;
+    case 5: if (g_tune_x[2] == 1) launch_nt256<5, V>(p, stream); else launch_nt256s3<V>(p, stream); break;
     case 6: launch_nt256<6, V>(p, stream); break;
     case 7: launch_nt256<7, V>(p, stream); break;
     default: launch_nt256<8, V>(p, stream); break;
@@ -736,7 +968,16 @@ extern "C" int x2_gemm_nt(const void* A, const void* B, void* C, int M, int N, i
   // a small part of the tile - long contractions (K >= 2048: 1.19 vs 1.07 PFLOP/s main loops) or single-output bf16 / fp32
   // epilogues - and its plan fills >= 80 % of the CU rounds; never for the short fp32 + residual launches of the text rows.
   const bool light = var == 0 || var == 1;
-  const bool auto256 = (light || K >= 2048) && eff256 * 100.0 >= (g_tune_x[1] > 0 ? g_tune_x[1] : 80) && !(resid && M < 8192);
+  bool auto256 = (light || K >= 2048) && eff256 * 100.0 >= (g_tune_x[1] > 0 ? g_tune_x[1] : 80) && !(resid && M < 8192);
+  // Round 5, with the three-stage ring at 160 rows and outputs that are NOT cache-resident (probes/bench_nt_choice.py,
+  // profiles/r09k_nt_kernel_choice.txt): the fp32 + residual launches of the long-row towers win on this kernel at any K (vision proj
+  // 37.2 -> 28.8 us, X2VLM-large 68.1 -> 58.5, the image-token input gradient of the cross-attentions 41.4 -> 40.1), and so do the
+  // GELU launches whose plan fills >= 90 % of its rounds (vision fc1 92.6 -> 88.4, fusion ffn1 57.6 -> 55.1 at 192 rows, X2VLM-large
+  // fc1 199.6 -> 183.7 at 256 rows); the text / fusion rows (M < 8192) with a residual stay where they were.  x2_tune(11, 1): the old rule.
+  if (g_tune_x[3] != 1) {
+    if ((var == 5 || var == 6) && M >= 8192 && eff256 * 100.0 >= (g_tune_x[1] > 0 ? g_tune_x[1] : 80)) auto256 = true;
+    if (var == 2 && eff256 * 100.0 >= 90.0) auto256 = true;
+  }
   const bool use256 = var != 4 && N % 8 == 0 && (g_tune[1] == 3 || ((g_tune[1] == 0 || g_tune[1] == 4) && g_tune[3] == 0 && auto256));
   if (use256) {
     switch (var) {
