@@ -380,27 +380,62 @@ def run_attention(K, B, Bkv, H, Lq, Lk, use_bias, use_mask, kv_map, seed, bias_l
         K.attn_fwd(K.view3(qd, B, Lq), K.view3(kd, Bkv, Lk), K.view3(vd, Bkv, Lk), B, Bkv, H, Lq, Lk, scale,
                    K.view3(od, B, Lq), lse, **{k_: v_ for k_, v_ in kw.items() if k_ not in drop_keys})
         assert relerr(od.view(B, Lq, H * d), ref_out) < 8e-3 and bool(torch.isfinite(lse).all())
-    dq, dk, dv = torch.empty_like(qd), torch.empty_like(kd), torch.empty_like(vd)
-    dS = torch.zeros(B, H, Lq, Lkp, device=dev, dtype=torch.bfloat16) if use_bias else None
-    K.attn_bwd(K.view3(qd, B, Lq), K.view3(kd, Bkv, Lk), K.view3(vd, Bkv, Lk), K.view3(od, B, Lq), K.view3(dod, B, Lq),
-               B, Bkv, H, Lq, Lk, scale, lse, delta, K.view3(dq, B, Lq), K.view3(dk, Bkv, Lk), K.view3(dv, Bkv, Lk),
-               dS=dS, **kw)
     tol = 1.5e-2   # P and dS are rounded to bf16 before the second MFMA
-    assert relerr(dq.view(B, Lq, H * d), q.grad.permute(0, 2, 1, 3).reshape(B, Lq, H * d)) < tol
-    assert relerr(dk.view(Bkv, Lk, H * d), k0.grad.permute(0, 2, 1, 3).reshape(Bkv, Lk, H * d)) < tol
-    assert relerr(dv.view(Bkv, Lk, H * d), v0.grad.permute(0, 2, 1, 3).reshape(Bkv, Lk, H * d)) < tol
-    if use_bias:
-        assert relerr(dS[..., :Lk].float().sum(0), bias_leaf.grad) < tol
-    # the two halves as separate calls (phase 1: dQ, dS, delta; phase 2: dK / dV from that delta) - what lets a caller put the
-    # K/V-side gradients on another stream - give the same bits as the one call
-    dq2, dk2, dv2, delta2 = torch.zeros_like(dq), torch.zeros_like(dk), torch.zeros_like(dv), torch.zeros_like(delta)
-    for phase in (1, 2):
+    want = (q.grad.permute(0, 2, 1, 3).reshape(B, Lq, H * d), k0.grad.permute(0, 2, 1, 3).reshape(Bkv, Lk, H * d),
+            v0.grad.permute(0, 2, 1, 3).reshape(Bkv, Lk, H * d))
+
+    def backward(phase=0, into=None):
+        dq, dk, dv, delta = into if into is not None else (torch.full_like(qd, float("nan")), torch.full_like(kd, float("nan")),
+                                                            torch.full_like(vd, float("nan")), torch.full_like(lse, float("nan")))
+        dS = torch.zeros(B, H, Lq, Lkp, device=dev, dtype=torch.bfloat16) if use_bias else None
         K.attn_bwd(K.view3(qd, B, Lq), K.view3(kd, Bkv, Lk), K.view3(vd, Bkv, Lk), K.view3(od, B, Lq), K.view3(dod, B, Lq),
-                   B, Bkv, H, Lq, Lk, scale, lse, delta2, K.view3(dq2, B, Lq), K.view3(dk2, Bkv, Lk), K.view3(dv2, Bkv, Lk),
+                   B, Bkv, H, Lq, Lk, scale, lse, delta, K.view3(dq, B, Lq), K.view3(dk, Bkv, Lk), K.view3(dv, Bkv, Lk),
                    dS=dS, phase=phase, **kw)
-        if phase == 1:
-            assert torch.equal(dq2, dq) and float(dk2.float().abs().max()) == 0.0 and float(dv2.float().abs().max()) == 0.0
-    assert torch.equal(dk2, dk) and torch.equal(dv2, dv) and torch.equal(delta2, delta)
+        return dq, dk, dv, delta, dS
+
+    def check(dq, dk, dv, delta, dS):
+        assert relerr(dq.view(B, Lq, H * d), want[0]) < tol
+        assert relerr(dk.view(Bkv, Lk, H * d), want[1]) < tol
+        assert relerr(dv.view(Bkv, Lk, H * d), want[2]) < tol
+        assert bool(torch.isfinite(delta).all())
+        if use_bias:
+            assert relerr(dS[..., :Lk].float().sum(0), bias_leaf.grad) < tol
+    got = backward()
+    check(*got)
+    # 64 < L <= 208 without K/V sharing: the call above ran the ONE-PASS kernel (one workgroup per (sequence, head) forms S, P, dP, dS
+    # once); x2_tune(14, 1) runs the dQ + dK/dV pair on the same inputs - against the oracle as well, and the two forms against
+    # each other (same products, different summation order in Delta and in the accumulators: bf16-rounding-sized differences)
+    one_pass = kv_map is None and 64 < Lq <= 208 and 64 < Lk <= 208
+    lib = importlib.import_module("x2-vlm_amd._lib").lib()
+    if one_pass:
+        lib.x2_tune(14, 1)
+        try:
+            two = backward()
+            check(*two)
+            for a_, b_ in zip(got[:3], two[:3]):
+                assert relerr(a_.float(), b_.float().cpu()) < 6e-3
+            assert relerr(got[3], two[3].cpu()) < 1e-5
+            if use_bias:
+                assert relerr(got[4][..., :Lk].float().sum(0), two[4][..., :Lk].float().sum(0).cpu()) < 6e-3
+                # pad columns of the dS stream (keys past Lk): the buffer was zeroed, neither form writes anything else there
+                if Lkp > Lk:
+                    assert float(got[4][..., Lk:].float().abs().max()) == 0.0 and float(two[4][..., Lk:].float().abs().max()) == 0.0
+            _phase_split_matches(backward, two)
+        finally:
+            lib.x2_tune(14, 0)
+    else:
+        _phase_split_matches(backward, got)
+
+
+def _phase_split_matches(backward, ref):
+    """the two halves as separate calls (phase 1: dQ, dS, delta; phase 2: dK / dV from that delta) - what lets a caller put the K/V-side
+    gradients on another stream - give the same bits as the two-kernel form in one call"""
+    dq, dk, dv, delta, _ = ref
+    into = (torch.zeros_like(dq), torch.zeros_like(dk), torch.zeros_like(dv), torch.zeros_like(delta))
+    backward(phase=1, into=into)
+    assert torch.equal(into[0], dq) and float(into[1].float().abs().max()) == 0.0 and float(into[2].float().abs().max()) == 0.0
+    backward(phase=2, into=into)
+    assert torch.equal(into[1], dk) and torch.equal(into[2], dv) and torch.equal(into[3], delta)
 
 
 def test_attention_vision_bias(K):
@@ -433,6 +468,16 @@ def test_attention_cross_shared_kv(K):
     # an image nobody attends to (zero gradient, nothing to do), and more rows per image than one 128-query pass holds
     run_attention(K, B=4, Bkv=3, H=2, Lq=30, Lk=197, use_bias=False, use_mask=True, kv_map=[0, 2, 2, 0], seed=320)
     run_attention(K, B=11, Bkv=2, H=3, Lq=30, Lk=70, use_bias=False, use_mask=True, kv_map=[0] * 9 + [1] * 2, seed=330)
+
+
+def test_attention_one_pass_backward_shapes(K):
+    """attn_bwd_onepass_kernel beyond the N = 197 / 208 / 70 cases above: 8 key strips (every wave owns exactly one), 7 (one wave
+    owns none and only keeps the barriers), more queries than keys and the reverse, without a bias (no dS stream) and with bias + mask."""
+    run_attention(K, B=2, Bkv=2, H=2, Lq=128, Lk=128, use_bias=True, use_mask=False, kv_map=None, seed=500)
+    run_attention(K, B=2, Bkv=2, H=3, Lq=100, Lk=100, use_bias=True, use_mask=False, kv_map=None, seed=510, bias_log2=True)
+    run_attention(K, B=1, Bkv=1, H=2, Lq=150, Lk=90, use_bias=False, use_mask=True, kv_map=None, seed=520)
+    run_attention(K, B=2, Bkv=2, H=2, Lq=90, Lk=150, use_bias=True, use_mask=True, kv_map=None, seed=530)
+    run_attention(K, B=33, Bkv=33, H=12, Lq=197, Lk=197, use_bias=True, use_mask=False, kv_map=None, seed=540, bias_log2=True)
 
 
 def test_attention_long_keys(K):

@@ -12,6 +12,7 @@
 // reduced from) and dK/dV.
 #include "x2_common.h"
 #include <cstdlib>
+extern "C" int x2_tune_get(int key);
 
 #define HD 64                 // head dim
 #define KT 64                 // keys (or queries) per LDS tile
@@ -1018,6 +1019,270 @@ __global__ __launch_bounds__(64 * KW, WPS) void attn_bwd_dkv_kernel(AttnArgs a) 
   }
 }
 
+// ------------------------------------------------------------------------------------------ backward in one pass
+// Self-attention with 64 < Lq, Lk <= 208 and no K/V sharing (the BEiT-2 blocks at N = 197): ONE eight-wave workgroup per
+// (sequence, head) forms S, P, dP and dS once - 5 matrix products instead of the 7 of the dQ + dK/dV pair above, half the score
+// arithmetic, Q / dO / K / V fetched once instead of three times.
+//   phase A (key side, the tile arithmetic of attn_bwd_dkv_kernel): a wave owns the key strips {wave, wave + 8} (16 keys each, K / V
+//     fragments in registers), walks the query strips in pairs (32 queries = one MFMA contraction) over Q and dO resident in LDS,
+//     accumulates dK / dV in registers and leaves every dS tile in LDS as bf16, laid out [query strip][key][16 queries] - the
+//     lane that owns a key writes its 4 queries as one 8-byte store, the wave 512 contiguous bytes;
+//   phase B (query side): the K fragments go from registers into the LDS image Q occupied, and a wave forms dQ^T = K^T . dS^T for the
+//     query strips {wave, wave + 8}: both operands by transposing reads (ds_read_b64_tr_b16), the dS fragment it has just read
+//     is also what goes to the HBM dS stream (bias gradient), in the layout the dQ kernels write.
+// Delta = rowsum(dO * O) is computed while Q / dO are staged (and still written out: callers keep the buffer).
+// LDS image (140.6 KB, one workgroup per CU): dO | Q (later K) | 16 zero rows | dS blocks | 16 zero rows | LSE | Delta.  The order
+// matters: a transposing fragment read of the last 32-row step runs 16 rows past its operand, and what it finds there must be
+// finite AND meet a zero on the other side of the product - dO runs into Q (finite; its P is 0: no such queries), Q / K into
+// the zero rows, a dS block into the next block (finite) while K has already run into the zero rows.
+#define OP_ROWS 208
+#define OP_REG (OP_ROWS * 128)
+#define OP_BLK (OP_ROWS * 32)
+#define OP_NBLK (OP_ROWS / 16)
+#define OP_DO 0
+#define OP_QK OP_REG
+#define OP_Z1 (2 * OP_REG)
+#define OP_DS (OP_Z1 + 16 * 128)
+#define OP_Z2 (OP_DS + OP_NBLK * OP_BLK)
+#define OP_LSE (OP_Z2 + 16 * 32)
+#define OP_DEL (OP_LSE + OP_ROWS * 4)
+#define OP_BYTES (OP_DEL + OP_ROWS * 4)
+template <bool BL2>
+__global__ __launch_bounds__(512, 2) void attn_bwd_onepass_kernel(AttnArgs a) {
+  __shared__ __attribute__((aligned(16))) char smem[OP_BYTES];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fi = lane & 15, g = lane >> 4;
+  int bx_, h, b;
+  if (!attn_block(a, bx_, h, b)) return;
+  const float sc2 = a.scale * LOG2E;
+  const int nsq = (a.Lq + 15) >> 4, nsk = (a.Lk + 15) >> 4;      // 16-row strips of queries / keys
+  const uint32_t lbase = lds_addr(smem), dotile = lbase + OP_DO, qtile = lbase + OP_QK;
+  float* lse_s = reinterpret_cast<float*>(smem + OP_LSE);
+  float* del_s = reinterpret_cast<float*>(smem + OP_DEL);
+
+  // this wave's key strips (wave, wave + 8): K / V rows straight into MFMA fragments
+  int key[2]; bool kok[2];
+  bf16x8 kf[2][2], vf[2][2];
+#pragma unroll
+  for (int gk = 0; gk < 2; ++gk) {
+    const int k0 = (wave + 8 * gk) * 16;
+    kok[gk] = k0 + fi < a.Lk;
+    key[gk] = min(k0 + fi, a.Lk - 1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      kf[gk][ks] = *reinterpret_cast<const bf16x8*>(a.K + b * a.k_bs + (long)key[gk] * a.k_rs + h * HD + ks * 32 + g * 8);
+      vf[gk][ks] = *reinterpret_cast<const bf16x8*>(a.V + b * a.v_bs + (long)key[gk] * a.v_rs + h * HD + ks * 32 + g * 8);
+    }
+  }
+  // zero rows and dS blocks (strips no wave owns, queries past Lq and the columns of keys past Lk stay zero)
+  for (int o = tid * 16; o < OP_LSE - OP_Z1; o += 512 * 16) *reinterpret_cast<u32x4*>(smem + OP_Z1 + o) = u32x4{0u, 0u, 0u, 0u};
+  {
+    // Q and dO -> LDS (rows past Lq: copies of the last row - finite, and their LSE = +1e30 makes P = dS = 0), Delta on the way
+    u32x4 rq[4], rdo[4], ro[4];
+    float rl[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = tid + i * 512;
+      if (c < OP_ROWS * 8) {
+        const int row = c >> 3, ch = c & 7, gr = min(row, a.Lq - 1);
+        rq[i] = *reinterpret_cast<const u32x4*>(a.Q + b * a.q_bs + (long)gr * a.q_rs + h * HD + ch * 8);
+        rdo[i] = *reinterpret_cast<const u32x4*>(a.dO + b * a.do_bs + (long)gr * a.do_rs + h * HD + ch * 8);
+        ro[i] = *reinterpret_cast<const u32x4*>(a.O + b * a.o_bs + (long)gr * a.o_rs + h * HD + ch * 8);
+        rl[i] = (ch == 0 && row < a.Lq) ? a.LSE[((long)b * a.H + h) * a.Lq + row] : 1e30f;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = tid + i * 512;
+      if (c < OP_ROWS * 8) {            // wave-uniform: 1664 = 26 waves of chunks
+        const int row = c >> 3, ch = c & 7;
+        float dl = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dl += bf_lo(rdo[i][e]) * bf_lo(ro[i][e]) + bf_hi(rdo[i][e]) * bf_hi(ro[i][e]);
+        dl += __shfl_xor(dl, 1, 64); dl += __shfl_xor(dl, 2, 64); dl += __shfl_xor(dl, 4, 64);
+        const int off = row * 128 + ((ch ^ (row & 7)) << 4);
+        *reinterpret_cast<u32x4*>(smem + OP_QK + off) = rq[i];
+        *reinterpret_cast<u32x4*>(smem + OP_DO + off) = rdo[i];
+        if (ch == 0) {
+          const bool ok = row < a.Lq;
+          lse_s[row] = rl[i];
+          del_s[row] = ok ? dl : 0.f;
+          if (ok) a.Delta[((long)b * a.H + h) * a.Lq + row] = dl;
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- phase A
+  f32x4 dk[2][4], dv[2][4];
+#pragma unroll
+  for (int gk = 0; gk < 2; ++gk)
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) { dk[gk][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[gk][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  auto phase_a = [&](auto ng_) {
+    constexpr int NG = decltype(ng_)::value;
+    float mk[NG];
+#pragma unroll
+    for (int gk = 0; gk < NG; ++gk) mk[gk] = (a.mask ? a.mask[(long)b * a.mask_ld + key[gk]] : 0.f) * LOG2E;
+    // relative-position bias of this lane's keys for one pair of query strips (4 queries per strip and lane), fetched ONE PAIR
+    // AHEAD: left to the top of the pair that uses them the loads sit exposed in front of the exponentials (two waves per SIMD
+    // do not cover an L2 round trip with eight MFMAs).  Columns up to 32 * ceil(nsq / 2) - 1 < biasT_ld (a multiple of 64 >= Lq).
+    const int last_pair = ((nsq + 1) >> 1) - 1;
+    float4 bnext[NG][2];
+    auto load_bias = [&](int s) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int gk = 0; gk < NG; ++gk) {
+          bnext[gk][t] = float4{0.f, 0.f, 0.f, 0.f};
+          if (BL2 || a.biasT) bnext[gk][t] = *reinterpret_cast<const float4*>(a.biasT + ((long)h * a.Lk + key[gk]) * a.biasT_ld + 32 * s + 16 * t + g * 4);
+        }
+    };
+    load_bias(0);
+    auto pair = [&](int s, auto full_) {
+      constexpr int NTQ = decltype(full_)::value ? 2 : 1;        // query strips of this pair that exist
+      float4 btv[NG][2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int gk = 0; gk < NG; ++gk) {
+          btv[gk][t] = bnext[gk][t];
+          if (!BL2 && (a.dbg & 16)) { btv[gk][t].x *= LN2; btv[gk][t].y *= LN2; btv[gk][t].z *= LN2; btv[gk][t].w *= LN2; }
+        }
+      load_bias(min(s + 1, last_pair));
+      f32x4 p[NG][2], ds[NG][2];
+#pragma unroll
+      for (int gk = 0; gk < NG; ++gk) { p[gk][1] = f32x4{0.f, 0.f, 0.f, 0.f}; ds[gk][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+      for (int t = 0; t < NTQ; ++t) {
+        f32x4 sa[NG], dp[NG];
+#pragma unroll
+        for (int gk = 0; gk < NG; ++gk) { sa[gk] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[gk] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const bf16x8 qfr = frag_rows(qtile, 32 * s + 16 * t + fi, ks * 4 + g), dofr = frag_rows(dotile, 32 * s + 16 * t + fi, ks * 4 + g);
+#pragma unroll
+          for (int gk = 0; gk < NG; ++gk) {
+            sa[gk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qfr, kf[gk][ks], sa[gk], 0, 0, 0);
+            dp[gk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dofr, vf[gk][ks], dp[gk], 0, 0, 0);
+          }
+        }
+        // this lane: its own key per strip, queries 32 s + 16 t + 4 g + r
+        const float4 ls = *reinterpret_cast<const float4*>(lse_s + 32 * s + 16 * t + g * 4);
+        const float4 dl = *reinterpret_cast<const float4*>(del_s + 32 * s + 16 * t + g * 4);
+        const float lsv[4] = {ls.x, ls.y, ls.z, ls.w}, dlv[4] = {dl.x, dl.y, dl.z, dl.w};
+#pragma unroll
+        for (int gk = 0; gk < NG; ++gk) {
+          const float bbv[4] = {btv[gk][t].x, btv[gk][t].y, btv[gk][t].z, btv[gk][t].w};
+          // branch-free as the LEAN tile of attn_bwd_dkv_kernel: a query past Lq has LSE = +1e30 (P = dS = 0); the min keeps the pad
+          // columns of the bias (undefined) out of the exponent; a key past Lk reaches dK / dV rows that are not stored, and its
+          // dS column is zeroed where it is written for phase B
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float x = BL2 ? fmaf(sa[gk][r], sc2, bbv[r]) : fmaf(sa[gk][r], sc2, fmaf(bbv[r], LOG2E, mk[gk]));
+            const float pv = fast_exp2(fminf(x, 1e29f) - lsv[r]);
+            p[gk][t][r] = pv;
+            ds[gk][t][r] = pv * (dp[gk][r] - dlv[r]);
+          }
+        }
+      }
+      bf16x8 pf[NG], dsf[NG];
+#pragma unroll
+      for (int gk = 0; gk < NG; ++gk) {
+        pf[gk] = pack8(p[gk][0], p[gk][1]);
+        dsf[gk] = pack8(ds[gk][0], ds[gk][1]);
+        const u32x4 w = __builtin_bit_cast(u32x4, dsf[gk]);
+        char* blk = smem + OP_DS + (2 * s) * OP_BLK + ((wave + 8 * gk) * 16 + fi) * 32 + g * 8;
+        *reinterpret_cast<u32x2*>(blk) = kok[gk] ? u32x2{w[0], w[1]} : u32x2{0u, 0u};
+        if (NTQ == 2) *reinterpret_cast<u32x2*>(blk + OP_BLK) = kok[gk] ? u32x2{w[2], w[3]} : u32x2{0u, 0u};
+      }
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        const bf16x8 dotr = frag_cols(dotile, s, dt, lane), qtr = frag_cols(qtile, s, dt, lane);
+#pragma unroll
+        for (int gk = 0; gk < NG; ++gk) {
+          dv[gk][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dotr, pf[gk], dv[gk][dt], 0, 0, 0);
+          dk[gk][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qtr, dsf[gk], dk[gk][dt], 0, 0, 0);
+        }
+      }
+    };
+    for (int s = 0; s < (nsq >> 1); ++s) pair(s, std::true_type{});
+    if (nsq & 1) pair(nsq >> 1, std::false_type{});
+#pragma unroll
+    for (int gk = 0; gk < NG; ++gk) {
+      if (!kok[gk]) continue;
+      bf16_t* kp = a.dK + b * a.dk_bs + (long)key[gk] * a.dk_rs + h * HD + g * 4;
+      bf16_t* vp = a.dV + b * a.dv_bs + (long)key[gk] * a.dv_rs + h * HD + g * 4;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        *reinterpret_cast<u32x2*>(kp + dt * 16) = u32x2{pack_bf16(dk[gk][dt][0] * a.scale, dk[gk][dt][1] * a.scale),
+                                                         pack_bf16(dk[gk][dt][2] * a.scale, dk[gk][dt][3] * a.scale)};
+        *reinterpret_cast<u32x2*>(vp + dt * 16) = u32x2{pack_bf16(dv[gk][dt][0], dv[gk][dt][1]), pack_bf16(dv[gk][dt][2], dv[gk][dt][3])};
+      }
+    }
+  };
+  const int ng = wave + 8 < nsk ? 2 : (wave < nsk ? 1 : 0);
+  if (ng == 2) phase_a(std::integral_constant<int, 2>{});
+  else if (ng == 1) phase_a(std::integral_constant<int, 1>{});
+  __syncthreads();                     // every wave is done with Q
+  // K rows of the strips this wave holds -> the image Q occupied (strips nobody holds keep Q rows: finite, and their dS is zero)
+#pragma unroll
+  for (int gk = 0; gk < 2; ++gk)
+    if (gk < ng) {
+      const int row = (wave + 8 * gk) * 16 + fi;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+        *reinterpret_cast<bf16x8*>(smem + OP_QK + row * 128 + (((ks * 4 + g) ^ (row & 7)) << 4)) = kf[gk][ks];
+    }
+  __syncthreads();
+
+  // ---- phase B
+  auto phase_b = [&](auto nq_) {
+    constexpr int NQ = decltype(nq_)::value;
+    f32x4 dq[NQ][4];
+#pragma unroll
+    for (int j = 0; j < NQ; ++j)
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) dq[j][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int r4 = fi >> 2, c4 = fi & 3;
+    const int kend = min(nsk * 16, a.ds_ld);
+    for (int s = 0; s < ((nsk + 1) >> 1); ++s) {
+      bf16x8 dsf[NQ];
+#pragma unroll
+      for (int j = 0; j < NQ; ++j) {
+        const uint32_t a0 = lbase + OP_DS + (wave + 8 * j) * OP_BLK + (32 * s + 4 * g + r4) * 32 + c4 * 8;
+        dsf[j] = lds_read_tr_frag(a0, a0 + 16 * 32);
+        const int q = (wave + 8 * j) * 16 + fi;
+        if (a.dS && q < a.Lq) {          // the dS stream of the bias gradient: [B][H][Lq][ds_ld], this lane = one query, 2 x 4 keys
+          const u32x4 w = __builtin_bit_cast(u32x4, dsf[j]);
+          bf16_t* dsp = a.dS + (((long)b * a.H + h) * a.Lq + q) * a.ds_ld + 32 * s + 4 * g;
+          if (32 * s + 4 * g < kend) *reinterpret_cast<u32x2*>(dsp) = u32x2{w[0], w[1]};
+          if (32 * s + 16 + 4 * g < kend) *reinterpret_cast<u32x2*>(dsp + 16) = u32x2{w[2], w[3]};
+        }
+      }
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        const bf16x8 ktr = frag_cols(qtile, s, dt, lane);
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) dq[j][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktr, dsf[j], dq[j][dt], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+      const int q = (wave + 8 * j) * 16 + fi;
+      if (q >= a.Lq) continue;
+      bf16_t* op = a.dQ + b * a.dq_bs + (long)q * a.dq_rs + h * HD + g * 4;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+        *reinterpret_cast<u32x2*>(op + dt * 16) = u32x2{pack_bf16(dq[j][dt][0] * a.scale, dq[j][dt][1] * a.scale),
+                                                         pack_bf16(dq[j][dt][2] * a.scale, dq[j][dt][3] * a.scale)};
+    }
+  };
+  if (wave + 8 < nsq) phase_b(std::integral_constant<int, 2>{});
+  else if (wave < nsq) phase_b(std::integral_constant<int, 1>{});
+}
+
 // ------------------------------------------------------------------------------------------ C ABI
 // `args` is the AttnArgs struct laid out as 8-byte slots (pointers, longs) followed by ints/floats;
 // the Python side fills it through ctypes.Structure with the same field order.
@@ -1088,6 +1353,14 @@ extern "C" int x2_attn_bwd(const AttnArgs* pa, void* stream) {
   X2_REQUIRE(a.Bkv > 0, "x2_attn_bwd: Bkv");
   X2_REQUIRE(a.phase >= 0 && a.phase <= 2, "x2_attn_bwd: phase=%d", a.phase);
   const hipStream_t st = (hipStream_t)stream;
+  // one workgroup per (sequence, head) for the whole backward (attn_bwd_onepass_kernel): the BEiT-2 blocks at N = 197; x2_tune(14, 1)
+  // keeps the dQ + dK/dV pair (A/B measurements, and the tests that compare the two forms)
+  if (a.phase == 0 && !a.seq_off && !a.kv_idx && a.B == a.Bkv && a.Lq > 64 && a.Lq <= OP_ROWS && a.Lk > 64 && a.Lk <= OP_ROWS &&
+      !a.drop.thr16 && (a.do_rs % 8 | a.do_bs % 8 | a.o_rs % 8 | a.o_bs % 8) == 0 && x2_tune_get(14) != 1) {
+    if (bl2) attn_launch(attn_bwd_onepass_kernel<true>, a, 1, a.H, a.B, 512, xm, st);
+    else attn_launch(attn_bwd_onepass_kernel<false>, a, 1, a.H, a.B, 512, xm, st);
+    return x2_check_launch("x2_attn_bwd(one pass)");
+  }
   if (a.phase == 2) { /* the dQ half ran in an earlier call */ }
   else if (a.seq_off && a.Lk <= 256 && !a.bias && !a.dS)      // rows sharing K/V: one workgroup per (K/V batch, head)
     hipLaunchKernelGGL((attn_bwd_dq_grouped_kernel<8>), dim3(1, a.H, a.Bkv), dim3(512), 0, st, a);

@@ -840,6 +840,7 @@ static int g_tune[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 //        2 = three-stage ring, reads at the head of their phase, 1 = the two-stage kernel
 //   [11] 1: the rounds 3-4 rule for choosing the 256-column kernel (no fp32 + residual launches below K = 2048, no GELU launches)
 //   [13] LayerNorm forward rows per wave (rowwise.hip): 0 automatic, 1 / 2 / 4
+//   [14] 1: attention backward always as the dQ + dK/dV pair (attention.hip: no one-pass kernel at 64 < L <= 208)
 static int g_tune_x[8] = {0, 0, 0, 0, 0, 0, 0, 0};       // keys 8.. : [1] = key 9, [4] = key 12
 extern "C" int x2_device_cus(void);
 // compute units of the current device (256 on MI355X), asked once: grid-fill decisions below are made in units of it
