@@ -23,7 +23,7 @@ extern "C" {
 #endif
 
 const char* x2_last_error(void);
-int x2_abi_version(void);          /* == 10 */
+int x2_abi_version(void);          /* == 11 */
 int x2_device_cus(void);           /* compute units of the current HIP device, 0 if none */
 int x2_tune(int key, int value);   /* kernel-variant knobs for probes/ and tests (0 = automatic); keys listed in csrc/gemm.hip.
                                     * key 12 = compute units every tile plan leaves to RCCL's channel kernels (world > 1);
@@ -111,6 +111,11 @@ typedef struct X2AttnArgs {
 } X2AttnArgs;
 int x2_attn_fwd(const X2AttnArgs* args, void* stream);
 int x2_attn_bwd(const X2AttnArgs* args, void* stream);   /* dQ (+dS, Delta) then dK/dV; no atomics */
+/* Which backward a phase-0 x2_attn_bwd call with these arguments runs: 0 = two kernels (dQ, then dK/dV), 1 = one pass, one workgroup per
+ * (sequence, head) (64 < Lq, Lk <= 208, no K/V sharing, no probability dropout: the BEiT-2 blocks, beit2.py:135-159), 2 = one pass, one
+ * workgroup per (shared K/V batch, head) (Lq <= 128, Lk <= 208, no bias: the cross-attention of xbert.py:322-415).  A caller that
+ * would put the dK/dV half (phase 2) on another stream asks first: in one pass there is no such half. */
+int x2_attn_bwd_one_pass(const X2AttnArgs* args);
 
 /* ---- row-wise kernels (csrc/rowwise.hip) ------------------------------------------------------------
  * nn.LayerNorm: beit2.py:175,181,411 (eps 1e-6); xbert.py:214,422,506,796 (1e-12); xvlm.py:166 (1e-5).

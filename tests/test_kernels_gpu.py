@@ -384,14 +384,14 @@ def run_attention(K, B, Bkv, H, Lq, Lk, use_bias, use_mask, kv_map, seed, bias_l
     want = (q.grad.permute(0, 2, 1, 3).reshape(B, Lq, H * d), k0.grad.permute(0, 2, 1, 3).reshape(Bkv, Lk, H * d),
             v0.grad.permute(0, 2, 1, 3).reshape(Bkv, Lk, H * d))
 
-    def backward(phase=0, into=None):
+    def backward(phase=0, into=None, ask_form=False):
         dq, dk, dv, delta = into if into is not None else (torch.full_like(qd, float("nan")), torch.full_like(kd, float("nan")),
                                                             torch.full_like(vd, float("nan")), torch.full_like(lse, float("nan")))
         dS = torch.zeros(B, H, Lq, Lkp, device=dev, dtype=torch.bfloat16) if use_bias else None
-        K.attn_bwd(K.view3(qd, B, Lq), K.view3(kd, Bkv, Lk), K.view3(vd, Bkv, Lk), K.view3(od, B, Lq), K.view3(dod, B, Lq),
-                   B, Bkv, H, Lq, Lk, scale, lse, delta, K.view3(dq, B, Lq), K.view3(dk, Bkv, Lk), K.view3(dv, Bkv, Lk),
-                   dS=dS, phase=phase, **kw)
-        return dq, dk, dv, delta, dS
+        form = K.attn_bwd(K.view3(qd, B, Lq), K.view3(kd, Bkv, Lk), K.view3(vd, Bkv, Lk), K.view3(od, B, Lq), K.view3(dod, B, Lq),
+                          B, Bkv, H, Lq, Lk, scale, lse, delta, K.view3(dq, B, Lq), K.view3(dk, Bkv, Lk), K.view3(dv, Bkv, Lk),
+                          dS=dS, phase=phase, ask_form=ask_form, **kw)
+        return form if ask_form else (dq, dk, dv, delta, dS)
 
     def check(dq, dk, dv, delta, dS):
         assert relerr(dq.view(B, Lq, H * d), want[0]) < tol
@@ -402,10 +402,13 @@ def run_attention(K, B, Bkv, H, Lq, Lk, use_bias, use_mask, kv_map, seed, bias_l
             assert relerr(dS[..., :Lk].float().sum(0), bias_leaf.grad) < tol
     got = backward()
     check(*got)
-    # 64 < L <= 208 without K/V sharing: the call above ran the ONE-PASS kernel (one workgroup per (sequence, head) forms S, P, dP, dS
-    # once); x2_tune(14, 1) runs the dQ + dK/dV pair on the same inputs - against the oracle as well, and the two forms against
-    # each other (same products, different summation order in Delta and in the accumulators: bf16-rounding-sized differences)
-    one_pass = kv_map is None and 64 < Lq <= 208 and 64 < Lk <= 208
+    # 64 < L <= 208 without K/V sharing, and rows sharing K/V with Lq <= 128, Lk <= 208: the call above ran a ONE-PASS kernel (one
+    # workgroup per (sequence, head) / (shared K/V batch, head) forms S, P, dP, dS once); x2_tune(14, 1) runs the dQ + dK/dV pair on
+    # the same inputs - against the oracle as well, and the two forms against each other (same products, different summation
+    # order in Delta and in the accumulators: bf16-rounding-sized differences)
+    form = backward(ask_form=True)
+    assert form == (1 if kv_map is None and 64 < Lq <= 208 and 64 < Lk <= 208 else 2 if kv_map is not None and Lq <= 128 and Lk <= 208 else 0)
+    one_pass = form != 0
     lib = importlib.import_module("x2-vlm_amd._lib").lib()
     if one_pass:
         lib.x2_tune(14, 1)
@@ -415,6 +418,7 @@ def run_attention(K, B, Bkv, H, Lq, Lk, use_bias, use_mask, kv_map, seed, bias_l
             for a_, b_ in zip(got[:3], two[:3]):
                 assert relerr(a_.float(), b_.float().cpu()) < 6e-3
             assert relerr(got[3], two[3].cpu()) < 1e-5
+            assert backward(ask_form=True) == 0
             if use_bias:
                 assert relerr(got[4][..., :Lk].float().sum(0), two[4][..., :Lk].float().sum(0).cpu()) < 6e-3
                 # pad columns of the dS stream (keys past Lk): the buffer was zeroed, neither form writes anything else there
@@ -478,6 +482,40 @@ def test_attention_one_pass_backward_shapes(K):
     run_attention(K, B=1, Bkv=1, H=2, Lq=150, Lk=90, use_bias=False, use_mask=True, kv_map=None, seed=520)
     run_attention(K, B=2, Bkv=2, H=2, Lq=90, Lk=150, use_bias=True, use_mask=True, kv_map=None, seed=530)
     run_attention(K, B=33, Bkv=33, H=12, Lq=197, Lk=197, use_bias=True, use_mask=False, kv_map=None, seed=540, bias_log2=True)
+
+
+def test_attention_one_pass_forms_agree_under_dropout(K):
+    """Probability dropout (xbert.py:399) in the shared-K/V one-pass backward: the element index of (sequence, head, query, key) - hence
+    the mask - is the one the forward and the two-kernel backward use, so on the same inputs the two backward forms agree to rounding
+    (a wrong index would decorrelate the masks: errors of order one).  9 sequences on one image = 3 chunks of 4."""
+    lib = importlib.import_module("x2-vlm_amd._lib").lib()
+    d, H, Lq, Lk, kv_map = 64, 3, 30, 70, [0] * 9 + [1] * 2
+    B, Bkv = len(kv_map), 2
+    qd, dod = (bf(rnd(B * Lq, H * d, seed=600 + i)).to(dev) for i in range(2))
+    kd, vd = (bf(rnd(Bkv * Lk, H * d, seed=610 + i)).to(dev) for i in range(2))
+    keep = (torch.rand(B, Lk, generator=torch.Generator().manual_seed(7)) > 0.3).float(); keep[:, 0] = 1
+    mp = torch.zeros(B, K.round_up(Lk, 64)); mp[:, :Lk] = (1 - keep) * -10000.0
+    kv_idx = torch.tensor(kv_map, dtype=torch.int32)
+    off = torch.zeros(Bkv + 1, dtype=torch.int32); off[1:] = torch.cumsum(torch.bincount(kv_idx, minlength=Bkv), 0)
+    kw = dict(mask=mp.to(dev), kv_idx=kv_idx.to(dev), seq_off=off.to(dev), seq_ids=torch.argsort(kv_idx, stable=True).to(torch.int32).to(dev),
+              drop=K.dropout_spec(0.1, 4242, 5))
+    od = torch.empty_like(qd); lse = torch.empty(B * H * Lq, device=dev)
+    K.attn_fwd(K.view3(qd, B, Lq), K.view3(kd, Bkv, Lk), K.view3(vd, Bkv, Lk), B, Bkv, H, Lq, Lk, d ** -0.5, K.view3(od, B, Lq), lse,
+               **{k_: v_ for k_, v_ in kw.items() if k_ not in ("seq_off", "seq_ids")})
+    res = []
+    try:
+        for knob in (0, 1):
+            lib.x2_tune(14, knob)
+            dq, dk, dv, delta = torch.full_like(qd, float("nan")), torch.full_like(kd, float("nan")), torch.full_like(vd, float("nan")), torch.empty_like(lse)
+            args = (K.view3(qd, B, Lq), K.view3(kd, Bkv, Lk), K.view3(vd, Bkv, Lk), K.view3(od, B, Lq), K.view3(dod, B, Lq), B, Bkv, H, Lq, Lk,
+                    d ** -0.5, lse, delta, K.view3(dq, B, Lq), K.view3(dk, Bkv, Lk), K.view3(dv, Bkv, Lk))
+            assert K.attn_bwd(*args, ask_form=True, **kw) == (2 if knob == 0 else 0)
+            K.attn_bwd(*args, **kw)
+            res.append((dq, dk, dv, delta))
+    finally:
+        lib.x2_tune(14, 0)
+    for a_, b_ in zip(res[0], res[1]):
+        assert bool(torch.isfinite(a_.float()).all()) and relerr(a_.float(), b_.float().cpu()) < 6e-3
 
 
 def test_attention_long_keys(K):

@@ -85,7 +85,8 @@ _COMM_SIGS = {
     "x2_comm_broadcast": [P, P, L, I, I, P, P],
     "x2_comm_destroy": [P],
 }
-EXPORTS = sorted(list(_SIGS) + list(_COMM_SIGS) + ["x2_last_error", "x2_abi_version", "x2_device_cus", "x2_tune", "x2_tune_get"])
+EXPORTS = sorted(list(_SIGS) + list(_COMM_SIGS) + ["x2_last_error", "x2_abi_version", "x2_device_cus", "x2_tune", "x2_tune_get",
+                                                         "x2_attn_bwd_one_pass"])
 
 _lib = None
 
@@ -113,6 +114,7 @@ def lib():
         h.x2_device_cus.restype = I
         h.x2_tune.argtypes, h.x2_tune.restype = [I, I], I
         h.x2_tune_get.argtypes, h.x2_tune_get.restype = [I], I
+        h.x2_attn_bwd_one_pass.argtypes, h.x2_attn_bwd_one_pass.restype = [C.POINTER(AttnArgs)], I
         for kv in filter(None, os.environ.get("X2_TUNE", "").split(",")):      # probes: "key=value,..." kernel-variant knobs (csrc/gemm.hip)
             k, v = kv.split("=")
             if h.x2_tune(int(k), int(v)) != 0:

@@ -1283,6 +1283,239 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_onepass_kernel(AttnArgs a) {
   else if (wave < nsq) phase_b(std::integral_constant<int, 1>{});
 }
 
+// ------------------------------------------------------------------------------------------ backward in one pass, shared K/V
+// Cross-attention of the fusion stack (text rows -> the image tokens several of them share; Lq <= 128, Lk <= 208, no bias): the
+// one-pass scheme above with ONE eight-wave workgroup per (image, head) that walks the sequences using the image (CSR seq_off /
+// seq_ids) in chunks of 8 query strips.  A sequence is padded to whole 16-query strips (30 tokens -> 2 strips, so a chunk is 4
+// sequences and a 32-query contraction step is one sequence): every strip belongs to one sequence, its additive key mask and
+// its dropout element base are per-strip values, and the pad queries carry LSE = +1e30 (P = dS = 0).  dK / dV stay in the
+// accumulators across the chunks; K sits in an LDS image of its own (phase B of one chunk, phase A of the next need K and Q).
+//   per chunk: stage Q / dO / LSE / Delta / mask rows -> barrier -> phase A -> barrier -> phase B (one strip per wave) -> barrier
+// Replaces attn_bwd_dq_grouped_kernel + attn_bwd_dkv_kernel<4, 1, false> (which walked 64-row tiles holding ONE 30-row
+// sequence each, one barrier and one exposed load per sequence): 5 matrix products instead of 7, and the K/V-side gradients no
+// longer need a stream of their own to hide behind.
+#define XP_STRIPS 8
+#define XP_ROWS (XP_STRIPS * 16)
+#define XP_DO 0
+#define XP_Q (XP_ROWS * 128)
+#define XP_Z1 (2 * XP_ROWS * 128)
+#define XP_K (XP_Z1 + 16 * 128)
+#define XP_Z3 (XP_K + OP_REG)
+#define XP_DS (XP_Z3 + 16 * 128)
+#define XP_Z2 (XP_DS + XP_STRIPS * OP_BLK)
+#define XP_LSE (XP_Z2 + 16 * 32)
+#define XP_DEL (XP_LSE + XP_ROWS * 4)
+#define XP_MASK (XP_DEL + XP_ROWS * 4)                 // [8 strips][208 keys] fp32, x log2 e
+#define XP_SB (XP_MASK + XP_STRIPS * OP_ROWS * 4)      // [8] sequence of every strip (-1: none)
+#define XP_BYTES (XP_SB + 64)
+template <bool DROP>
+__global__ __launch_bounds__(512, 2) void attn_bwd_onepass_grouped_kernel(AttnArgs a) {
+  const DropSpec drop_ = drop_at_epoch(a.drop, a.drop_epoch);
+  __shared__ __attribute__((aligned(16))) char smem[XP_BYTES];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fi = lane & 15, g = lane >> 4;
+  const int h = blockIdx.y, bk = blockIdx.z;
+  const float sc2 = a.scale * LOG2E;
+  const int lkp = (a.Lk + 63) & ~63;
+  const int nsk = (a.Lk + 15) >> 4;                    // key strips (<= 13)
+  const int sps = (a.Lq + 15) >> 4;                    // strips per sequence (<= 8)
+  const int spc = XP_STRIPS / sps;                     // sequences per chunk
+  const int sb = a.seq_off[bk], nseq = a.seq_off[bk + 1] - sb;
+  const uint32_t lbase = lds_addr(smem), dotile = lbase + XP_DO, qtile = lbase + XP_Q, ktile = lbase + XP_K;
+  float* lse_s = reinterpret_cast<float*>(smem + XP_LSE);
+  float* del_s = reinterpret_cast<float*>(smem + XP_DEL);
+  float* mask_s = reinterpret_cast<float*>(smem + XP_MASK);
+  int* sb_s = reinterpret_cast<int*>(smem + XP_SB);
+
+  int key[2]; bool kok[2];
+  bf16x8 kf[2][2], vf[2][2];
+  const int ng = wave + 8 < nsk ? 2 : (wave < nsk ? 1 : 0);
+#pragma unroll
+  for (int gk = 0; gk < 2; ++gk) {
+    const int k0 = (wave + 8 * gk) * 16;
+    kok[gk] = k0 + fi < a.Lk;
+    key[gk] = min(k0 + fi, a.Lk - 1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      kf[gk][ks] = *reinterpret_cast<const bf16x8*>(a.K + bk * a.k_bs + (long)key[gk] * a.k_rs + h * HD + ks * 32 + g * 8);
+      vf[gk][ks] = *reinterpret_cast<const bf16x8*>(a.V + bk * a.v_bs + (long)key[gk] * a.v_rs + h * HD + ks * 32 + g * 8);
+    }
+  }
+  f32x4 dk[2][4], dv[2][4];
+#pragma unroll
+  for (int gk = 0; gk < 2; ++gk)
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) { dk[gk][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[gk][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+  if (nseq > 0) {                      // block-uniform
+    // zero rows, dS blocks; K rows from the fragments (strips nobody holds: zeros - their dS rows are zero as well, but 0 x NaN is not)
+    for (int o = tid * 16; o < 16 * 128; o += 512 * 16) *reinterpret_cast<u32x4*>(smem + XP_Z1 + o) = u32x4{0u, 0u, 0u, 0u};
+    for (int o = tid * 16; o < XP_LSE - XP_Z3; o += 512 * 16) *reinterpret_cast<u32x4*>(smem + XP_Z3 + o) = u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int gk = 0; gk < 2; ++gk) {
+      const int row = (wave + 8 * gk) * 16 + fi;
+      if (row < OP_ROWS) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+          *reinterpret_cast<bf16x8*>(smem + XP_K + row * 128 + (((ks * 4 + g) ^ (row & 7)) << 4)) = gk < ng ? kf[gk][ks] : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+      }
+    }
+    const int nchunk = (nseq + spc - 1) / spc;
+    for (int c = 0; c < nchunk; ++c) {
+      const int nsc = min(spc, nseq - c * spc), nvs = nsc * sps;       // sequences / strips of this chunk
+      {
+        // stage the chunk: row = strip * 16 + r, strip -> (sequence slot strip / sps, query strip strip % sps)
+        u32x4 rq[2], rdo[2], ro[2];
+        float rl[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int cc = tid + i * 512, row = cc >> 3, ch = cc & 7, strip = row >> 4, slot = strip / sps, q = (strip - slot * sps) * 16 + (row & 15);
+          const bool ok = slot < nsc && q < a.Lq;
+          rq[i] = rdo[i] = ro[i] = u32x4{0u, 0u, 0u, 0u};
+          rl[i] = 1e30f;
+          if (ok) {
+            const int b = a.seq_ids[sb + c * spc + slot];
+            rq[i] = *reinterpret_cast<const u32x4*>(a.Q + b * a.q_bs + (long)q * a.q_rs + h * HD + ch * 8);
+            rdo[i] = *reinterpret_cast<const u32x4*>(a.dO + b * a.do_bs + (long)q * a.do_rs + h * HD + ch * 8);
+            ro[i] = *reinterpret_cast<const u32x4*>(a.O + b * a.o_bs + (long)q * a.o_rs + h * HD + ch * 8);
+            if (ch == 0) rl[i] = a.LSE[((long)b * a.H + h) * a.Lq + q];
+          }
+        }
+        // additive key mask of every strip's sequence (x log2 e), and the sequence itself
+        for (int e = tid; e < XP_STRIPS * OP_ROWS; e += 512) {
+          const int strip = e / OP_ROWS, k = e - strip * OP_ROWS, slot = strip / sps;
+          float m = 0.f;
+          if (a.mask && slot < nsc && k < a.Lk) m = a.mask[(long)a.seq_ids[sb + c * spc + slot] * a.mask_ld + k] * LOG2E;
+          mask_s[e] = m;
+        }
+        if (tid < XP_STRIPS) { const int slot = tid / sps; sb_s[tid] = slot < nsc ? a.seq_ids[sb + c * spc + slot] : -1; }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int cc = tid + i * 512, row = cc >> 3, ch = cc & 7, strip = row >> 4, slot = strip / sps, q = (strip - slot * sps) * 16 + (row & 15);
+          const bool ok = slot < nsc && q < a.Lq;
+          float dl = 0.f;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) dl += bf_lo(rdo[i][e]) * bf_lo(ro[i][e]) + bf_hi(rdo[i][e]) * bf_hi(ro[i][e]);
+          dl += __shfl_xor(dl, 1, 64); dl += __shfl_xor(dl, 2, 64); dl += __shfl_xor(dl, 4, 64);
+          const int off = row * 128 + ((ch ^ (row & 7)) << 4);
+          *reinterpret_cast<u32x4*>(smem + XP_Q + off) = rq[i];
+          *reinterpret_cast<u32x4*>(smem + XP_DO + off) = rdo[i];
+          if (ch == 0) {
+            lse_s[row] = rl[i];
+            del_s[row] = ok ? dl : 0.f;
+            if (ok) a.Delta[((long)a.seq_ids[sb + c * spc + slot] * a.H + h) * a.Lq + q] = dl;
+          }
+        }
+      }
+      __syncthreads();
+      // ---- phase A
+      auto phase_a = [&](auto ng_) {
+        constexpr int NG = decltype(ng_)::value;
+        auto pair = [&](int s, auto full_) {
+          constexpr int NTQ = decltype(full_)::value ? 2 : 1;
+          f32x4 p[NG][2], ds[NG][2];
+#pragma unroll
+          for (int gk = 0; gk < NG; ++gk) { p[gk][1] = f32x4{0.f, 0.f, 0.f, 0.f}; ds[gk][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+          for (int t = 0; t < NTQ; ++t) {
+            const int strip = 2 * s + t;
+            f32x4 sa[NG], dp[NG];
+#pragma unroll
+            for (int gk = 0; gk < NG; ++gk) { sa[gk] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[gk] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+              const bf16x8 qfr = frag_rows(qtile, strip * 16 + fi, ks * 4 + g), dofr = frag_rows(dotile, strip * 16 + fi, ks * 4 + g);
+#pragma unroll
+              for (int gk = 0; gk < NG; ++gk) {
+                sa[gk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qfr, kf[gk][ks], sa[gk], 0, 0, 0);
+                dp[gk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dofr, vf[gk][ks], dp[gk], 0, 0, 0);
+              }
+            }
+            const float4 ls = *reinterpret_cast<const float4*>(lse_s + strip * 16 + g * 4);
+            const float4 dl = *reinterpret_cast<const float4*>(del_s + strip * 16 + g * 4);
+            const float lsv[4] = {ls.x, ls.y, ls.z, ls.w}, dlv[4] = {dl.x, dl.y, dl.z, dl.w};
+            // dropout element of (query, key): ((b H + h) Lq + query) lkp + key; pad queries (P = 0 anyway) take the last row's
+            const int slot = strip / sps, qq0 = (strip - slot * sps) * 16 + g * 4;
+            uint32_t ebase = 0;
+            if (DROP) ebase = (uint32_t)(((long)sb_s[strip] * a.H + h) * a.Lq);
+#pragma unroll
+            for (int gk = 0; gk < NG; ++gk) {
+              const float mk = mask_s[strip * OP_ROWS + key[gk]];
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const float pv = fast_exp2(fmaf(sa[gk][r], sc2, mk) - lsv[r]);
+                float dm = 1.f;
+                if (DROP) dm = drop_mul(drop_, (ebase + (uint32_t)min(qq0 + r, a.Lq - 1)) * (uint32_t)lkp + (uint32_t)key[gk]);
+                p[gk][t][r] = DROP ? pv * dm : pv;
+                ds[gk][t][r] = pv * ((DROP ? dp[gk][r] * dm : dp[gk][r]) - dlv[r]);
+              }
+            }
+          }
+          bf16x8 pf[NG], dsf[NG];
+#pragma unroll
+          for (int gk = 0; gk < NG; ++gk) {
+            pf[gk] = pack8(p[gk][0], p[gk][1]);
+            dsf[gk] = pack8(ds[gk][0], ds[gk][1]);
+            const u32x4 w = __builtin_bit_cast(u32x4, dsf[gk]);
+            char* blk = smem + XP_DS + (2 * s) * OP_BLK + ((wave + 8 * gk) * 16 + fi) * 32 + g * 8;
+            *reinterpret_cast<u32x2*>(blk) = kok[gk] ? u32x2{w[0], w[1]} : u32x2{0u, 0u};
+            if (NTQ == 2) *reinterpret_cast<u32x2*>(blk + OP_BLK) = kok[gk] ? u32x2{w[2], w[3]} : u32x2{0u, 0u};
+          }
+#pragma unroll
+          for (int dt = 0; dt < 4; ++dt) {
+            const bf16x8 dotr = frag_cols(dotile, s, dt, lane), qtr = frag_cols(qtile, s, dt, lane);
+#pragma unroll
+            for (int gk = 0; gk < NG; ++gk) {
+              dv[gk][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dotr, pf[gk], dv[gk][dt], 0, 0, 0);
+              dk[gk][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qtr, dsf[gk], dk[gk][dt], 0, 0, 0);
+            }
+          }
+        };
+        for (int s = 0; s < (nvs >> 1); ++s) pair(s, std::true_type{});
+        if (nvs & 1) pair(nvs >> 1, std::false_type{});
+      };
+      if (ng == 2) phase_a(std::integral_constant<int, 2>{});
+      else if (ng == 1) phase_a(std::integral_constant<int, 1>{});
+      __syncthreads();
+      // ---- phase B: strip `wave` of the chunk
+      if (wave < nvs) {
+        f32x4 dq[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int r4 = fi >> 2, c4 = fi & 3;
+        for (int s = 0; s < ((nsk + 1) >> 1); ++s) {
+          const uint32_t a0 = lbase + XP_DS + wave * OP_BLK + (32 * s + 4 * g + r4) * 32 + c4 * 8;
+          const bf16x8 dsf = lds_read_tr_frag(a0, a0 + 16 * 32);
+#pragma unroll
+          for (int dt = 0; dt < 4; ++dt) dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_cols(ktile, s, dt, lane), dsf, dq[dt], 0, 0, 0);
+        }
+        const int slot = wave / sps, q = (wave - slot * sps) * 16 + fi;
+        if (q < a.Lq) {
+          const int b = sb_s[wave];
+          bf16_t* op = a.dQ + b * a.dq_bs + (long)q * a.dq_rs + h * HD + g * 4;
+#pragma unroll
+          for (int dt = 0; dt < 4; ++dt)
+            *reinterpret_cast<u32x2*>(op + dt * 16) = u32x2{pack_bf16(dq[dt][0] * a.scale, dq[dt][1] * a.scale),
+                                                             pack_bf16(dq[dt][2] * a.scale, dq[dt][3] * a.scale)};
+        }
+      }
+      __syncthreads();                 // the next chunk overwrites Q / dO / the per-strip tables, and phase A the dS blocks
+    }
+  }
+#pragma unroll
+  for (int gk = 0; gk < 2; ++gk) {
+    if (gk >= ng || !kok[gk]) continue;
+    bf16_t* kp = a.dK + bk * a.dk_bs + (long)key[gk] * a.dk_rs + h * HD + g * 4;
+    bf16_t* vp = a.dV + bk * a.dv_bs + (long)key[gk] * a.dv_rs + h * HD + g * 4;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      *reinterpret_cast<u32x2*>(kp + dt * 16) = u32x2{pack_bf16(dk[gk][dt][0] * a.scale, dk[gk][dt][1] * a.scale),
+                                                       pack_bf16(dk[gk][dt][2] * a.scale, dk[gk][dt][3] * a.scale)};
+      *reinterpret_cast<u32x2*>(vp + dt * 16) = u32x2{pack_bf16(dv[gk][dt][0], dv[gk][dt][1]), pack_bf16(dv[gk][dt][2], dv[gk][dt][3])};
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------ C ABI
 // `args` is the AttnArgs struct laid out as 8-byte slots (pointers, longs) followed by ints/floats;
 // the Python side fills it through ctypes.Structure with the same field order.
@@ -1340,6 +1573,20 @@ extern "C" int x2_attn_fwd(const AttnArgs* pa, void* stream) {
   return x2_check_launch("x2_attn_fwd");
 }
 
+// Which backward runs for these arguments: 0 = the dQ + dK/dV pair, 1 = attn_bwd_onepass_kernel (one sequence per K/V batch, 64 < Lq,
+// Lk <= 208, no probability dropout), 2 = attn_bwd_onepass_grouped_kernel (rows sharing K/V through the CSR, Lq <= 128, Lk <= 208, no
+// bias).  Only a phase-0 call can take the one-pass forms; x2_tune(14, 1) switches them off (A/B measurements, tests of both forms).
+static int attn_bwd_one_pass(const AttnArgs& a) {
+  if (a.phase != 0 || x2_tune_get(14) == 1 || a.Lk > OP_ROWS) return 0;
+  if ((a.do_rs % 8 | a.do_bs % 8 | a.o_rs % 8 | a.o_bs % 8) != 0) return 0;
+  if (!a.seq_off && !a.kv_idx && a.B == a.Bkv && a.Lq > 64 && a.Lq <= OP_ROWS && a.Lk > 64 && !a.drop.thr16) return 1;
+  if (a.seq_off && a.seq_ids && a.kv_idx && a.Lq <= XP_ROWS && !a.bias && !a.dS) return 2;
+  return 0;
+}
+// for callers that place the K/V-side half on another stream only when there is one (engine.py): 1 / 2 as above when a phase-0 call
+// with these arguments runs in one pass
+extern "C" int x2_attn_bwd_one_pass(const AttnArgs* pa) { AttnArgs a = *pa; a.phase = 0; return attn_bwd_one_pass(a); }
+
 extern "C" int x2_attn_bwd(const AttnArgs* pa, void* stream) {
   AttnArgs a = *pa;
   a.grid_nx = a.grid_ny = a.grid_nz = a.grid_map = 0;
@@ -1355,8 +1602,12 @@ extern "C" int x2_attn_bwd(const AttnArgs* pa, void* stream) {
   const hipStream_t st = (hipStream_t)stream;
   // one workgroup per (sequence, head) for the whole backward (attn_bwd_onepass_kernel): the BEiT-2 blocks at N = 197; x2_tune(14, 1)
   // keeps the dQ + dK/dV pair (A/B measurements, and the tests that compare the two forms)
-  if (a.phase == 0 && !a.seq_off && !a.kv_idx && a.B == a.Bkv && a.Lq > 64 && a.Lq <= OP_ROWS && a.Lk > 64 && a.Lk <= OP_ROWS &&
-      !a.drop.thr16 && (a.do_rs % 8 | a.do_bs % 8 | a.o_rs % 8 | a.o_bs % 8) == 0 && x2_tune_get(14) != 1) {
+  if (attn_bwd_one_pass(a) == 2) {
+    if (a.drop.thr16) hipLaunchKernelGGL((attn_bwd_onepass_grouped_kernel<true>), dim3(1, a.H, a.Bkv), dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((attn_bwd_onepass_grouped_kernel<false>), dim3(1, a.H, a.Bkv), dim3(512), 0, st, a);
+    return x2_check_launch("x2_attn_bwd(one pass, shared K/V)");
+  }
+  if (attn_bwd_one_pass(a) == 1) {
     if (bl2) attn_launch(attn_bwd_onepass_kernel<true>, a, 1, a.H, a.B, 512, xm, st);
     else attn_launch(attn_bwd_onepass_kernel<false>, a, 1, a.H, a.B, 512, xm, st);
     return x2_check_launch("x2_attn_bwd(one pass)");

@@ -341,6 +341,10 @@ SIDE = SideStream()
 # around its tail segment, where the GPU otherwise runs one 1.0-1.4-round launch of the M = 7680 chain at a time.
 AUX = SideStream()
 AUX.enabled = False
+# auto: the fork is skipped where the cross-attention backward runs in ONE pass (kernels.attn_bwd_form == 2: 30 text tokens on <= 208
+# image tokens) - dK / dV then come out of the kernel that forms dQ, nothing but one GEMM per layer is left for the second stream, and
+# the fork-free tail measured faster (profiles/r10c_*: 22.33 vs 22.40 ms per base step) while its graph replays as ONE launch
+AUX.auto = False
 
 
 def _begin_layer_backward():
@@ -784,7 +788,9 @@ class BertLayersFn(torch.autograd.Function):
         BertLayersFn.prepare_weights(p, meta["lo"], meta["hi"], meta["fusion_at"], cross)
         saved = []
         kv_ahead = {}
-        if cross and AUX.enabled:
+        use_aux = cross and AUX.enabled and not (AUX.auto and K.attn_bwd_form(L, enc.shape[1], shared_kv=meta.get("seq_off") is not None,
+                                                                               dropout=BertLayersFn._drop(meta, meta["hi"] - 1, 2)[0] != 0) == 2)
+        if use_aux:
             # every layer's K/V projection of the image tokens now, on the second stream: layer i waits for its event only
             for i in range(max(meta["lo"], meta["fusion_at"]), meta["hi"]):
                 c = "layer.%d.crossattention." % i
@@ -912,15 +918,18 @@ class BertLayersFn(torch.autograd.Function):
                 # the K/V side of this layer (dK / dV, then their input gradient into the image tokens) feeds the vision tower only:
                 # on the second stream when there is one.  Its readers inside this stage (bias sums, weight gradients) are either
                 # deferred past the stage's join (WGRAD_QUEUE) or wait for its event at the end of the layer (kv_done below).
-                aux = AUX.enabled
                 kv_done = None
 
-                def attn2(phase):
-                    K.attn_bwd(K.view3(q2, S, L), K.view3(kv, Bi, T, 0), K.view3(kv, Bi, T, Hd), K.view3(att2, S, L), K.view3(datt2, S, L),
-                               S, Bi, H, L, T, scale, lse2, delta2, K.view3(dq2, S, L), K.view3(dkv, Bi, T, 0), K.view3(dkv, Bi, T, Hd),
-                               mask=meta["enc_mask"], kv_idx=meta["kv_idx"], seq_off=meta["seq_off"], seq_ids=meta["seq_ids"],
-                               drop=BertLayersFn._drop(meta, i, 2), phase=phase)
-                attn2(1 if aux else 0)
+                def attn2(phase, ask_form=False):
+                    return K.attn_bwd(K.view3(q2, S, L), K.view3(kv, Bi, T, 0), K.view3(kv, Bi, T, Hd), K.view3(att2, S, L),
+                                      K.view3(datt2, S, L), S, Bi, H, L, T, scale, lse2, delta2, K.view3(dq2, S, L), K.view3(dkv, Bi, T, 0),
+                                      K.view3(dkv, Bi, T, Hd), mask=meta["enc_mask"], kv_idx=meta["kv_idx"], seq_off=meta["seq_off"],
+                                      seq_ids=meta["seq_ids"], drop=BertLayersFn._drop(meta, i, 2), phase=phase, ask_form=ask_form)
+                # one workgroup per (image, head) forms dQ, dK and dV in one pass where the library has that form: no dK / dV half is left
+                # for the second stream (only the K/V input gradient below)
+                one_pass = attn2(0, ask_form=True) != 0
+                aux = AUX.enabled and not (AUX.auto and one_pass)
+                attn2(1 if aux and not one_pass else 0)
                 _param_only(po, K.colsum_bf16, dq2, G["crossattention.self.query.bias"])
                 G.alias("crossattention.self.key.bias", G["c.kv_bias"][:Hd])
                 G.alias("crossattention.self.value.bias", G["c.kv_bias"][Hd:])
@@ -934,8 +943,9 @@ class BertLayersFn(torch.autograd.Function):
                     if first:
                         denc = torch.empty(Bi * T, Dv, device=dev, dtype=F32)       # one buffer, accumulated in place layer by layer
 
-                    def kv_side(attn2=attn2, dkv=dkv, wkvT=wkvT, first=first, denc=denc):
-                        attn2(2)
+                    def kv_side(attn2=attn2, dkv=dkv, wkvT=wkvT, first=first, denc=denc, one_pass=one_pass):
+                        if not one_pass:
+                            attn2(2)
                         K.gemm_nt(dkv, wkvT, resid=None if first else denc, out=denc)
                     kv_done = AUX.launch(kv_side, [q2, kv, att2, datt2, lse2, delta2, dq2, dkv, wkvT, denc])
                 else:

@@ -192,6 +192,9 @@ class SegmentedStep:
         # backward - so the fork is OFF by default when collectives are issued (X2_AUX_OVERLAP=1 forces it on, =0 off).
         env_aux = os.environ.get("X2_AUX_OVERLAP")
         self.aux_overlap = (env_aux == "1") if env_aux is not None else not self.coll
+        # left to itself the fork is also skipped where the cross-attention backward is one kernel (engine.AUX.auto): the base / video /
+        # region configurations; X2VLM-large (577 image tokens: two kernels, the K/V half on the second stream) keeps it
+        self.aux_auto = env_aux is None
         # bf16 payload for the gradient all-reduces (0.51 GB per step instead of 1.02 GB): the arena is cast to a static
         # bf16 buffer, averaged there, and written back to the fp32 arena on arrival.  Off by default (parity-tested at 2 and
         # 8 gloo ranks; never measured on xGMI): X2_GRAD_BF16=1
@@ -533,11 +536,11 @@ class SegmentedStep:
             self._gather()
         if mode != "replay":
             eng.WGRAD_QUEUE = [] if self.defer_tail_wgrad else None
-            eng.AUX.enabled, eng.AUX.only_from = self.aux_overlap, self.sA.cuda_stream
+            eng.AUX.enabled, eng.AUX.only_from, eng.AUX.auto = self.aux_overlap, self.sA.cuda_stream, self.aux_auto
         try:
             self._seg(mode, "F2", A, self._s_loss, pa)
         finally:
-            eng.AUX.enabled, eng.AUX.only_from = False, None
+            eng.AUX.enabled, eng.AUX.only_from, eng.AUX.auto = False, None, False
         if mode != "replay":
             self._queue, eng.WGRAD_QUEUE = eng.WGRAD_QUEUE, None
         Bs.wait_stream(A)

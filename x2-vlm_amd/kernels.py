@@ -6,6 +6,7 @@ import ctypes as C
 
 import torch
 
+from . import _lib
 from ._lib import AttnArgs, call, ptr, raw_stream
 
 BF16, F32 = torch.bfloat16, torch.float32
@@ -276,8 +277,25 @@ def attn_fwd(q, k, v, B, Bkv, H, Lq, Lk, scale, out, lse, **kw):
     call("x2_attn_fwd", C.byref(a))
 
 
-def attn_bwd(q, k, v, o, do, B, Bkv, H, Lq, Lk, scale, lse, delta, dq, dk, dv, dS=None, phase=0, **kw):
-    """phase: 0 both halves; 1 the dQ half (+ dS, delta); 2 the dK / dV half (needs the delta of a phase-1 call)."""
+def attn_bwd_form(Lq, Lk, shared_kv=False, dropout=False):
+    """Which backward x2_attn_bwd runs for this geometry (x2_attn_bwd_one_pass on an argument block with placeholder pointers - the
+    library reads sizes, strides and which pointers are null): 0 two kernels, 1 / 2 one pass.  For callers that decide BEFORE the
+    backward whether a second stream has anything to do (engine.BertLayersFn.forward: the K/V projections ahead of the layers)."""
+    a = AttnArgs()
+    a.B = a.Bkv = a.H = 1
+    a.Lq, a.Lk, a.head_dim, a.scale = Lq, Lk, 64, 0.125
+    for f in ("q_bs", "q_rs", "k_bs", "k_rs", "v_bs", "v_rs", "o_bs", "o_rs", "dq_bs", "dq_rs", "dk_bs", "dk_rs", "dv_bs", "dv_rs", "do_bs", "do_rs"):
+        setattr(a, f, 64)
+    if shared_kv:
+        a.kv_idx = a.seq_off = a.seq_ids = 8        # non-null, never dereferenced by the query
+    a.drop_thr16 = 1 if dropout else 0
+    return _lib.lib().x2_attn_bwd_one_pass(C.byref(a))
+
+
+def attn_bwd(q, k, v, o, do, B, Bkv, H, Lq, Lk, scale, lse, delta, dq, dk, dv, dS=None, phase=0, ask_form=False, **kw):
+    """phase: 0 both halves; 1 the dQ half (+ dS, delta); 2 the dK / dV half (needs the delta of a phase-1 call).
+    ask_form: launch nothing, return which backward a phase-0 call with these arguments runs (x2_attn_bwd_one_pass: 0 = the two
+    kernels, 1 / 2 = one pass) - a caller that would put the dK / dV half on a second stream has nothing to put there in one pass."""
     a = _attn_args(q, k, v, B, Bkv, H, Lq, Lk, scale, **kw)
     a.phase = phase
     a.O, a.o_bs, a.o_rs = o
@@ -289,6 +307,8 @@ def attn_bwd(q, k, v, o, do, B, Bkv, H, Lq, Lk, scale, lse, delta, dq, dk, dv, d
     if dS is not None:
         assert dS.dtype == BF16 and dS.is_contiguous() and dS.shape[:3] == (B, H, Lq)
         a.dS, a.ds_ld = dS.data_ptr(), dS.shape[3]
+    if ask_form:
+        return _lib.lib().x2_attn_bwd_one_pass(C.byref(a))
     call("x2_attn_bwd", C.byref(a))
 
 

@@ -116,6 +116,9 @@ class BertLayer(nn.Module):
         self.output = BertOutput(config)
 
 
+_IDENTITY_CSR = {}      # (rows, device) -> (kv_idx, seq_off, seq_ids) of the identity row -> image map
+
+
 class BertEncoder(nn.Module):
     def __init__(self, config):
         super().__init__()
@@ -142,6 +145,15 @@ class BertEncoder(nn.Module):
             meta["enc_mask"] = _key_mask(enc_atts, -1e9)
             if kv_idx is None:
                 assert Bi == S, "encoder batch %d != text batch %d and no kv_idx given" % (Bi, S)
+                if enc.is_cuda and K.attn_bwd_form(L, enc.shape[1], shared_kv=True) == 2:
+                    # one text row per image (predict_bbox: xvlm.py:905-915) as the identity sharing: the backward then runs as ONE
+                    # kernel per layer (attn_bwd_onepass_grouped_kernel, a workgroup per (image, head)) instead of the per-row dQ and
+                    # dK/dV kernels - and the tail segment needs no second stream (engine.AUX.auto)
+                    ident = _IDENTITY_CSR.get((S, enc.device))
+                    if ident is None:
+                        ar = torch.arange(S + 1, device=enc.device, dtype=torch.int32)
+                        ident = _IDENTITY_CSR[(S, enc.device)] = (ar[:S].contiguous(), ar, ar[:S].contiguous())
+                    meta.update(kv_idx=ident[0], seq_off=ident[1], seq_ids=ident[2])
             else:
                 kv = kv_idx.to(torch.int32).contiguous()
                 if kv.is_cuda:
