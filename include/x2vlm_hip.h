@@ -186,7 +186,8 @@ int x2_embed_bwd(const long* ids, const float* g, float* dword, float* dpos, flo
                  void* stream);
 /* torch.gather of sequences / masked positions (xbert.py:1588-1589, xvlm.py:866-884) and its backward */
 int x2_gather_rows(const float* src, const int* idx, float* dst, void* dst_bf16, int R, long len, void* stream);
-int x2_scatter_add_rows(const float* src, const int* idx, float* dst, int R, long len, void* stream);
+/* dst[d][:] = sum of src[r][:] over idx[r] == d, all D rows of dst written (zeros where nothing points); no atomics; R <= 8192 */
+int x2_scatter_rows(const float* src, const int* idx, float* dst, int R, int D, long len, void* stream);
 /* small fp32 linear with arbitrary strides: vision_proj / text_proj (xvlm.py:785-792), similarity matrices
  * (xvlm.py:807, 831-832), last layers of itm_head / bbox_head (xvlm.py:163-169) and their backward */
 int x2_linear_f32(const float* A, const float* B, float* C, const float* bias, const float* alpha_ptr, float alpha,

@@ -711,9 +711,17 @@ def test_embed_gather_linear_l2norm(K):
     src = rnd(6, 40, seed=6); idx = torch.tensor([3, 3, 0, 5], dtype=torch.int32)
     d32, d16 = K.gather_rows(src.to(dev), idx.to(dev), 40, want_bf16=True)
     assert torch.equal(d32.cpu(), src[idx.long()]) and torch.equal(d16.cpu(), bf(src[idx.long()]))
-    acc = torch.zeros(6, 40, device=dev)
-    K.scatter_add_rows(d32, idx.to(dev), acc, 40)
+    acc = K.scatter_rows(d32, idx.to(dev), 6, 40)                # every row written: rows nothing points at are zeros, not what was there
     assert relerr(acc, torch.zeros(6, 40).index_add_(0, idx.long(), src[idx.long()])) < 1e-6
+    assert float(acc[[1, 2, 4]].abs().max()) == 0.0
+    # the two shapes of the step: 256 sequences of 30 x 768 onto 128 (several per row, some rows none), 768 masked rows onto 1920
+    for R, Dn, ln in ((256, 128, 30 * 768), (768, 1920, 768), (5000, 37, 8)):
+        g_ = torch.Generator().manual_seed(R)
+        ix = torch.randint(0, Dn, (R,), generator=g_).to(torch.int32)
+        sr = torch.randn(R, ln, generator=g_)
+        got = K.scatter_rows(sr.to(dev), ix.to(dev), Dn, ln)
+        assert relerr(got, torch.zeros(Dn, ln).index_add_(0, ix.long(), sr)) < 1e-6
+        assert torch.equal(got, K.scatter_rows(sr.to(dev), ix.to(dev), Dn, ln))      # ascending-r sums: the same bits every time
     A, Bm, bias = rnd(70, 50, seed=7), rnd(30, 50, seed=8), rnd(30, seed=9)
     assert relerr(K.linear_f32(A.to(dev), Bm.to(dev), bias=bias.to(dev)), A @ Bm.t() + bias) < 1e-5
     assert relerr(K.linear_f32(A.t().contiguous().to(dev), Bm.t().contiguous().to(dev), transA=True, transB=True, alpha=0.5),

@@ -56,7 +56,7 @@ _SIGS = {
     "x2_embed_fwd": [P, P, P, P, P, I, I, I, P],
     "x2_embed_bwd": [P, P, P, P, P, I, I, I, P],
     "x2_gather_rows": [P, P, P, P, I, L, P],
-    "x2_scatter_add_rows": [P, P, P, I, L, P],
+    "x2_scatter_rows": [P, P, P, I, I, L, P],
     "x2_linear_f32": [P, P, P, P, P, F, I, I, I, L, L, L, L, L, I, I, P, P],
     "x2_l2norm": [P, P, P, I, I, I, P],
     "x2_ce_fwd": [P, L, P, I, I, P, P, P, P],

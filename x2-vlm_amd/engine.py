@@ -1219,6 +1219,5 @@ class GatherRowsFn(torch.autograd.Function):
     def backward(ctx, dy):
         (idx,) = ctx.saved_tensors
         row_len = dy[0].numel()
-        dst = torch.zeros(ctx.shape, device=dy.device, dtype=F32)
-        K.scatter_add_rows(dy.contiguous().view(idx.numel(), row_len), idx, dst.view(ctx.shape[0], row_len), row_len)
-        return dst, None
+        dst = K.scatter_rows(dy.contiguous().view(idx.numel(), row_len), idx, ctx.shape[0], row_len)
+        return dst.view(ctx.shape), None

@@ -526,9 +526,12 @@ def gather_rows(src, idx, row_len, want_f32=True, want_bf16=False):
     return dst, dstb
 
 
-def scatter_add_rows(src, idx, dst, row_len):
-    assert src.dtype == F32 and dst.dtype == F32 and src.is_contiguous() and dst.is_contiguous()
-    call("x2_scatter_add_rows", ptr(src), ptr(idx), ptr(dst), idx.numel(), row_len)
+def scatter_rows(src, idx, rows, row_len):
+    """-> dst [rows, row_len] fp32: dst[d] = sum of src[r] over idx[r] == d (zeros where nothing points): the gather's backward."""
+    assert src.dtype == F32 and src.is_contiguous() and idx.dtype == torch.int32 and src.numel() == idx.numel() * row_len
+    dst = torch.empty(rows, row_len, device=src.device, dtype=F32)
+    call("x2_scatter_rows", ptr(src), ptr(idx), ptr(dst), idx.numel(), rows, row_len)
+    return dst
 
 
 def linear_f32(A, B, *, bias=None, transA=False, transB=False, alpha=1.0, alpha_ptr=None, out=None, accumulate=False):
