@@ -222,6 +222,20 @@ class SegmentedStep:
             # (world > 1: quarters - the last stage's arenas are the only all-reduce that nothing can overlap)
             parts = 4 if world > 1 else 3
             vision_cuts = [int(c) for c in env.split(",") if c] if env is not None else [depth * i // parts for i in range(1, parts)]
+            # Round 5, one rank: where the vision blocks' attention backward is ONE kernel (64 < N <= 208 tokens) stream A's backward
+            # chain lost a fifth of its time (8.9 instead of 10.9 ms per base step) and ended 1.9 ms before stream B - which carries the
+            # text backward, the fusion stack's weight gradients AND the deferred vision weight gradients.  One cut at 3/4 of the depth
+            # (only the top quarter's weight gradients go to stream B) when the text side is heavy enough to be the longer stream: base
+            # 21.96 vs 22.27 ms per step; the video step (8 captions beside 64 frames) and X2VLM-large (N = 577) keep thirds
+            # (profiles/r11b_vision_cut_ab.txt)
+            if env is None and world == 1 and "image" in batch:
+                pe = getattr(model.vision_encoder, "patch_embed", None)
+                ntok = (pe.num_patches + 1) if pe is not None else 0
+                img = batch["image"]
+                nimg = img.shape[0] * (img.shape[1] if img.dim() == 5 else 1)
+                text_rows = 4 * batch["text_ids"].shape[0] * batch["text_ids"].shape[1]
+                if 64 < ntok <= 208 and 2 * text_rows >= nimg * ntok:
+                    vision_cuts = [depth * 3 // 4]
         self.vcuts = sorted(c for c in vision_cuts if 0 < c < depth)
         self.defer_vision_wgrad = os.environ.get("X2_SEG_VISION_WGRAD", "1") == "1"
         self.prefetch_casts = os.environ.get("X2_SEG_PREFETCH_CASTS", "1") == "1" and recast_weights
