@@ -152,7 +152,9 @@ class BertEncoder(nn.Module):
                     ident = _IDENTITY_CSR.get((S, enc.device))
                     if ident is None:
                         ar = torch.arange(S + 1, device=enc.device, dtype=torch.int32)
-                        ident = _IDENTITY_CSR[(S, enc.device)] = (ar[:S].contiguous(), ar, ar[:S].contiguous())
+                        ident = (ar[:S].contiguous(), ar, ar[:S].contiguous())
+                        if not torch.cuda.is_current_stream_capturing():      # a tensor born inside a capture belongs to that graph's pool
+                            _IDENTITY_CSR[(S, enc.device)] = ident
                     meta.update(kv_idx=ident[0], seq_off=ident[1], seq_ids=ident[2])
             else:
                 kv = kv_idx.to(torch.int32).contiguous()
