@@ -42,6 +42,28 @@ def test_attn_args_struct_matches_header_layout():
     assert lib.AttnArgs.drop_thr16.offset == 324 and lib.AttnArgs.dbg.offset == 336 and lib.AttnArgs.head_dim.offset == 340 and lib.AttnArgs.drop_epoch.offset == 344
 
 
+def test_attention_backward_form_rules():
+    """x2_attn_bwd_one_pass is a host-side query (no launch, pointers only tested for null): which geometries the one-pass backward
+    kernels take - the BEiT-2 blocks (one sequence per K/V batch, 64 < N <= 208, no probability dropout), the cross-attention of rows
+    sharing K/V (Lq <= 128 per sequence, Lk <= 208) - and that x2_tune(14, 1) switches both off."""
+    K = importlib.import_module("x2-vlm_amd.kernels")
+    h = importlib.import_module("x2-vlm_amd._lib").lib()
+    own = {(197, 197): 1, (208, 208): 1, (65, 65): 1, (150, 90): 1, (64, 64): 0, (30, 30): 0, (209, 209): 0, (577, 577): 0, (197, 60): 0}
+    for (lq, lk), form in own.items():
+        assert K.attn_bwd_form(lq, lk) == form, (lq, lk)
+        assert K.attn_bwd_form(lq, lk, dropout=True) == 0
+    shared = {(30, 197): 2, (8, 5): 2, (128, 208): 2, (60, 197): 2, (129, 197): 0, (30, 577): 0, (30, 209): 0}
+    for (lq, lk), form in shared.items():
+        assert K.attn_bwd_form(lq, lk, shared_kv=True) == form, (lq, lk)
+        assert K.attn_bwd_form(lq, lk, shared_kv=True, dropout=True) == form          # the shared-K/V kernel regenerates the masks
+    try:
+        assert h.x2_tune(14, 1) == 0
+        assert all(K.attn_bwd_form(lq, lk) == 0 for lq, lk in own) and all(K.attn_bwd_form(lq, lk, shared_kv=True) == 0 for lq, lk in shared)
+    finally:
+        h.x2_tune(14, 0)
+    assert h.x2_tune_get(14) == 0
+
+
 def test_argument_checks_fail_loudly_without_launching():
     lib = importlib.import_module("x2-vlm_amd._lib")
     h = lib.lib()
