@@ -12,12 +12,19 @@ lib.x2_probe_set_buffer.argtypes, lib.x2_probe_set_buffer.restype = [ctypes.c_vo
 dev = "cuda"
 NSET = 8
 SHAPES = [("vit qkv", 12608, 2304, 768), ("vit dqkv", 12608, 768, 2304), ("vit dfc1", 12608, 768, 3072)]
+if os.environ.get("ABL_SHAPES"):           # "M,N,K;M,N,K": other problem sizes (occupancy / cache-residency experiments)
+    SHAPES = [("custom", *[int(v) for v in t.split(",")]) for t in os.environ["ABL_SHAPES"].split(";")]
 VARIANTS = [("all three", 0), ("no DMA", 32), ("no reads", 64), ("no MFMA", 128), ("MFMA only", 32 + 64), ("reads only", 32 + 128), ("DMA only", 64 + 128)]
 for name, M, N, Kd in SHAPES:
-    As = [torch.randn(M, Kd, device=dev).bfloat16() for _ in range(NSET)]
-    W = (torch.randn(N, Kd, device=dev) / Kd ** 0.5).bfloat16()
+    PAD = int(os.environ.get("ABL_PAD", "0"))      # extra elements per operand row (leading dimension K + PAD): L2 channel mapping experiments
+    As = [torch.randn(M, Kd + PAD, device=dev).bfloat16()[:, :Kd] for _ in range(NSET)]
+    W = (torch.randn(N, Kd + PAD, device=dev) / Kd ** 0.5).bfloat16()[:, :Kd]
     outs = [torch.empty(M, N, device=dev, dtype=torch.bfloat16) for _ in range(NSET)]
-    lib.x2_tune(1, 3)
+    PP = int(os.environ.get("PP_H", "0"))          # 4 / 5 / 6: the ping-pong kernel at 32 x PP_H rows instead of gemm_nt256_kernel
+    if PP:
+        lib.x2_tune(15, PP)
+    else:
+        lib.x2_tune(1, 3)
     nbuf = torch.zeros(4096 * 4, device=dev, dtype=torch.int64)
     res = []
     for vname, bits in VARIANTS:
@@ -37,8 +44,8 @@ for name, M, N, Kd in SHAPES:
             mains.append(float((t[:, 2] - t[:, 1]).mean()))
             spans.append(float(t[:, 3].max() - t[:, 0].min()))
         res.append((vname, min(mains), min(spans)))
-    lib.x2_tune(2, 0); lib.x2_tune(1, 0)
+    lib.x2_tune(2, 0); lib.x2_tune(1, 0); lib.x2_tune(15, 0)
     steps = Kd // 64
-    print("%-10s M=%d N=%d K=%d (%d contraction steps per 160 x 256 tile; MFMA issue alone = %.2f us per step at 2.4 GHz)" % (name, M, N, Kd, steps, 1280 / 2400.0))
+    print("%-10s M=%d N=%d K=%d (%d contraction steps per tile; MFMA issue alone = %.2f us per step at 2.4 GHz)" % (name, M, N, Kd, steps, 1280 / 2400.0))
     for vname, m, sp in res:
         print("   %-12s main loop %6.2f us per tile = %5.2f us per step   launch %6.1f us" % (vname, m, m / steps, sp))

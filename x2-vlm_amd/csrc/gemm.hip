@@ -112,6 +112,29 @@ static __device__ unsigned long long* g_nt_probe = nullptr;
 #define NT_DBG(p, bit) false
 #define NT_STAMP(i) do { } while (0)
 #endif
+// One 32-row half of a wave tile into its staging rows (row-major, 68-float pitch).  Two accumulator shapes:
+//   f32x4 acc[TM][4]   - 16x16x32 MFMA tiles (C^T: a lane holds row lane & 15 and 4 consecutive columns at (lane >> 4) * 4 of each 16-column tile)
+//   f32x16 acc[TM/2][2] - 32x32x16 MFMA tiles (C^T: a lane holds row lane & 31 and, of each 32-column tile, the columns 8 g + 4 (lane >> 5) + 0..3, g < 4)
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+template <int TM>
+__device__ __forceinline__ void epi_stage_half(f32x4 (&acc)[TM][4], int half, bool full, float* stg, int lane) {
+  const int frow = lane & 15, fg = lane >> 4;
+#pragma unroll
+  for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (full || ii == 0) *reinterpret_cast<f32x4*>(stg + (ii * 16 + frow) * 68 + j * 16 + fg * 4) = acc[full ? half * 2 + ii : half * 2][j];
+}
+template <int RT>
+__device__ __forceinline__ void epi_stage_half(f32x16 (&acc)[RT][2], int half, bool, float* stg, int lane) {
+  const int row = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      *reinterpret_cast<f32x4*>(stg + row * 68 + tj * 32 + g * 8 + h * 4) =
+          f32x4{acc[half][tj][4 * g], acc[half][tj][4 * g + 1], acc[half][tj][4 * g + 2], acc[half][tj][4 * g + 3]};
+}
 template <int V> struct EpiTraits {
   static constexpr bool generic = V == 4;
   static constexpr int act = V == 2 ? 1 : (V == 3 || V == 10) ? 2 : 0;
@@ -123,8 +146,8 @@ template <int V> struct EpiTraits {
   static constexpr bool colsum = false;
   static constexpr bool colparts = V == 10;       // column sums of the stored values as one partial row per wave row (no atomics)
 };
-template <int TM, int VAR>
-__device__ __forceinline__ void nt_epilogue(const GemmNT& p, f32x4 (&acc)[TM][4], char* smem, int wave, int lane, int mw0, int nw0, int prow = 0) {
+template <int TM, int VAR, class Acc>
+__device__ __forceinline__ void nt_epilogue(const GemmNT& p, Acc& acc, char* smem, int wave, int lane, int mw0, int nw0, int prow = 0) {
   using E = EpiTraits<VAR>;
   const int act = E::generic ? p.act : E::act;
   const bool out_f32 = E::generic ? p.out_f32 != 0 : E::out_f32;
@@ -133,7 +156,6 @@ __device__ __forceinline__ void nt_epilogue(const GemmNT& p, f32x4 (&acc)[TM][4]
   const bool has_aux0 = E::generic ? (p.act == 0 && p.aux != nullptr) : E::aux0;
   const bool has_drop = (E::generic || E::drop) ? p.drop.thr16 != 0 : false;
   const bool has_colsum = E::generic ? p.colsum != nullptr : (E::colsum && p.colsum != nullptr);
-  const int frow = lane & 15, fg = lane >> 4;
   float* stg = reinterpret_cast<float*>(smem) + wave * (32 * 68);
   // read-back: 8 lanes x 8 columns cover one 64-column row (32-byte fp32 reads, 16-byte bf16 / 2 x 16-byte fp32 stores),
   // 8 rows per instruction: half the store instructions of a 4-column mapping (the tail is store-issue bound)
@@ -178,11 +200,7 @@ __device__ __forceinline__ void nt_epilogue(const GemmNT& p, f32x4 (&acc)[TM][4]
         pre[rr] = *reinterpret_cast<const u32x4*>(p.aux + (size_t)mc * p.ldaux + nc);
       }
     }
-#pragma unroll
-    for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (full || ii == 0) *reinterpret_cast<f32x4*>(stg + (ii * 16 + frow) * 68 + j * 16 + fg * 4) = acc[full ? half * 2 + ii : half * 2][j];
+    epi_stage_half(acc, half, full, stg, lane);
     // same-wave LDS traffic only: no barrier, the compiler's lgkmcnt wait orders write -> read
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
@@ -282,12 +300,11 @@ __device__ __forceinline__ void nt_epilogue(const GemmNT& p, f32x4 (&acc)[TM][4]
 // pieces interleave at a 32-byte stride: every store instruction half-fills 16 lines (8 rows x 2).  Here a lane takes 4
 // columns of TWO rows (r and r + 4): a store instruction writes 4 rows x 256 contiguous bytes = 8 full lines; the residual
 // is loaded the same way.  Feature sets 1, 5, 6 (the fp32-out ones), same arithmetic.
-template <int TM, int VAR>
-__device__ __forceinline__ void nt_epilogue_f4(const GemmNT& p, f32x4 (&acc)[TM][4], char* smem, int wave, int lane, int mw0, int nw0) {
+template <int TM, int VAR, class Acc>
+__device__ __forceinline__ void nt_epilogue_f4(const GemmNT& p, Acc& acc, char* smem, int wave, int lane, int mw0, int nw0) {
   using E = EpiTraits<VAR>;
   static_assert(!E::generic && E::out_f32 && E::act == 0 && VAR <= 6, "nt_epilogue_f4: feature sets 1, 5, 6");
   const bool has_drop = E::drop ? p.drop.thr16 != 0 : false;
-  const int frow = lane & 15, fg = lane >> 4;
   float* stg = reinterpret_cast<float*>(smem) + wave * (32 * 68);
   const int er = lane >> 4, ec = (lane & 15) * 4;          // rows er and er + 4 of every 8-row group, 4 columns
   const int n = nw0 + ec;
@@ -312,11 +329,7 @@ __device__ __forceinline__ void nt_epilogue_f4(const GemmNT& p, f32x4 (&acc)[TM]
         }
       }
     }
-#pragma unroll
-    for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (full || ii == 0) *reinterpret_cast<f32x4*>(stg + (ii * 16 + frow) * 68 + j * 16 + fg * 4) = acc[full ? half * 2 + ii : half * 2][j];
+    epi_stage_half(acc, half, full, stg, lane);
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
       if (!full && rr >= 2) continue;
@@ -825,6 +838,244 @@ __global__ __launch_bounds__(512) void gemm_nt256s3_kernel(GemmNT p) {
   nt_epilogue<TMW, VAR>(p, acc, smem, wave, lane, m0 + wr * HROWS, n0 + wc * 64);
 }
 
+// ---------------------------------------------------------------------------------------------
+// NT, 256-column tiles, "ping-pong" schedule on 32x32x16 MFMAs (round 6).  The kernels above run their eight waves in lockstep: every
+// wave reads fragments, then every wave multiplies, so on each SIMD the matrix pipe and the LDS / DMA issue take turns (46 % MFMA issue
+// inside the loop, profiles/r09b).  Here the two waves that share a SIMD (wave w and w + 4) work in opposite segments of a contraction
+// step: while the waves of row 0 multiply, the waves of row 1 fetch their fragments and request operand tiles, and vice versa - one
+// barrier between segments, the row-1 waves one barrier behind for the whole tile.  A segment holds ALL MFMAs of one contraction step
+// of the wave (RT x 2 tiles of 32x32 x 4 k-slices of 16: 16-24 instructions of 32 cycles = 512-768 matrix-pipe cycles, issued under
+// s_setprio 1 with nothing between them), so the pipe sees back-to-back MFMAs from alternating waves and everything else is issued in
+// the partner's shadow.  The 32x32x16 form halves the MFMA count per flop (half the issue slots) at the same fragment bytes.
+//   Tile: 32 (RT0 + RT1) rows x 256 columns; wave row 0 owns RT0 32-row tiles, wave row 1 RT1 (RT0 <= RT1: the 160-row tile is 2 + 3 -
+//   the pipe is time-shared, so unequal halves cost nothing as long as each fetch segment fits in the partner's multiply segment;
+//   row 0 runs first and requests the larger B tiles during row 1's longer multiply segment); wave column c owns columns 64 c .. + 63.
+//   LDS: 2 stages x {A0 (RT0 x 4 KB), A1 (RT1 x 4 KB), B0, B1 (16 KB each)}, images [rows][64 k] with chunk c (16 B) of row r at
+//   position c ^ ((r >> 1) & 7): conflict-free ds_read_b128 for the 32-row fragment (lanes = rows r .. r + 31 of ONE chunk).
+//   DMA: buffer_load ... lds through buffer descriptors (rows past M / N read zeros: no clamping, one 32-bit offset per request).
+//   Row 0 (phases 2t: fetch, 2t + 1: multiply) requests B(t + 1) at the head of its fetch segment and waits for it behind its multiply
+//   segment; row 1 (phases 2t + 1, 2t + 2) requests A1(t + 1) and A0(t + 2) and waits for A0(t + 1) behind its fetch segment, for
+//   A1(t + 1) behind its multiply segment: every request has >= one multiply segment (>= 512 cycles) + most of a fetch segment to land.
+// Epilogue: nt_epilogue / nt_epilogue_f4 through the f32x16 staging overload.
+// ---------------------------------------------------------------------------------------------
+#define PP_BHALF 16384
+#ifndef PP_MODE
+#define PP_MODE 1
+#endif
+#include <utility>
+template <class F, int... I> __device__ __forceinline__ void pp_static_for(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N_> __device__ __forceinline__ void pp_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory"); }
+template <int RT0, int RT1, int VAR, int NST>
+__global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmNT p) {
+  constexpr int BMT = 32 * (RT0 + RT1);
+  constexpr int A0_BYTES = RT0 * 4096, A1_BYTES = RT1 * 4096, STAGE = A0_BYTES + A1_BYTES + 2 * PP_BHALF;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int tiles_n = (p.N + 255) / 256, tiles_m = (p.M + BMT - 1) / BMT;
+  int tm, tn;
+  tile_coords(xcd_remap(blockIdx.x, gridDim.x), tiles_m, tiles_n, p.group_m, tm, tn);
+  const int m0 = tm * BMT, n0 = tn * 256;
+  const uint32_t lds0 = lds_addr(smem);
+  // this lane's chunk of a DMA request: LDS image is lane-linear, request q of a region covers rows 32 q + 8 wc + (lane >> 3)
+  const int drow = wc * 8 + (lane >> 3), dchunk = (lane & 7) ^ ((wc & 1) * 4 + (lane >> 4));
+  // fragment address pieces: row (lane & 31) of a 32-row tile, k-slice ks -> chunk (2 ks + (lane >> 5)) ^ swizzle(row)
+  uint32_t foff[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) foff[ks] = (uint32_t)((lane & 31) * 128 + (((ks * 2 + (lane >> 5)) ^ ((lane >> 1) & 7)) << 4));
+  const uint32_t boff = (uint32_t)(A0_BYTES + A1_BYTES + (wc >> 1) * PP_BHALF + (wc & 1) * 8192);
+  const int nk = p.K / BK;
+  NT_ABL_DECL(p);
+  NT_STAMP(0);
+  constexpr int pp_mode = PP_MODE;                   // where the operand requests are issued (compile-time: a run-time choice spills): 0 between the MFMAs, 1 one burst ahead of the reads, 2 between the reads
+
+  auto run = [&](auto rt_, auto first_) {
+    constexpr int RT = decltype(rt_)::value;
+    constexpr bool FIRST = decltype(first_)::value;
+    const uint32_t aoff = FIRST ? 0u : (uint32_t)A0_BYTES;
+    f32x16 acc[RT][2];
+#pragma unroll
+    for (int i = 0; i < RT; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    bf16x8 fa[RT][4], fb[2][4];
+    // operand requests.  Row 0 owns B (two halves of 128 weight rows), row 1 owns A (both row groups)
+    const __amdgpu_buffer_rsrc_t rs = FIRST
+        ? __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, (int)(((size_t)(p.N - 1) * p.ldb + p.K) * 2), 0x00020000)
+        : __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)(((size_t)(p.M - 1) * p.lda + p.K) * 2), 0x00020000);
+    const int ld = FIRST ? p.ldb : p.lda;
+    const uint32_t v0 = (uint32_t)(((size_t)((FIRST ? n0 : m0) + drow) * ld + dchunk * 8) * 2);     // row `drow` of the tile
+    const uint32_t step32 = (uint32_t)ld * 64u;                                                     // 32 rows further, bytes
+    auto dma = [&](int kt, int stage, int region_bytes_off, int row32_first, auto count_) {        // `count` requests of 32 rows each
+      constexpr int CNT = decltype(count_)::value;
+      NT_ABL_NO_DMA(kt + 1);
+#pragma unroll
+      for (int q = 0; q < CNT; ++q)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(smem + stage * STAGE + region_bytes_off + q * 4096 + wc * 1024),
+                                                 16, v0 + (uint32_t)(row32_first + q) * step32, kt * 128, 0, 0);
+    };
+    using C4 = std::integral_constant<int, 4>; using CR0 = std::integral_constant<int, RT0>; using CR1 = std::integral_constant<int, RT1>;
+    auto reads = [&](uint32_t sb) {
+      NT_ABL_NO_READ();
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) fb[j][ks] = lds_read_b128(sb + boff + foff[ks] + j * 4096);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int i = 0; i < RT; ++i) fa[i][ks] = lds_read_b128(sb + aoff + foff[ks] + i * 4096);
+    };
+    auto mfmas = [&]() {
+      NT_ABL_NO_MFMA();
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int i = 0; i < RT; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            // operands swapped: the accumulator tile is C^T (a lane holds m = lane & 31 and 4 x 4 consecutive n)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j][ks], fa[i][ks], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+    };
+#define PP_FENCE() __builtin_amdgcn_sched_barrier(0)
+#define PP_BARRIER() do { PP_FENCE(); asm volatile("s_barrier" ::: "memory"); PP_FENCE(); } while (0)
+    if constexpr (NST == 3) {
+      // Three whole stages (tile heights whose 3 stages fit 160 KB): every region of step t + 2 is requested in step t's fetch segment, into
+      // the stage read in step t - 1.  Row 0 waits for B(t + 1) behind its multiply segment of step t (requested two steps = four segments
+      // earlier), row 1 for A(t + 1) behind its fetch segment of step t (three segments): an unloaded request takes ~0.5 us, a step ~0.8.
+      constexpr int MINE = FIRST ? 8 : RT0 + RT1;        // requests of this wave per step
+      auto request = [&](int kt, int stage) {
+        if constexpr (FIRST) { dma(kt, stage, A0_BYTES + A1_BYTES, 0, C4{}); dma(kt, stage, A0_BYTES + A1_BYTES + PP_BHALF, 4, C4{}); }
+        else { dma(kt, stage, 0, 0, CR0{}); dma(kt, stage, A0_BYTES, RT0, CR1{}); }
+      };
+      // one step's fragment reads with this wave's MINE requests spread evenly between them: a request stalls the wave while the
+      // texture path's queue is full (4 waves x MINE requests arrive at once), and reads issued BEHIND such a burst wait for all of it
+      constexpr int NR = 8 + 4 * RT;
+      auto fetch = [&](uint32_t sb, bool more, int kt, int stage) {
+        pp_static_for([&](auto idx_) {
+          constexpr int idx = decltype(idx_)::value;
+          {
+            if constexpr (idx < 8) fb[idx & 1][idx >> 1] = lds_read_b128(sb + boff + foff[idx >> 1] + (idx & 1) * 4096);
+            else fa[(idx - 8) % RT][(idx - 8) / RT] = lds_read_b128(sb + aoff + foff[(idx - 8) / RT] + ((idx - 8) % RT) * 4096);
+          }
+          if constexpr ((idx + 1) * MINE / NR > idx * MINE / NR) {
+            constexpr int q = idx * MINE / NR;             // request q of the step: 32 rows of this row's operand (B for row 0, A for row 1)
+            if (more) {
+              __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(smem + stage * STAGE + (FIRST ? A0_BYTES + A1_BYTES : 0) + q * 4096 + wc * 1024),
+                                                       16, v0 + (uint32_t)q * step32, kt * 128, 0, 0);
+            }
+            PP_FENCE();
+          }
+        }, std::make_integer_sequence<int, NR>{});
+      };
+      // the same requests spread between the MFMAs of the multiply segment instead (one every NM / MINE instructions)
+      constexpr int NM = 8 * RT;
+      auto mfmas_dma = [&](bool more, int kt, int stage) {
+        __builtin_amdgcn_s_setprio(1);
+        pp_static_for([&](auto idx_) {
+          constexpr int idx = decltype(idx_)::value, ks = idx / (2 * RT), i = (idx % (2 * RT)) / 2, j = idx & 1;
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j][ks], fa[i][ks], acc[i][j], 0, 0, 0);
+          if constexpr ((idx + 1) * MINE / NM > idx * MINE / NM) {
+            constexpr int q = idx * MINE / NM;
+            if (more)
+              __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(smem + stage * STAGE + (FIRST ? A0_BYTES + A1_BYTES : 0) + q * 4096 + wc * 1024),
+                                                       16, v0 + (uint32_t)q * step32, kt * 128, 0, 0);
+            PP_FENCE();
+          }
+        }, std::make_integer_sequence<int, NM>{});
+        __builtin_amdgcn_s_setprio(0);
+      };
+      request(0, 0);
+      if (!FIRST && pp_mode == 0 && nk > 2) { request(1, 1); request(2, 2); pp_wait_vm<2 * MINE>(); }   // row 1 requests THREE steps ahead (below)
+      else if (nk > 1) { request(1, 1); pp_wait_vm<MINE>(); } else pp_wait_vm<0>();
+      PP_BARRIER();
+      if constexpr (!FIRST) PP_BARRIER();               // row 1 runs one segment behind
+      NT_STAMP(1);
+      int rs = 0, ws = 2;
+      for (int t = 0; t < nk; ++t) {
+        const uint32_t sb = lds0 + (uint32_t)(rs * STAGE);
+        NT_ABL_STEP(t);
+        const bool more = t + 2 < nk;
+        if constexpr (pp_mode == 1) { if (more) request(t + 2, ws); reads(sb); }
+        else if constexpr (pp_mode == 2) fetch(sb, more, t + 2, ws);
+        else reads(sb);
+        PP_FENCE();
+        if constexpr (!FIRST) { if (more) pp_wait_vm<MINE>(); else pp_wait_vm<0>(); }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        PP_BARRIER();
+        // mode 0: requests between the MFMAs.  Row 0 (multiplying in phase 2t + 1) requests B(t + 2) into the stage read in step t - 1; row 1
+        // (phase 2t + 2: BOTH rows are done with stage t) requests A(t + 3) into the stage it has just read
+        if constexpr (pp_mode == 0) { if constexpr (FIRST) mfmas_dma(more, t + 2, ws); else mfmas_dma(t + 3 < nk, t + 3, rs); }
+        else mfmas();
+        PP_FENCE();
+        if constexpr (FIRST) { if (more) pp_wait_vm<MINE>(); else pp_wait_vm<0>(); }
+        PP_BARRIER();
+        rs = rs == 2 ? 0 : rs + 1;
+        ws = ws == 2 ? 0 : ws + 1;
+      }
+    } else {
+      // prologue: step 0 complete in LDS (row 1 also has A0 of step 1 under way)
+      if constexpr (FIRST) {
+        dma(0, 0, A0_BYTES + A1_BYTES, 0, C4{}); dma(0, 0, A0_BYTES + A1_BYTES + PP_BHALF, 4, C4{});
+        pp_wait_vm<0>();
+      } else {
+        dma(0, 0, A0_BYTES, RT0, CR1{}); dma(0, 0, 0, 0, CR0{});
+        if (nk > 1) { dma(1, 1, 0, 0, CR0{}); pp_wait_vm<RT0>(); } else pp_wait_vm<0>();
+      }
+      PP_BARRIER();
+      if constexpr (!FIRST) PP_BARRIER();                 // row 1 runs one segment behind
+      NT_STAMP(1);
+      for (int t = 0; t < nk; ++t) {
+        const int s_ = t & 1;
+        const uint32_t sb = lds0 + (uint32_t)(s_ * STAGE);
+        NT_ABL_STEP(t);
+        if constexpr (FIRST) {
+          if (t + 1 < nk) { dma(t + 1, s_ ^ 1, A0_BYTES + A1_BYTES, 0, C4{}); dma(t + 1, s_ ^ 1, A0_BYTES + A1_BYTES + PP_BHALF, 4, C4{}); }
+          reads(sb);
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          PP_BARRIER();
+          mfmas();
+          PP_FENCE();
+          pp_wait_vm<0>();
+          PP_BARRIER();
+        } else {
+          int mode = 0;                                    // what this segment requested: 2 = A1(t+1) and A0(t+2), 1 = A1(t+1), 0 = nothing
+          if (t + 2 < nk) { dma(t + 1, s_ ^ 1, A0_BYTES, RT0, CR1{}); dma(t + 2, s_, 0, 0, CR0{}); mode = 2; }
+          else if (t + 1 < nk) { dma(t + 1, s_ ^ 1, A0_BYTES, RT0, CR1{}); mode = 1; }
+          reads(sb);
+          PP_FENCE();
+          // A0(t+1), requested one fetch segment ago, has landed: everything but this segment's requests
+          if (mode == 2) pp_wait_vm<RT0 + RT1>(); else if (mode == 1) pp_wait_vm<RT1>(); else pp_wait_vm<0>();
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          PP_BARRIER();
+          mfmas();
+          PP_FENCE();
+          if (mode == 2) pp_wait_vm<RT0>(); else pp_wait_vm<0>();      // A1(t+1) has landed; A0(t+2) may still be in flight
+          PP_BARRIER();
+        }
+      }
+    }
+    if constexpr (FIRST) PP_BARRIER();                  // row 1's last multiply segment: afterwards nobody reads operand tiles
+    NT_STAMP(2);
+#undef PP_BARRIER
+#undef PP_FENCE
+    const int mw0 = m0 + (FIRST ? 0 : RT0 * 32), nw0 = n0 + wc * 64;
+    if constexpr (EpiTraits<VAR>::out_f32 && VAR <= 6) nt_epilogue_f4<2 * RT, VAR>(p, acc, smem, wave, lane, mw0, nw0);
+    else nt_epilogue<2 * RT, VAR>(p, acc, smem, wave, lane, mw0, nw0);
+#ifdef X2_PROBE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    NT_STAMP(3);
+#endif
+  };
+  if (wr == 0) run(std::integral_constant<int, RT0>{}, std::true_type{});
+  else run(std::integral_constant<int, RT1>{}, std::false_type{});
+}
+
 // knobs for A/B measurements and for the tests that pin a kernel variant (0 = automatic everywhere)
 //   [0] GROUP_M of the NT tile raster            [1] 0: automatic, 1: 128-column kernels only, 3: always the 256-column kernel
 //   [2] NT ablation bits (4 no epilogue, 16 sc1 stores): -DX2_PROBE builds only, refused by the shipped library
@@ -841,6 +1092,7 @@ static int g_tune[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 //   [11] 1: the rounds 3-4 rule for choosing the 256-column kernel (no fp32 + residual launches below K = 2048, no GELU launches)
 //   [13] LayerNorm forward rows per wave (rowwise.hip): 0 automatic, 1 / 2 / 4
 //   [14] 1: attention backward always as the dQ + dK/dV pair (attention.hip: no one-pass kernel at 64 < L <= 208)
+//   [15] ping-pong NT kernel (gemm_nt_pp_kernel): 0 automatic, 1 never, 3 .. 6 always at 96 / 128 / 160 / 192 rows
 static int g_tune_x[8] = {0, 0, 0, 0, 0, 0, 0, 0};       // keys 8.. : [1] = key 9, [4] = key 12
 extern "C" int x2_device_cus(void);
 // compute units of the current device (256 on MI355X), asked once: grid-fill decisions below are made in units of it
@@ -923,6 +1175,29 @@ static void launch_nt256_h(const GemmNT& p, int tmw, hipStream_t stream) {
   }
 }
 
+// ping-pong kernel: height h = 4 / 5 / 6 32-row tiles (128 / 160 / 192 rows), split over the two wave rows as 2+2 / 2+3 / 3+3
+template <int RT0, int RT1, int V, int NST>
+static void launch_nt_pp(const GemmNT& p, hipStream_t stream) {
+  constexpr int lds = NST * ((RT0 + RT1) * 4096 + 2 * PP_BHALF);
+  static bool raised = false;
+  if (!raised) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_pp_kernel<RT0, RT1, V, NST>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    raised = true;
+  }
+  constexpr int BMT = 32 * (RT0 + RT1);
+  const int tiles = ((p.M + BMT - 1) / BMT) * ((p.N + 255) / 256);
+  hipLaunchKernelGGL((gemm_nt_pp_kernel<RT0, RT1, V, NST>), dim3(tiles), dim3(512), lds, stream, p);
+}
+template <int V>
+static void launch_nt_pp_h(const GemmNT& p, int h, hipStream_t stream) {
+  switch (h) {
+    case 3: launch_nt_pp<1, 2, V, 3>(p, stream); break;
+    case 4: if (g_tune_x[2] == 1) launch_nt_pp<2, 2, V, 2>(p, stream); else launch_nt_pp<2, 2, V, 3>(p, stream); break;
+    case 5: if (g_tune_x[2] == 1) launch_nt_pp<2, 3, V, 2>(p, stream); else launch_nt_pp<2, 3, V, 3>(p, stream); break;
+    default: launch_nt_pp<3, 3, V, 2>(p, stream); break;
+  }
+}
+
 // one NT launch: LDS = two stages of a (32 * TM) x 64 A tile + a 128 x 64 B tile; above 64 KB the limit is raised once
 template <int TM, int V, bool F4>
 static void launch_nt(const GemmNT& p, int tiles, hipStream_t stream) {
@@ -980,6 +1255,31 @@ extern "C" int x2_gemm_nt(const void* A, const void* B, void* C, int M, int N, i
     if (var == 2 && eff256 * 100.0 >= 90.0) auto256 = true;
   }
   const bool use256 = var != 4 && N % 8 == 0 && (g_tune[1] == 3 || ((g_tune[1] == 0 || g_tune[1] == 4) && g_tune[3] == 0 && auto256));
+  // Ping-pong kernel (gemm_nt_pp_kernel).  x2_tune(15, h), h = 3 .. 6: always, at 32 h rows (probes); 1: never; 0: automatic - the launches the 128-column kernels
+  // serve worst: a long contraction (K >= 2048) over few output tiles (the fusion stack's ffn2 forward and ffn1 input gradient, M = 7680 x N = 768: 180 tiles of
+  // 128 x 128, 48 serial steps each, 54-61 us), where ONE round of 96- or 128-row x 256-column tiles fills >= 70 % of the CUs: 44-50 us (profiles/r12a_nt_pp_tail.txt).
+  // Same sums in the same order as every other NT kernel (bit-identical results: probes/bench_nt_pp.py).  Operands must be addressable through a 2 GB descriptor.
+  const bool pp_ok = var != 4 && ((size_t)(M - 1) * lda + K) * 2 < (1ull << 31) && ((size_t)(N - 1) * ldb + K) * 2 < (1ull << 31);
+  int pp_h = 0;
+  if (g_tune_x[7] >= 3 && g_tune_x[7] <= 6) pp_h = g_tune_x[7];
+  else if (g_tune_x[7] == 0 && g_tune[1] == 0 && g_tune[3] == 0 && !use256 && K >= 2048 && (var == 0 || var == 1 || var == 5)) {
+    const int cus = x2_cus(), tn256 = (N + 255) / 256;
+    for (int h = 3; h <= 4 && !pp_h; ++h) {
+      const int tiles = ((M + 32 * h - 1) / (32 * h)) * tn256;
+      if (tiles <= cus && tiles * 10 >= cus * 7) pp_h = h;
+    }
+  }
+  if (pp_ok && pp_h) {
+    switch (var) {
+      case 0: launch_nt_pp_h<0>(p, pp_h, (hipStream_t)stream); break;
+      case 1: launch_nt_pp_h<1>(p, pp_h, (hipStream_t)stream); break;
+      case 2: launch_nt_pp_h<2>(p, pp_h, (hipStream_t)stream); break;
+      case 3: launch_nt_pp_h<3>(p, pp_h, (hipStream_t)stream); break;
+      case 5: launch_nt_pp_h<5>(p, pp_h, (hipStream_t)stream); break;
+      default: launch_nt_pp_h<6>(p, pp_h, (hipStream_t)stream); break;
+    }
+    return x2_check_launch("x2_gemm_nt");
+  }
   if (use256) {
     switch (var) {
       case 0: launch_nt256_h<0>(p, tmw, (hipStream_t)stream); break;
