@@ -19,6 +19,8 @@ for name, M, N, Kd in SHAPES:
     PAD = int(os.environ.get("ABL_PAD", "0"))      # extra elements per operand row (leading dimension K + PAD): L2 channel mapping experiments
     As = [torch.randn(M, Kd + PAD, device=dev).bfloat16()[:, :Kd] for _ in range(NSET)]
     W = (torch.randn(N, Kd + PAD, device=dev) / Kd ** 0.5).bfloat16()[:, :Kd]
+    if os.environ.get("ABL_A_ALIAS"):          # every row of A is the SAME 2 K bytes (row stride 0): the A tile never leaves L2 - what does its first-touch traffic cost the operand DMA?
+        As = [torch.randn(1, Kd, device=dev).bfloat16().expand(M, Kd) for _ in range(NSET)]
     outs = [torch.empty(M, N, device=dev, dtype=torch.bfloat16) for _ in range(NSET)]
     PP = int(os.environ.get("PP_H", "0"))          # 4 / 5 / 6: the ping-pong kernel at 32 x PP_H rows instead of gemm_nt256_kernel
     if PP:

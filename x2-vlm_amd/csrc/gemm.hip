@@ -859,11 +859,6 @@ __global__ __launch_bounds__(512) void gemm_nt256s3_kernel(GemmNT p) {
 // Epilogue: nt_epilogue / nt_epilogue_f4 through the f32x16 staging overload.
 // ---------------------------------------------------------------------------------------------
 #define PP_BHALF 16384
-#ifndef PP_MODE
-#define PP_MODE 1
-#endif
-#include <utility>
-template <class F, int... I> __device__ __forceinline__ void pp_static_for(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
 template <int N_> __device__ __forceinline__ void pp_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory"); }
 template <int RT0, int RT1, int VAR, int NST>
 __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmNT p) {
@@ -888,7 +883,6 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmNT p) {
   const int nk = p.K / BK;
   NT_ABL_DECL(p);
   NT_STAMP(0);
-  constexpr int pp_mode = PP_MODE;                   // where the operand requests are issued (compile-time: a run-time choice spills): 0 between the MFMAs, 1 one burst ahead of the reads, 2 between the reads
 
   auto run = [&](auto rt_, auto first_) {
     constexpr int RT = decltype(rt_)::value;
@@ -945,54 +939,18 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmNT p) {
 #define PP_FENCE() __builtin_amdgcn_sched_barrier(0)
 #define PP_BARRIER() do { PP_FENCE(); asm volatile("s_barrier" ::: "memory"); PP_FENCE(); } while (0)
     if constexpr (NST == 3) {
-      // Three whole stages (tile heights whose 3 stages fit 160 KB): every region of step t + 2 is requested in step t's fetch segment, into
+      // Three whole stages (tile heights whose 3 stages fit 160 KB): every region of step t + 2 is requested at the head of step t's fetch segment, into
       // the stage read in step t - 1.  Row 0 waits for B(t + 1) behind its multiply segment of step t (requested two steps = four segments
-      // earlier), row 1 for A(t + 1) behind its fetch segment of step t (three segments): an unloaded request takes ~0.5 us, a step ~0.8.
+      // earlier), row 1 for A(t + 1) behind its fetch segment of step t (three segments).  Measured and NOT kept (profiles/r12a_nt_pp_per_shape.txt (3),
+      // r12b_nt_pp_prefetch.txt; code at commit f9489e1): the requests spread between the fragment reads or between the MFMAs instead of one burst
+      // (+-1 %), and an L2 prefetch of the A tile's lines six steps ahead through the same texture path (+10 %: it costs as many line requests as it saves).
       constexpr int MINE = FIRST ? 8 : RT0 + RT1;        // requests of this wave per step
       auto request = [&](int kt, int stage) {
         if constexpr (FIRST) { dma(kt, stage, A0_BYTES + A1_BYTES, 0, C4{}); dma(kt, stage, A0_BYTES + A1_BYTES + PP_BHALF, 4, C4{}); }
         else { dma(kt, stage, 0, 0, CR0{}); dma(kt, stage, A0_BYTES, RT0, CR1{}); }
       };
-      // one step's fragment reads with this wave's MINE requests spread evenly between them: a request stalls the wave while the
-      // texture path's queue is full (4 waves x MINE requests arrive at once), and reads issued BEHIND such a burst wait for all of it
-      constexpr int NR = 8 + 4 * RT;
-      auto fetch = [&](uint32_t sb, bool more, int kt, int stage) {
-        pp_static_for([&](auto idx_) {
-          constexpr int idx = decltype(idx_)::value;
-          {
-            if constexpr (idx < 8) fb[idx & 1][idx >> 1] = lds_read_b128(sb + boff + foff[idx >> 1] + (idx & 1) * 4096);
-            else fa[(idx - 8) % RT][(idx - 8) / RT] = lds_read_b128(sb + aoff + foff[(idx - 8) / RT] + ((idx - 8) % RT) * 4096);
-          }
-          if constexpr ((idx + 1) * MINE / NR > idx * MINE / NR) {
-            constexpr int q = idx * MINE / NR;             // request q of the step: 32 rows of this row's operand (B for row 0, A for row 1)
-            if (more) {
-              __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(smem + stage * STAGE + (FIRST ? A0_BYTES + A1_BYTES : 0) + q * 4096 + wc * 1024),
-                                                       16, v0 + (uint32_t)q * step32, kt * 128, 0, 0);
-            }
-            PP_FENCE();
-          }
-        }, std::make_integer_sequence<int, NR>{});
-      };
-      // the same requests spread between the MFMAs of the multiply segment instead (one every NM / MINE instructions)
-      constexpr int NM = 8 * RT;
-      auto mfmas_dma = [&](bool more, int kt, int stage) {
-        __builtin_amdgcn_s_setprio(1);
-        pp_static_for([&](auto idx_) {
-          constexpr int idx = decltype(idx_)::value, ks = idx / (2 * RT), i = (idx % (2 * RT)) / 2, j = idx & 1;
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j][ks], fa[i][ks], acc[i][j], 0, 0, 0);
-          if constexpr ((idx + 1) * MINE / NM > idx * MINE / NM) {
-            constexpr int q = idx * MINE / NM;
-            if (more)
-              __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(smem + stage * STAGE + (FIRST ? A0_BYTES + A1_BYTES : 0) + q * 4096 + wc * 1024),
-                                                       16, v0 + (uint32_t)q * step32, kt * 128, 0, 0);
-            PP_FENCE();
-          }
-        }, std::make_integer_sequence<int, NM>{});
-        __builtin_amdgcn_s_setprio(0);
-      };
       request(0, 0);
-      if (!FIRST && pp_mode == 0 && nk > 2) { request(1, 1); request(2, 2); pp_wait_vm<2 * MINE>(); }   // row 1 requests THREE steps ahead (below)
-      else if (nk > 1) { request(1, 1); pp_wait_vm<MINE>(); } else pp_wait_vm<0>();
+      if (nk > 1) { request(1, 1); pp_wait_vm<MINE>(); } else pp_wait_vm<0>();
       PP_BARRIER();
       if constexpr (!FIRST) PP_BARRIER();               // row 1 runs one segment behind
       NT_STAMP(1);
@@ -1001,17 +959,13 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(GemmNT p) {
         const uint32_t sb = lds0 + (uint32_t)(rs * STAGE);
         NT_ABL_STEP(t);
         const bool more = t + 2 < nk;
-        if constexpr (pp_mode == 1) { if (more) request(t + 2, ws); reads(sb); }
-        else if constexpr (pp_mode == 2) fetch(sb, more, t + 2, ws);
-        else reads(sb);
+        if (more) request(t + 2, ws);
+        reads(sb);
         PP_FENCE();
         if constexpr (!FIRST) { if (more) pp_wait_vm<MINE>(); else pp_wait_vm<0>(); }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         PP_BARRIER();
-        // mode 0: requests between the MFMAs.  Row 0 (multiplying in phase 2t + 1) requests B(t + 2) into the stage read in step t - 1; row 1
-        // (phase 2t + 2: BOTH rows are done with stage t) requests A(t + 3) into the stage it has just read
-        if constexpr (pp_mode == 0) { if constexpr (FIRST) mfmas_dma(more, t + 2, ws); else mfmas_dma(t + 3 < nk, t + 3, rs); }
-        else mfmas();
+        mfmas();
         PP_FENCE();
         if constexpr (FIRST) { if (more) pp_wait_vm<MINE>(); else pp_wait_vm<0>(); }
         PP_BARRIER();
