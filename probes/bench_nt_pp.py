@@ -10,7 +10,6 @@ lib = importlib.import_module("x2-vlm_amd._lib").lib()
 dev = "cuda"
 NSET = 8
 HEIGHTS = [int(x) for x in (sys.argv[1].split(",") if len(sys.argv) > 1 else "4,5,6".split(","))]
-lib.x2_tune(4, int(os.environ.get("PP_MODE", "0")))       # operand requests: 0 between the MFMAs, 1 one burst ahead of the fragment reads, 2 between the reads
 SHAPES = [("vit qkv", 12608, 2304, 768, "bias"), ("vit dqkv", 12608, 768, 2304, "plain"), ("vit dfc1", 12608, 768, 3072, "plain"),
           ("vit fc2", 12608, 768, 3072, "lscale"), ("vit proj", 12608, 768, 768, "lscale"), ("vit dproj", 12608, 768, 768, "plain"),
           ("vit fc1", 12608, 3072, 768, "gelu"), ("vit dfc2", 12608, 3072, 768, "dgelu"), ("fus xkv", 12608, 1536, 768, "bias"),
@@ -49,19 +48,26 @@ for name, M, N, Kd, kind in SHAPES:
     resid = torch.randn(M, N, device=dev) if f32 else None
     aux = torch.randn(M, N, device=dev).bfloat16() if kind in ("gelu", "dgelu") else None
 
+    BLOCKED = bool(os.environ.get("PP_BLOCKED"))      # hand the ping-pong kernel A as [K / 64][M][64] (x2_tune(4, 1)): 20 KB of contiguous bytes per tile and step
+    Ab = [a_.view(M, Kd // 64, 64).permute(1, 0, 2).contiguous().view(M, Kd) for a_ in As] if BLOCKED else None
+    cur = {"v": 0}
+
+    As_n = As
+
     def run(i):
+        As_ = Ab if (BLOCKED and cur["v"] != 0) else As_n
         if kind == "bias":
-            K.gemm_nt(As[i], W, bias=bias, out=outs[i])
+            K.gemm_nt(As_[i], W, bias=bias, out=outs[i])
         elif kind == "plain":
-            K.gemm_nt(As[i], W, out=outs[i])
+            K.gemm_nt(As_[i], W, out=outs[i])
         elif kind == "gelu":
-            K.gemm_nt(As[i], W, bias=bias, aux=aux, act=1, out=outs[i])
+            K.gemm_nt(As_[i], W, bias=bias, aux=aux, act=1, out=outs[i])
         elif kind == "dgelu":
-            K.gemm_nt(As[i], W, aux=aux, act=2, out=outs[i])
+            K.gemm_nt(As_[i], W, aux=aux, act=2, out=outs[i])
         elif kind == "resid":
-            K.gemm_nt(As[i], W, bias=bias, resid=resid, out=outs[i])
+            K.gemm_nt(As_[i], W, bias=bias, resid=resid, out=outs[i])
         else:
-            K.gemm_nt(As[i], W, bias=bias, gamma=gamma, resid=resid, out=outs[i])
+            K.gemm_nt(As_[i], W, bias=bias, gamma=gamma, resid=resid, out=outs[i])
     variants = [0] + HEIGHTS
     res = {v: 1e9 for v in variants}
     ref = None
