@@ -23,7 +23,7 @@ extern "C" {
 #endif
 
 const char* x2_last_error(void);
-int x2_abi_version(void);          /* == 11 */
+int x2_abi_version(void);          /* == 12 */
 int x2_device_cus(void);           /* compute units of the current HIP device, 0 if none */
 int x2_tune(int key, int value);   /* kernel-variant knobs for probes/ and tests (0 = automatic); keys listed in csrc/gemm.hip.
                                     * key 12 = compute units every tile plan leaves to RCCL's channel kernels (world > 1);
@@ -219,6 +219,20 @@ int x2_ce_combine(const float* part, int chunks, const float* zlab, const long* 
 int x2_mlm_ce_bwd(const void* X, const void* E, const float* bias, const long* labels, const float* lse, const float* g,
                   const float* stat, float gscale, int R, int Vp, int V, int Hd, int ldx, int lde, void* dl_bf16, long ldd,
                   void* stream);
+/* MLM text masking of a padded batch on the device (csrc/masking.hip): dataset/pretrain_dataset.py:59-130 (TextMaskingGenerator.__call__) and
+ * :242-275 (ImageTextJsonDataset.preprocess: masked_ids, padding) - host work of the reference's data-loader workers.
+ *   text_ids, text_atts [B, L] int64 (captions left-aligned, atts = 1 on the caption, first token = cls_id); is_subword [vocab] bytes, 1 where the
+ *   token text starts with '##' (WordPiece continuation); outputs int64: text_ids_masked [B, L] (pad_id beyond the caption), masked_pos [B, max_masks]
+ *   (pad 0), masked_ids [B, max_masks] (original ids, pad pad_mask = -100).  2 <= L <= 512.
+ *   Random draws come from a stream of 32-bit words per caption, consumed in the reference's draw order (rand() < p: word < ceil(p 2^32);
+ *   randint(a, b): a + ((word (b - a + 1)) >> 32); shuffle: random.shuffle's loop with j = (word (i + 1)) >> 32): words != NULL: caption b reads
+ *   words[b * words_ld + k] (injected, parity tests: at most 4 L + 64 are consumed); words == NULL: word k = hash(seed', b, k) with
+ *   seed' = epoch ? hash(seed + 0x9E3779B1 * *epoch) : seed (a hipGraph-captured step increments *epoch per replay: new masks every step).
+ *   The order of the reported positions is the iteration order of the CPython set the reference collects them in (restated in the kernel). */
+int x2_mask_tokens(const long* text_ids, const long* text_atts, int B, int L, const unsigned char* is_subword, int vocab,
+                   const unsigned* words, int words_ld, unsigned seed, const unsigned* epoch, double mask_prob, int max_masks,
+                   double skipgram_prb, int skipgram_size, int mask_whole_word, long cls_id, long mask_id, long pad_id, long pad_mask,
+                   long* text_ids_masked, long* masked_pos, long* masked_ids, void* stream);
 /* hard negatives, xvlm.py:828-857: softmax(sim)+1e-5 with the diagonal (or same-group entries) zeroed, one
  * inverse-CDF draw per row from u[b] in [0,1); replaces 2*B torch.multinomial(...).item() host syncs */
 int x2_sample_negatives(const float* sim, int n, const long* group, const float* u, int* out, void* stream);

@@ -10,7 +10,7 @@ OUT="$HERE/_probe"
 mkdir -p "$OUT"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result -DX2_PROBE"
 pids=()
-for f in runtime gemm attention rowwise heads optim comm; do
+for f in runtime gemm attention rowwise heads masking optim comm; do
   if [ ! -f "$OUT/$f.o" ] || [ "$SRC/$f.hip" -nt "$OUT/$f.o" ] || [ "$SRC/x2_common.h" -nt "$OUT/$f.o" ]; then
     hipcc $FLAGS -c "$SRC/$f.hip" -o "$OUT/$f.o" &
     pids+=($!)

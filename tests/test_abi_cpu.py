@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(h, name), "include/x2vlm_hip.h declares %s but libx2vlm_hip.so does not export it" % name
     assert sorted(lib.EXPORTS) == declared, set(lib.EXPORTS) ^ set(declared)
-    assert lib.lib().x2_abi_version() == 11
+    assert lib.lib().x2_abi_version() == 12
 
 
 def test_attn_args_struct_matches_header_layout():

@@ -38,15 +38,18 @@ def relerr(got, ref):
     return float((got - ref).abs().max() / ref.abs().max().clamp_min(1e-12))
 
 
-@pytest.fixture(params=[(1, 1), (1, 2), (1, 3), (1, 4), (3, 8), (3, 7), (3, 6), (3, 5)],
-                ids=["tile128x128", "tile192x128", "tile64x128", "tile160x128", "nt256x256", "nt224x256", "nt192x256", "nt160x256"])
+@pytest.fixture(params=[(1, 1, 0), (1, 2, 0), (1, 3, 0), (1, 4, 0), (3, 8, 0), (3, 7, 0), (3, 6, 0), (3, 5, 0), (0, 0, 3), (0, 0, 4), (0, 0, 5), (0, 0, 6)],
+                ids=["tile128x128", "tile192x128", "tile64x128", "tile160x128", "nt256x256", "nt224x256", "nt192x256", "nt160x256",
+                     "pingpong96x256", "pingpong128x256", "pingpong160x256", "pingpong192x256"])
 def nt_tile(request):
     lib = importlib.import_module("x2-vlm_amd._lib").lib()
     lib.x2_tune(1, request.param[0])
     lib.x2_tune(3, request.param[1])
+    lib.x2_tune(15, request.param[2])           # the ping-pong kernel (32x32x16 MFMAs) at 32 x value rows; runs the same tests as every other tile
     yield request.param
     lib.x2_tune(1, 0)
     lib.x2_tune(3, 0)
+    lib.x2_tune(15, 0)
 
 
 @pytest.mark.parametrize("M,N,K_", [(256, 256, 128), (300, 200, 192), (788, 2304, 768), (12608, 768, 768), (100, 30528, 64)])

@@ -65,6 +65,7 @@ _SIGS = {
     "x2_ce_combine": [P, I, P, P, I, P, P, P, P],
     "x2_mlm_ce_bwd": [P, P, P, P, P, P, P, F, I, I, I, I, I, I, P, L, P],
     "x2_sample_negatives": [P, I, P, P, P, P],
+    "x2_mask_tokens": [P, P, I, I, P, I, P, I, U, P, C.c_double, I, C.c_double, I, I, L, L, L, L, P, P, P, P],
     "x2_additive_mask": [P, P, I, I, I, F, P],
     "x2_kv_csr": [P, I, I, P, P, P],
     "x2_tail_index": [P, P, P, P, I, I, I, I, P, P, P, P, P],

@@ -6,7 +6,7 @@ OUT=../libx2vlm_hip.so
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result"
 mkdir -p ../_build
 pids=()
-for f in runtime gemm attention rowwise heads optim comm; do
+for f in runtime gemm attention rowwise heads masking optim comm; do
   if [ ! -f ../_build/$f.o ] || [ $f.hip -nt ../_build/$f.o ] || [ x2_common.h -nt ../_build/$f.o ]; then
     hipcc $FLAGS -c $f.hip -o ../_build/$f.o &
     pids+=($!)

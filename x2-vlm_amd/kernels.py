@@ -609,6 +609,39 @@ def mlm_ce_bwd(x, E, bias, labels, lse, g, stat, V, gscale=1.0):
     return dl
 
 
+def mask_words(seed, epoch, batch, count):
+    """Host mirror of csrc/masking.hip mk_word(): the 32-bit words caption b consumes when none are injected, [batch, count] int64 (CPU)."""
+    seed = int(seed) & 0xFFFFFFFF
+    if epoch is not None:
+        seed = _hash32_int((seed + 0x9E3779B1 * (int(epoch) & 0xFFFFFFFF)) & 0xFFFFFFFF)
+    out = torch.empty(batch, count, dtype=torch.int64)
+    for b in range(batch):
+        hb = _hash32_int((seed + 0x9E3779B1 * (b + 1)) & 0xFFFFFFFF)
+        for k in range(count):
+            out[b, k] = _hash32_int(hb ^ ((0x85EBCA6B * (k + 1)) & 0xFFFFFFFF))
+    return out
+
+
+def mask_tokens(text_ids, text_atts, is_subword, *, words=None, seed=0, epoch=None, mask_prob=0.5, max_masks=12, skipgram_prb=0.2, skipgram_size=3,
+                mask_whole_word=True, cls_id=101, mask_id=103, pad_id=0, pad_mask=-100):
+    """MLM masking of a padded batch on the device (pretrain_dataset.py:59-130, 242-275): (text_ids_masked [B, L], masked_pos [B, max_masks],
+    masked_ids [B, max_masks]), int64.  is_subword: uint8 [vocab], 1 = WordPiece continuation ('##...').  words: injected uint32 stream [B, W]
+    stored as int32 / uint32 bits (parity tests) or None: hashed from (seed, *epoch, caption, draw) - epoch is a device uint32 word (DROP_EPOCH)."""
+    assert text_ids.dtype == torch.int64 and text_atts.dtype == torch.int64 and text_ids.shape == text_atts.shape and text_ids.dim() == 2
+    assert text_ids.is_contiguous() and text_atts.is_contiguous() and is_subword.dtype == torch.uint8 and is_subword.is_contiguous()
+    B, L = text_ids.shape
+    dev = text_ids.device
+    idm = torch.empty(B, L, device=dev, dtype=torch.int64)
+    mpos = torch.empty(B, max_masks, device=dev, dtype=torch.int64)
+    mids = torch.empty(B, max_masks, device=dev, dtype=torch.int64)
+    if words is not None:
+        assert words.dtype in (torch.int32, torch.uint32) and words.dim() == 2 and words.shape[0] == B and words.is_contiguous()
+    call("x2_mask_tokens", ptr(text_ids), ptr(text_atts), B, L, ptr(is_subword), is_subword.numel(), ptr(words), words.shape[1] if words is not None else 0,
+         int(seed) & 0xFFFFFFFF, ptr(epoch), float(mask_prob), int(max_masks), float(skipgram_prb), int(skipgram_size), 1 if mask_whole_word else 0,
+         int(cls_id), int(mask_id), int(pad_id), int(pad_mask), ptr(idm), ptr(mpos), ptr(mids))
+    return idm, mpos, mids
+
+
 def sample_negatives(sim, u, group=None):
     n = sim.shape[0]
     out = torch.empty(n, device=sim.device, dtype=torch.int32)
