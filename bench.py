@@ -326,6 +326,7 @@ def main():
     # ~25 ms (base) / ~100 ms (large) of Python + ctypes launch time per step that bounded round 1.  The optimizer stays
     # outside the graph.  X2_GRAPH=0 / --no-graph: eager launches.
     graph = importlib.import_module("x2-vlm_amd.graph")
+    fresh = None
     use_graph = not args.no_graph and (world == 1 or args.graph == "segments")
     if use_graph and os.environ.get("X2_GRAPH_CANARY", "1") == "1" and not args.tiny and world == 1:
         # Stream capture leans on ROCm behaviour found by probing (graph.py): a runtime that breaks it tends to crash
@@ -352,15 +353,29 @@ def main():
             runner = graph.MixedStep(model, [dict(batch=batch), dict(batch=rbatch, ret_bbox_loss=True)], world=world, rank=rank, warmup=1,
                                      enabled=use_graph, verbose=(rank == 0))
         else:
+            masking = None
+            if not region and os.environ.get("X2_DEVICE_MASKING", "1") == "1":
+                # the MLM masking of the reference's data-loader workers (dataset/pretrain_dataset.py:59-130, 242-275) as the first kernel of the text
+                # segment: the step takes RAW captions and draws a new mask on every replay (X2_DEVICE_MASKING=0: the static host-made masks)
+                synth = importlib.import_module("x2-vlm_amd.synthetic")
+                masking = synth.masking_config({}, synth.synth_subword_flags(30522).to(dev), seed=1234 + rank)
+                # ... and every timed step first receives a FRESH device batch (image, text_ids, text_atts) by GraphedStep.copy_inputs
+                fresh = [{k: v.to(dev) for k, v in synthetic_batch(rank + 1000 * (i + 1), args.batch, args.seq_len, conf["res"], frames=conf["frames"]).items()
+                          if k in ("image", "text_ids", "text_atts")} for i in range(3)]
             runner = graph.SegmentedStep(model, batch, world=world, rank=rank, warmup=1, enabled=use_graph, verbose=(rank == 0),
-                                         ret_bbox_loss=region)
+                                         ret_bbox_loss=region, masking=masking)
     else:
         # N = 1: the whole step as ONE multi-stream hipGraph (fork / join edges: ~15 us of host time per node).
         # N > 1 on this path: eager launches with bucketed all-reduces overlapped on a side stream (accelerator.GradientBuckets).
         fwd_bwd.parameters = lambda: params
         runner = graph.GraphedStep(fwd_bwd, warmup=1, enabled=use_graph and world == 1, verbose=(rank == 0))
 
+    nstep = [0]
+
     def step():
+        if fresh is not None:                   # new inputs into the tensors the segments were captured on (inside the timed region)
+            graph.GraphedStep.copy_inputs(batch, fresh[nstep[0] % len(fresh)])
+            nstep[0] += 1
         loss = runner()
         if isinstance(loss, list):              # MixedStep: one loss dict per part
             loss = dict(loss[0], **{"region_" + k: v for k, v in loss[1].items()})
@@ -439,6 +454,8 @@ def main():
                           "parallelism": "dp%d" % world, "streams": "single (--serialize)" if args.serialize else "concurrent",
                           "optimizer_in_step": bool(args.with_optimizer), "mode": "eval (dropout/DropPath off)" if args.eval_mode else
                           "train (BERT dropout 0.1, attention dropout 0.1, DropPath 0..0.1)",
+                          "inputs": ("a fresh device batch (image, text_ids, text_atts) copied into the step's tensors inside every timed step; MLM masking "
+                                     "on the device inside the text segment (x2_mask_tokens)") if fresh is not None else "static batch, host-made MLM masks",
                           "losses": {k: round(float(v), 4) for k, v in loss.items()}},
                "roofline": roof}
         # every kernel-variant knob that is not at its default (X2_TUNE / x2_tune) is part of the record: a line measured

@@ -165,6 +165,39 @@ def test_segmented_replays_draw_new_dropout_masks(synthetic):
     assert len(set(seen)) == 4, seen                                    # same inputs, four different masks
 
 
+def test_segmented_step_masks_raw_captions_on_the_device(synthetic):
+    """SegmentedStep(masking=...): the text segment starts with x2_mask_tokens on the raw (text_ids, text_atts); every replay draws the mask of the
+    step counter (= the oracle's masking on the host mirror of the hashed words), and the losses are those of the eager model on that mask."""
+    from oracle import masking_oracle as mo
+    graph = importlib.import_module("x2-vlm_amd.graph")
+    K = importlib.import_module("x2-vlm_amd.kernels")
+    model, c = _build(synthetic, train=False)
+    full = _batches(synthetic, c, 1)[0]
+    raw = {k: full[k].clone() for k in ("image", "text_ids", "text_atts")}
+    sub = synthetic.synth_subword_flags(c["vocab"]).to(raw["text_ids"].device)
+    mk = synthetic.masking_config(dict(max_masks=c["max_masks"]), sub, seed=77, big_vocab=c["vocab"] > 2000)
+    step = graph.SegmentedStep(model, raw, clamp_temp=False, masking=mk)
+    assert step.mode == "hipgraph-segments", step.error
+    seen = []
+    for _ in range(3):
+        lg = {k: float(v) for k, v in step().items()}
+        torch.cuda.synchronize()
+        ep = int(K.DROP_EPOCH.item())
+        B, L = raw["text_ids"].shape
+        words = K.mask_words(77, ep, B, 4 * L + 64).numpy().astype("uint32")
+        kw = {k: v for k, v in mk.items() if k not in ("is_subword", "seed")}
+        want = mo.mask_tokens(raw["text_ids"].cpu().numpy(), raw["text_atts"].cpu().numpy(), sub.cpu().numpy(), words, vocab_size=c["vocab"], **kw)
+        for key, w_ in zip(("text_ids_masked", "masked_pos", "masked_ids"), want):
+            assert (raw[key].cpu().numpy() == w_).all(), key
+        le = model(raw["image"], raw["text_ids"], raw["text_atts"], text_ids_masked=raw["text_ids_masked"], masked_pos=raw["masked_pos"],
+                   masked_ids=raw["masked_ids"])
+        for k in lg:
+            if k != "loss_itm":                         # ITM: hard negatives are re-drawn by the eager call
+                assert abs(float(le[k]) - lg[k]) <= 1e-5 * max(1.0, abs(lg[k])), (k, float(le[k]), lg[k])
+        seen.append(tuple(raw["masked_pos"].flatten().tolist()))
+    assert len(set(seen)) == 3                          # a new mask on every replay
+
+
 def _mixed_parts(synthetic, model, c, shift=0):
     """An image part and a region part (weight 0.5) for the tiny_region geometry, with their injected negatives (device tensors)."""
     bi = synthetic.synth_batch(c["bseed"] + shift, 4, c["seq_len"], c["image_res"], c["vocab"], c["max_masks"], ragged=True)

@@ -160,7 +160,7 @@ class SegmentedStep:
 
     def __init__(self, model, batch, world=1, rank=0, process_group=None, comm=None, warmup=2, enabled=True, verbose=False,
                  ret_bbox_loss=False, ret_match_loss=True, recast_weights=True, clamp_temp=True, total_loss=None, side_stream=None,
-                 vision_cuts=None, reduce_grads=True, defer_reduce=False):
+                 vision_cuts=None, reduce_grads=True, defer_reduce=False, masking=None):
         """side_stream: weight-gradient GEMMs of the stream-A segments (tail, vision backward) on engine.SIDE, forked from and
         joined into stream A inside the segment.  Those segments then replay node by node (~15 us of host time each, still
         well under the GPU time of a step) but keep the 3 % the side stream is worth on one GPU.  Default: X2_SEG_SIDE or off.
@@ -170,6 +170,17 @@ class SegmentedStep:
         from . import engine
         self.engine = engine
         self.model, self.batch, self.world, self.rank, self.pg, self.comm = model, batch, world, rank, process_group, comm
+        # masking: None (the batch carries text_ids_masked / masked_pos / masked_ids, made by the data pipeline as in the reference) or a
+        # dict for kernels.mask_tokens (is_subword uint8 [vocab] on the device, plus any of mask_prob, max_masks, skipgram_prb, skipgram_size,
+        # mask_whole_word, cls_id, mask_id, seed): the text segment then starts with the MLM masking of the RAW (text_ids, text_atts) of the
+        # batch (dataset/pretrain_dataset.py:59-130, 242-275 on the device) and draws a new mask on every replay (the epoch word)
+        self.masking = dict(masking) if masking else None
+        if self.masking:
+            mm = int(self.masking.get("max_masks", 12))
+            ids = batch["text_ids"]
+            batch.setdefault("text_ids_masked", torch.empty_like(ids))
+            batch.setdefault("masked_pos", torch.zeros(ids.shape[0], mm, dtype=torch.int64, device=ids.device))
+            batch.setdefault("masked_ids", torch.full((ids.shape[0], mm), -100, dtype=torch.int64, device=ids.device))
         # collectives are issued when there is more than one rank - or when X2_DDP_SINGLE_RANK_COLLECTIVES=1 asks a single rank to
         # run them anyway (the RCCL call path of the replayed step on a 1-GPU box; AVG over one rank is the identity)
         self.coll = world > 1 or os.environ.get("X2_DDP_SINGLE_RANK_COLLECTIVES", "0") == "1"
@@ -393,6 +404,8 @@ class SegmentedStep:
     # ------------------------------------------------------------------ the segments
     def _s_text(self):
         b = self.batch
+        if self.masking:
+            K.mask_tokens(b["text_ids"], b["text_atts"], epoch=self._epoch, out=(b["text_ids_masked"], b["masked_pos"], b["masked_ids"]), **self.masking)
         self.t["both"] = self.model.tower_text(b["text_ids"], b["text_atts"], b["text_ids_masked"])
 
     def _vhook(self, ci, x):

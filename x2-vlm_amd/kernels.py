@@ -623,7 +623,7 @@ def mask_words(seed, epoch, batch, count):
 
 
 def mask_tokens(text_ids, text_atts, is_subword, *, words=None, seed=0, epoch=None, mask_prob=0.5, max_masks=12, skipgram_prb=0.2, skipgram_size=3,
-                mask_whole_word=True, cls_id=101, mask_id=103, pad_id=0, pad_mask=-100):
+                mask_whole_word=True, cls_id=101, mask_id=103, pad_id=0, pad_mask=-100, out=None):
     """MLM masking of a padded batch on the device (pretrain_dataset.py:59-130, 242-275): (text_ids_masked [B, L], masked_pos [B, max_masks],
     masked_ids [B, max_masks]), int64.  is_subword: uint8 [vocab], 1 = WordPiece continuation ('##...').  words: injected uint32 stream [B, W]
     stored as int32 / uint32 bits (parity tests) or None: hashed from (seed, *epoch, caption, draw) - epoch is a device uint32 word (DROP_EPOCH)."""
@@ -631,9 +631,14 @@ def mask_tokens(text_ids, text_atts, is_subword, *, words=None, seed=0, epoch=No
     assert text_ids.is_contiguous() and text_atts.is_contiguous() and is_subword.dtype == torch.uint8 and is_subword.is_contiguous()
     B, L = text_ids.shape
     dev = text_ids.device
-    idm = torch.empty(B, L, device=dev, dtype=torch.int64)
-    mpos = torch.empty(B, max_masks, device=dev, dtype=torch.int64)
-    mids = torch.empty(B, max_masks, device=dev, dtype=torch.int64)
+    if out is not None:                              # static tensors of a captured step
+        idm, mpos, mids = out
+        assert idm.shape == (B, L) and mpos.shape == (B, max_masks) and mids.shape == (B, max_masks)
+        assert all(t.dtype == torch.int64 and t.is_contiguous() for t in out)
+    else:
+        idm = torch.empty(B, L, device=dev, dtype=torch.int64)
+        mpos = torch.empty(B, max_masks, device=dev, dtype=torch.int64)
+        mids = torch.empty(B, max_masks, device=dev, dtype=torch.int64)
     if words is not None:
         assert words.dtype in (torch.int32, torch.uint32) and words.dim() == 2 and words.shape[0] == B and words.is_contiguous()
     call("x2_mask_tokens", ptr(text_ids), ptr(text_atts), B, L, ptr(is_subword), is_subword.numel(), ptr(words), words.shape[1] if words is not None else 0,

@@ -64,6 +64,30 @@ def synth_state_dict(model, seed):
     return model
 
 
+def subword_flags(vocab):
+    """uint8 [V] from a tokenizer vocabulary {token text: id} (tokenizer.get_vocab()): 1 where the token is a WordPiece continuation ('##...').
+    What the reference's TextMaskingGenerator asks of every token it expands a whole word over (dataset/pretrain_dataset.py:89-93)."""
+    flags = np.zeros(len(vocab), dtype=np.uint8)
+    for tok, i in vocab.items():
+        flags[i] = 1 if tok.startswith("##") else 0
+    return torch.from_numpy(flags)
+
+
+def synth_subword_flags(vocab_size):
+    """Stand-in for subword_flags() when there is no tokenizer (bench, smoke, tests): every fifth id from 1000 on is a '##' piece - about the
+    share bert-base-uncased has (5 828 of 30 522)."""
+    ids = np.arange(vocab_size)
+    return torch.from_numpy(((ids >= min(1000, vocab_size // 2)) & (ids % 5 == 0)).astype(np.uint8))
+
+
+def masking_config(config, is_subword, seed=0, big_vocab=True):
+    """kernels.mask_tokens / graph.SegmentedStep(masking=...) arguments from the reference's config keys (configs/pretrain/x2vlm_base_4m.yaml:53-57)."""
+    cls_id, mask_id = (101, 103) if big_vocab else (1, 3)
+    return dict(is_subword=is_subword, mask_prob=float(config.get("mask_prob", 0.5)), max_masks=int(config.get("max_masks", 12)),
+                skipgram_prb=float(config.get("skipgram_prb", 0.2)), skipgram_size=int(config.get("skipgram_size", 3)),
+                mask_whole_word=bool(config.get("mask_whole_word", True)), cls_id=cls_id, mask_id=mask_id, seed=int(seed))
+
+
 def synth_batch(seed, batch, seq_len, image_res, vocab_size, max_masks=12, ragged=False,
                 frames=0):
     """Image-text batch in the reference's collate layout. Returns a dict of CPU tensors."""
