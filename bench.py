@@ -403,6 +403,42 @@ def main():
     pairs_s = world * units * args.steps / dt
     per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
 
+    # ---- the same iteration through the reference's UNPATCHED call sequence (Pretrain.run_image_iter, Pretrain.py:54-76): model(...) ->
+    # optimizer.zero_grad() -> accelerator.backward_step(sum of the losses) on what RocmDDPAccelerator.set_up returns (accelerator._Wrapped:
+    # the second call captures the segments, later calls replay them; host-made MLM masks, as the reference's data loader delivers them)
+    unpatched = None
+    if world == 1 and args.graph == "segments" and use_graph and not (mixed or region or args.serialize or args.tiny) and os.environ.get("X2_BENCH_UNPATCHED", "1") == "1":
+        try:
+            wrapped = acc._Wrapped(model, None)
+            a_ = acc.RocmDDPAccelerator(dict(), None)
+            a_.ddp_model = wrapped
+            full = [{k: v.to(dev) for k, v in synthetic_batch(rank + 2000 * (i + 1), args.batch, args.seq_len, conf["res"], frames=conf["frames"]).items()}
+                    for i in range(3)]
+
+            def run_image_iter(b):
+                loss_ = wrapped(b["image"], b["text_ids"], b["text_atts"], text_ids_masked=b["text_ids_masked"], masked_pos=b["masked_pos"],
+                                masked_ids=b["masked_ids"], ret_match_loss=True)
+                for p_ in params:                          # optimizer.zero_grad()
+                    p_.grad = None
+                a_.backward_step(loss_["loss_itc"] + loss_["loss_itm"] + loss_["loss_mlm"], opt)
+                optimizer_part()
+                return loss_
+            for i in range(4):
+                run_image_iter(full[i % 3])
+            fence()
+            t1 = time.perf_counter()
+            for i in range(args.steps):
+                run_image_iter(full[i % 3])
+            fence()
+            dt1 = time.perf_counter() - t1
+            unpatched = {"value": round(units * args.steps / dt1, 1), "unit": "image-text pairs/s", "ms_per_step": round(1e3 * dt1 / args.steps, 2),
+                         "launch_mode": wrapped.last_mode,
+                         "what": "model(...) + optimizer.zero_grad() + accelerator.backward_step(loss_itc + loss_itm + loss_mlm) per step, the call sequence "
+                                 "of Pretrain.run_image_iter, on the wrapper RocmDDPAccelerator.set_up returns (auto-captured segments); a fresh "
+                                 "device batch with host-made masks every step"}
+        except Exception as e:      # noqa: BLE001 - the headline line must still be printed
+            unpatched = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+
     roof = None
     f_min, f_note = conf["f_min"], None
     if f_min is None:
@@ -463,6 +499,8 @@ def main():
         # csrc/gemm.hip compiles them only with -DX2_PROBE, probes/build_probe.sh.)
         h_ = importlib.import_module("x2-vlm_amd._lib").lib()
         tuned = {str(k): h_.x2_tune_get(k) for k in range(16) if h_.x2_tune_get(k) > 0}
+        if unpatched is not None:
+            out["roofline"]["also"]["unpatched_pretrain_py"] = unpatched
         out["x2_tune_non_default"] = tuned
         out["env_switches"] = {k: v for k, v in sorted(os.environ.items()) if k.startswith("X2_") and k not in ("X2_BENCH_BACKEND",)}
         if world == 1 and not args.no_cpu_baseline:

@@ -114,16 +114,131 @@ class GradientBuckets:
         engine.GRAD_READY_HOOK = None
 
 
-class _Wrapped(torch.nn.Module):
-    """What set_up returns in place of apex's DistributedDataParallel: callable like the model,
-    exposes `.module` (Pretrain.py:328 clamps model.module.temp)."""
+class _PublishGrads(torch.autograd.Function):
+    """Joins the losses of a step whose backward has ALREADY run to autograd: forward hands out the loss values, backward - reached by the
+    caller's accelerator.backward_step(sum of the losses) - publishes the gradients (those of the plain sum of the returned losses,
+    Pretrain.py:67-68 / 98-100) into .grad instead of computing anything."""
 
-    def __init__(self, module):
+    @staticmethod
+    def forward(ctx, anchor, owner, pending, values):
+        ctx.owner, ctx.pending = owner, pending
+        return tuple(values.unbind(0))
+
+    @staticmethod
+    def backward(ctx, *cots):
+        ctx.owner._publish(ctx.pending, cots)
+        return None, None, None, None
+
+
+class _Wrapped(torch.nn.Module):
+    """What set_up returns in place of apex's DistributedDataParallel: callable like the model, exposes `.module`
+    (Pretrain.py:328 clamps model.module.temp).
+
+    Auto-capture (X2_AUTO_CAPTURE=0: the plain module call).  Pretrain.run_image_iter / run_region_iter do, every iteration and with the same shapes,
+        loss = model(image, text_ids, ...);  optimizer.zero_grad();  accelerator.backward_step(sum of the losses, optimizer)
+    (Pretrain.py:54-76, 79-107).  Launched eagerly that is ~1300 ctypes calls from Python per step (host-bound, ~29 ms for the base step); replayed as
+    graph.SegmentedStep segments it is ~1 ms of host time.  A training call (grad enabled, module.training, an image and the MLM inputs, device
+    tensors) therefore runs forward AND backward before it returns:
+      * the first call with a shape signature: eagerly (the module, then the backward of the plain sum of its losses) - a shape seen once, like the short
+        last batch of an epoch, is not worth a capture;
+      * the second call builds graph.SegmentedStep for the signature (static copies of the inputs), later calls copy their inputs in and replay it;
+    and returns the loss values tied to _PublishGrads.  The gradients (averaged over the ranks already) are kept out of reach of the caller's
+    optimizer.zero_grad() and appear in .grad when backward_step backpropagates the losses.  No autograd graph of the model survives the call, which
+    the captures need: an AccumulateGrad node kept alive by a previous iteration's loss tensors stays bound to the stream it was created on.
+    Everything else - no-grad / eval calls, text-only calls (image=None), X2_AUTO_CAPTURE=0 - is the plain module call.
+    Limit: the gradients are those of the PLAIN SUM of the returned losses.  A backward with unequal cotangents (a weighted sum, Pretrain.run_mixed_iter's
+    iter_perc) recomputes forward and backward eagerly with the caller's weights - correct, slow, warned about once; accelerator.mixed_step is the
+    fast form of that iteration."""
+
+    def __init__(self, module, accelerator=None):
         super().__init__()
         self.module = module
+        self._acc = accelerator
+        self._seen, self._steps = {}, {}
+        self._warned = False
+        self.auto_capture = os.environ.get("X2_AUTO_CAPTURE", "1") == "1"
+        self.last_mode = "eager"
 
-    def forward(self, *a, **k):
-        return self.module(*a, **k)
+    def forward(self, image=None, text_ids=None, text_atts=None, text_ids_masked=None, masked_pos=None, masked_ids=None, image_atts=None,
+                idx_to_group_img=None, target_bbox=None, is_image=None, ret_bbox_loss=False, ret_match_loss=True, **extra):
+        given = dict(image=image, text_ids=text_ids, text_atts=text_atts, text_ids_masked=text_ids_masked, masked_pos=masked_pos,
+                     masked_ids=masked_ids, image_atts=image_atts, idx_to_group_img=idx_to_group_img, target_bbox=target_bbox, is_image=is_image)
+        tensors = {k: v for k, v in given.items() if v is not None}
+        call = lambda: self.module(image, text_ids, text_atts, text_ids_masked=text_ids_masked, masked_pos=masked_pos, masked_ids=masked_ids,
+                                   image_atts=image_atts, idx_to_group_img=idx_to_group_img, target_bbox=target_bbox, is_image=is_image,
+                                   ret_bbox_loss=ret_bbox_loss, ret_match_loss=ret_match_loss, **extra)
+        ok = (self.auto_capture and not extra and torch.is_grad_enabled() and self.module.training and image is not None
+              and text_ids_masked is not None and all(torch.is_tensor(v) and v.is_cuda for v in tensors.values()))
+        if not ok:
+            self.last_mode = "eager"
+            return call()
+        sig = (tuple((k, tuple(v.shape), v.dtype) for k, v in tensors.items()), bool(ret_bbox_loss), bool(ret_match_loss))
+        step = self._steps.get(sig)
+        params = [p for p in self.module.parameters() if p.requires_grad]
+        before = [p.grad for p in params]                  # gradients of an earlier forward of the same iteration (accumulation): put back below
+        if step is None:
+            self._seen[sig] = self._seen.get(sig, 0) + 1
+        if step is None and self._seen[sig] >= 2:
+            static = {k: v.clone() for k, v in tensors.items()}
+            kw = dict(ret_bbox_loss=bool(ret_bbox_loss), ret_match_loss=bool(ret_match_loss))
+            if self._acc is not None:
+                step = self._acc.segmented_step(self.module, static, **kw)
+            else:
+                from .graph import SegmentedStep
+                step = SegmentedStep(self.module, static, **kw)
+            step._busy = False
+            self._steps[sig] = step
+        elif step is not None and not step._busy:
+            step.copy_inputs(step.batch, tensors)
+        if step is not None and not step._busy:
+            losses = step()
+            step._busy = True                               # its static gradient tensors are spoken for until the caller's backward
+            self.last_mode = step.mode
+        else:
+            # first sight of the signature (or a second forward of a step whose gradients are still unpublished): the module eagerly, backward at once
+            for p in params:
+                p.grad = None
+            losses = call()
+            sum(losses.values()).backward()
+            if self._acc is not None and self._acc.buckets is not None:
+                self._acc.buckets.finish()
+            step = None
+            self.last_mode = "eager-fused"
+        dev = tensors["image"].device
+        keys = list(losses)
+        values = torch.stack([losses[k].detach().reshape(()).to(dev) for k in keys])     # own storage: a step's loss tensors are rewritten by its next replay
+        del losses
+        held = [(p, p.grad) for p in params if p.grad is not None]
+        for p, g in zip(params, before):                    # out of reach of the caller's zero_grad (in place or to None) until its backward_step
+            p.grad = g
+        anchor = torch.zeros((), device=dev, requires_grad=True)
+        outs = _PublishGrads.apply(anchor, self, dict(held=held, call=call, step=step), values)
+        return dict(zip(keys, outs))
+
+    def _publish(self, pending, cots):
+        held, call, step = pending["held"], pending["call"], pending["step"]
+        if held is None:
+            raise RuntimeError("x2-vlm_amd: second backward through the losses of one model call (its gradients were published already)")
+        pending["held"] = None
+        if step is not None:
+            step._busy = False
+        live = [c for c in cots if c is not None]
+        same = len(live) == len(cots) and all(c.data_ptr() == live[0].data_ptr() or bool(torch.equal(c, live[0])) for c in live[1:])
+        if same and os.environ.get("X2_CHECK_COTANGENT", "0") == "1":
+            same = float(live[0]) == 1.0        # host sync: off by default (Pretrain.py backpropagates the plain sum)
+        if same:
+            for p, g in held:
+                p.grad = g if p.grad is None or p.grad is g else p.grad + g      # a second forward of the iteration accumulates (Pretrain.py:197, 247)
+            return
+        # a weighted sum: the gradients computed with the forward do not apply - one eager forward + backward with the caller's weights
+        if not self._warned:
+            print("x2-vlm_amd: backward with unequal loss weights through an auto-captured model call - recomputing eagerly (slow). "
+                  "accelerator.mixed_step / segmented_step(total_loss=...) are the fast forms of a weighted iteration.", flush=True)
+            self._warned = True
+        with torch.enable_grad():
+            losses = call()
+            keys = list(losses)
+            torch.autograd.backward([losses[k] for k in keys], [c if c is not None else torch.zeros_like(losses[k]) for k, c in zip(keys, cots)])
 
 
 class Accelerator:
@@ -177,7 +292,7 @@ class RocmDDPAccelerator(Accelerator):
                                     **({"device_id": torch.device("cuda", local_rank)} if backend == "nccl" else {}))
         self.world_size = world_size
         self.broadcast(model)
-        self.ddp_model = _Wrapped(model)
+        self.ddp_model = _Wrapped(model, self)
         # a single rank has nothing to average; X2_DDP_SINGLE_RANK_COLLECTIVES=1 keeps the collectives in (RCCL smoke test)
         if world_size > 1 or os.environ.get("X2_DDP_SINGLE_RANK_COLLECTIVES", "0") == "1":
             comm = None
@@ -206,6 +321,9 @@ class RocmDDPAccelerator(Accelerator):
 
     def backward_step(self, loss, optimizer=None):
         loss.backward()
+        wrapped = getattr(self, "ddp_model", None)
+        if wrapped is not None and wrapped.last_mode != "eager":
+            return                               # a fused model call (_Wrapped): forward, backward and the gradient averaging ran inside it
         if self.buckets is not None:
             self.buckets.finish()
 
