@@ -175,7 +175,8 @@ int x2_pool_tokens(float* x, const float* w, int B, int P, int D, int bwd, void*
 int x2_relpos_bias(const float* table, const long* index, const long* indexT /* index^T or NULL */, float* bias, float* biasT, int N, int H, int ld, int ldT,
                    float scale, void* stream);
 /* dtable[index[i][j]][h] += sum_b dS[b][h][i][j] (dS bf16 [B][H][N][ld]); the index arrives as its CSR inverse
- * (inv_off [T+1], inv_pos = i*ld + j); ws: slices*H*N*ld floats (batch-slice sums, then a gather: no atomics) */
+ * (inv_off [T+1], inv_pos = i*ld + j); ws: slices*H*N*ld floats (batch-slice sums, then a gather: no atomics).
+ * Reads columns j < 8 ceil(N / 8) of dS only: the one-pass attention backward leaves columns >= 16 ceil(N / 16) of its dS stream unwritten. */
 int x2_relpos_bias_bwd(const void* dS, const int* inv_off, const int* inv_pos, float* dtable, int B, int N, int H, int ld,
                        int T, float* ws, int slices, void* stream);
 

@@ -1254,7 +1254,9 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_onepass_kernel(AttnArgs a) {
         const uint32_t a0 = lbase + OP_DS + (wave + 8 * j) * OP_BLK + (32 * s + 4 * g + r4) * 32 + c4 * 8;
         dsf[j] = lds_read_tr_frag(a0, a0 + 16 * 32);
         const int q = (wave + 8 * j) * 16 + fi;
-        if (a.dS && q < a.Lq) {          // the dS stream of the bias gradient: [B][H][Lq][ds_ld], this lane = one query, 2 x 4 keys
+        if (a.dS && q < a.Lq) {          // the dS stream of the bias gradient: [B][H][Lq][ds_ld], this lane = one query, 2 x 4 keys.
+                                         // Written: columns < min(16 ceil(Lk / 16), ds_ld) (zeros past Lk); the two-kernel form fills all ds_ld.
+                                         // Contract (include/x2vlm_hip.h, x2_relpos_bias_bwd): consumers read columns < 8 ceil(Lk / 8) only.
           const u32x4 w = __builtin_bit_cast(u32x4, dsf[j]);
           bf16_t* dsp = a.dS + (((long)b * a.H + h) * a.Lq + q) * a.ds_ld + 32 * s + 4 * g;
           if (32 * s + 4 * g < kend) *reinterpret_cast<u32x2*>(dsp) = u32x2{w[0], w[1]};

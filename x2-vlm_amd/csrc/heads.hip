@@ -83,33 +83,41 @@ extern "C" int x2_gather_rows(const float* src, const int* idx, float* dst, void
 // ascending r: no atomics (the first form - a zero fill of dst plus one fp32 atomic per element, 5.9 M of them for the 256
 // sequences of the fusion pass - took 44 us per call in the tail segment, where nothing runs beside it), no dependence on the
 // order workgroups finish in.
-#define SCATTER_MAX_R 8192
+#define SCATTER_MAX_R 8192          // source rows marked per pass of the bitmap (any R: passes of 8192 rows, still ascending r)
 __global__ __launch_bounds__(256) void scatter_rows_kernel(const float* __restrict__ src, const int* __restrict__ idx, float* __restrict__ dst,
-                                                           int R, long len) {
+                                                           int R, long len, int chunks) {
   __shared__ uint32_t bm[SCATTER_MAX_R / 32];
-  const int d = blockIdx.y, nw = (R + 31) >> 5;
-  for (int w = threadIdx.x; w < nw; w += 256) bm[w] = 0u;
-  __syncthreads();
-  for (int r = threadIdx.x; r < R; r += 256)
-    if (idx[r] == d) atomicOr(&bm[r >> 5], 1u << (r & 31));
-  __syncthreads();
-  const long e = (blockIdx.x * 256L + threadIdx.x) * 4;
-  if (e >= len) return;
+  // (dst row, column chunk) folded into grid.x: no 65535-row limit of grid.y (the MLM gather backward has D = B * L rows)
+  const int d = blockIdx.x / chunks;
+  const long e = ((long)(blockIdx.x % chunks) * 256L + threadIdx.x) * 4;
   float4 acc{0.f, 0.f, 0.f, 0.f};
-  for (int w = 0; w < nw; ++w) {
-    uint32_t bits = bm[w];
-    while (bits) {
-      const int r = (w << 5) + __builtin_ctz(bits);
-      bits &= bits - 1;
-      const float4 v = *reinterpret_cast<const float4*>(src + (long)r * len + e);
-      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+  for (int r0 = 0; r0 < R; r0 += SCATTER_MAX_R) {
+    const int rn = min(SCATTER_MAX_R, R - r0), nw = (rn + 31) >> 5;
+    __syncthreads();                                  // the previous pass's bitmap has been read by everyone
+    for (int w = threadIdx.x; w < nw; w += 256) bm[w] = 0u;
+    __syncthreads();
+    for (int r = threadIdx.x; r < rn; r += 256)
+      if (idx[r0 + r] == d) atomicOr(&bm[r >> 5], 1u << (r & 31));
+    __syncthreads();
+    if (e < len) {
+      for (int w = 0; w < nw; ++w) {
+        uint32_t bits = bm[w];
+        while (bits) {
+          const int r = r0 + (w << 5) + __builtin_ctz(bits);
+          bits &= bits - 1;
+          const float4 v = *reinterpret_cast<const float4*>(src + (long)r * len + e);
+          acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+      }
     }
   }
-  *reinterpret_cast<float4*>(dst + (long)d * len + e) = acc;
+  if (e < len) *reinterpret_cast<float4*>(dst + (long)d * len + e) = acc;
 }
 extern "C" int x2_scatter_rows(const float* src, const int* idx, float* dst, int R, int D, long len, void* stream) {
-  X2_REQUIRE(R > 0 && R <= SCATTER_MAX_R && D > 0 && len > 0 && len % 4 == 0, "x2_scatter_rows: R=%d (<= %d) D=%d len=%ld", R, SCATTER_MAX_R, D, len);
-  hipLaunchKernelGGL(scatter_rows_kernel, dim3((int)((len / 4 + 255) / 256), D), dim3(256), 0, (hipStream_t)stream, src, idx, dst, R, len);
+  X2_REQUIRE(R > 0 && D > 0 && len > 0 && len % 4 == 0, "x2_scatter_rows: R=%d D=%d len=%ld", R, D, len);
+  const long chunks = (len / 4 + 255) / 256;
+  X2_REQUIRE(chunks * D <= 2147483647L, "x2_scatter_rows: D=%d x %ld column chunks exceed the grid", D, chunks);
+  hipLaunchKernelGGL(scatter_rows_kernel, dim3((unsigned)(chunks * D)), dim3(256), 0, (hipStream_t)stream, src, idx, dst, R, len, (int)chunks);
   return x2_check_launch("x2_scatter_rows");
 }
 

@@ -207,7 +207,8 @@ class SegmentedStep:
         # region configurations; X2VLM-large (577 image tokens: two kernels, the K/V half on the second stream) keeps it
         self.aux_auto = env_aux is None
         # bf16 payload for the gradient all-reduces (0.51 GB per step instead of 1.02 GB): the arena is cast to a static
-        # bf16 buffer, averaged there, and written back to the fp32 arena on arrival.  Off by default (parity-tested at 2 and
+        # bf16 buffer, averaged there, and written back to the fp32 arena on arrival (the AVERAGE itself is then formed in bf16: ~3 significant
+        # digits of every gradient - a precision trade, not a transport detail).  Off by default (parity-tested at 2 and
         # 8 gloo ranks; never measured on xGMI): X2_GRAD_BF16=1
         self.grad_bf16 = os.environ.get("X2_GRAD_BF16", "0") == "1"
         self._bf16_buf = {}
@@ -219,9 +220,8 @@ class SegmentedStep:
             self.reserved_cus = int(os.environ.get("NCCL_MAX_NCHANNELS", "0") or 0) if world > 1 else 0
         from ._lib import lib as _x2lib
         self._lib = _x2lib() if batch["text_ids"].is_cuda else None
-        if self._lib is not None and self.reserved_cus != self._lib.x2_tune_get(12):
-            if self._lib.x2_tune(12, self.reserved_cus) != 0:
-                raise RuntimeError("x2_tune(12, %d): %s" % (self.reserved_cus, self._lib.x2_last_error().decode()))
+        # (x2_tune(12, ...) is process-wide planning state: it is set around this step's own launches - warm-up, capture, eager runs - and put
+        # back afterwards (_reserve / _unreserve), so that other steps and plain eager calls keep their own tile plans)
         self._queue = None
         # The vision tower as a chain of stages cut at these block numbers (beit2.VisionTransformer.chunk_at): its backward
         # becomes one segment per stage, top first; the weight gradients of every stage but the lowest run as segments of
@@ -292,6 +292,7 @@ class SegmentedStep:
         self.sA.wait_stream(cur)
         side, tie, hook, rule = engine.SIDE.enabled, engine.TIE_WORD_GRAD, engine.GRAD_READY_HOOK, engine.SIDE.only_from
         engine.GRAD_READY_HOOK = None             # an accelerator's early all-reduce hook must not fire from these passes
+        prev_cus = self._reserve()
         try:
             for _ in range(max(warmup, 1)):       # eager, on the segments' own streams: caches, workspaces, allocator pools
                 self._run("eager")
@@ -299,6 +300,7 @@ class SegmentedStep:
             if enabled and os.environ.get("X2_GRAPH", "1") != "0":
                 self._capture(verbose)
         finally:
+            self._unreserve(prev_cus)
             engine.SIDE.enabled, engine.TIE_WORD_GRAD, engine.GRAD_READY_HOOK, engine.SIDE.only_from = side, tie, hook, rule
             # the warm-up / capture passes counted stage calls; an accelerator's GradientBuckets reads the counters of the NEXT
             # eager backward_step (a layer that "ran twice" loses its early all-reduce)
@@ -306,6 +308,20 @@ class SegmentedStep:
         if self.coll:
             self._agree_across_ranks(verbose)
         cur.wait_stream(self.sA)
+
+    def _reserve(self):
+        """GEMM tile plans of this step's launches leave `reserved_cus` compute units to RCCL's channel kernels (x2_tune key 12);
+        returns the previous value for _unreserve."""
+        if self._lib is None:
+            return None
+        prev = self._lib.x2_tune_get(12)
+        if prev != self.reserved_cus and self._lib.x2_tune(12, self.reserved_cus) != 0:
+            raise RuntimeError("x2_tune(12, %d): %s" % (self.reserved_cus, self._lib.x2_last_error().decode()))
+        return prev
+
+    def _unreserve(self, prev):
+        if self._lib is not None and prev is not None and prev != self.reserved_cus:
+            self._lib.x2_tune(12, prev)
 
     # ------------------------------------------------------------------ set-up
     def _plan_digest(self):
@@ -756,12 +772,14 @@ class SegmentedStep:
             eng = self.engine
             side, tie, hook, rule = eng.SIDE.enabled, eng.TIE_WORD_GRAD, eng.GRAD_READY_HOOK, eng.SIDE.only_from
             eng.GRAD_READY_HOOK = None
+            prev_cus = self._reserve()
             try:
                 self._run("eager")
                 if self.coll and self.reduce_grads and not self.defer_reduce:
                     with torch.cuda.stream(self.sA):
                         self._reduce_eager_fallback()
             finally:
+                self._unreserve(prev_cus)
                 eng.SIDE.enabled, eng.TIE_WORD_GRAD, eng.GRAD_READY_HOOK, eng.SIDE.only_from = side, tie, hook, rule
                 eng.STAGE_CALLS.clear()
         cur.wait_stream(self.sA)

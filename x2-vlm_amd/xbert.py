@@ -145,9 +145,11 @@ class BertEncoder(nn.Module):
             meta["enc_mask"] = _key_mask(enc_atts, -1e9)
             if kv_idx is None:
                 assert Bi == S, "encoder batch %d != text batch %d and no kv_idx given" % (Bi, S)
-                if enc.is_cuda and K.attn_bwd_form(L, enc.shape[1], shared_kv=True) == 2:
+                if enc.is_cuda and torch.is_grad_enabled() and (hidden.requires_grad or enc.requires_grad or self.training) \
+                        and K.attn_bwd_form(L, enc.shape[1], shared_kv=True) == 2:
                     # one text row per image (predict_bbox: xvlm.py:905-915) as the identity sharing: the backward then runs as ONE
                     # kernel per layer (attn_bwd_onepass_grouped_kernel, a workgroup per (image, head)) instead of the per-row dQ and
+                    # (only when a backward will follow: inference keeps kv_idx None and with it the forward's walk / resident kernels)
                     # dK/dV kernels - and the tail segment needs no second stream (engine.AUX.auto)
                     ident = _IDENTITY_CSR.get((S, enc.device))
                     if ident is None:
