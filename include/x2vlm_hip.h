@@ -13,7 +13,9 @@
  *   - the caller owns all memory; kernels never allocate, never synchronise the host; every call is
  *     asynchronous and ordered on the stream passed in; distinct streams may be used concurrently.
  *   - bf16 tensors are raw uint16 bit patterns; "ld*" are leading dimensions in ELEMENTS.
- *   - gradients documented as "+=" are accumulated with fp32 atomics into caller-initialised memory.
+ *   - gradients documented as "+=" are added onto caller-initialised memory; since ABI v12 no entry point the training step uses adds
+ *     with atomics (every sum has a fixed order: two runs give the same bits); the two that still can - x2_gemm_nt(colsum != NULL) and
+ *     x2_gemm_tn_grouped on its 128x128 kernel with split > 1 and no workspace - say so below.
  */
 #ifndef X2VLM_HIP_H
 #define X2VLM_HIP_H
@@ -77,8 +79,8 @@ int x2_gemm_nt_splitk(const void* A, const void* B, float* C, int M, int N, int 
  * the readable widths of dY / X rows (>= N / K, multiples of 8).  accumulate: dW += instead of dW =.
  * Contraction lengths that are all multiples of 64 run on 256x256 tiles (one workgroup per CU); split = slices of the
  * contraction per tile (0 = chosen to fill the CUs), whose partial tiles pass through ws (split * tiles256 * 65536
- * floats; ws = NULL: never split) and are added in a fixed order.  Otherwise 128x128 tiles, where split > 1 adds with
- * fp32 atomics and requires accumulate. */
+ * floats; ws = NULL: never split) and are added in a fixed order; an explicit split > 1 with a workspace takes this path whatever the tile
+ * count.  Otherwise 128x128 tiles, where split > 1 (without a workspace) adds with fp32 atomics and requires accumulate. */
 int x2_gemm_tn_grouped(const int64_t* problems, int count, int accumulate, int split, float* ws, long ws_floats,
                        void* stream);
 
@@ -184,8 +186,10 @@ int x2_relpos_bias_bwd(const void* dS, const int* inv_off, const int* inv_pos, f
  * BertEmbeddings xbert.py:205-213 (word + position + token-type 0); backward scatter-adds. */
 int x2_embed_fwd(const long* ids, const float* word, const float* pos, const float* type0, float* out, int R, int L,
                  int D, void* stream);
+/* dword[ids[r]] += g[r], dpos[r % L] += g[r], dtype0 += sum_r g[r]: every sum in a fixed order (no atomics: rows with the same token id are added in
+ * ascending r by one workgroup; position totals pass through `scratch`, min(L, R) * D floats).  D <= 4096. */
 int x2_embed_bwd(const long* ids, const float* g, float* dword, float* dpos, float* dtype0, int R, int L, int D,
-                 void* stream);
+                 float* scratch, void* stream);
 /* torch.gather of sequences / masked positions (xbert.py:1588-1589, xvlm.py:866-884) and its backward */
 int x2_gather_rows(const float* src, const int* idx, float* dst, void* dst_bf16, int R, long len, void* stream);
 /* dst[d][:] = sum of src[r][:] over idx[r] == d, all D rows of dst written (zeros where nothing points); no atomics; R <= 8192 */

@@ -5,18 +5,20 @@ on identical seeded weights, batches and injected hard negatives.
 Two sets of bounds per case:
 
 (A) against the reference's fp32 CPU run (the golden vectors: the pin).  bf16 GEMM / attention operands against fp32 ones through
-    ~36 GEMMs: each bound is ~1.3-2x the worst deviation measured on MI355X (profiles/*_parity_worst.txt), so that a regression shows:
+    ~36 GEMMs: each bound is >= 1.3x the worst deviation measured on MI355X over all 16 cases (round 6: profiles/r12c_parity_worst.txt; the step is
+    bit-reproducible run to run since that round - test_two_runs_give_the_same_bits - so the measured values are constants of the build, and the
+    margin is what a different compiler / ROCm release may move), so that a regression shows:
   losses              1e-3 relative at the configurations' own per-GPU batches (cases base_full_b64 = BASELINE.json configs[1] and
-                      large_full_b32 = configs[3]: the north-star tolerance; measured 6e-5 at B = 64); 5e-3 for the 2..8-sample toy batches, whose losses average the same per-sample
+                      large_full_b32 = configs[3]: the north-star tolerance; measured 3.1e-4 worst); 6.5e-3 for the 2..8-sample toy batches, whose losses average the same per-sample
                       bf16 operand-rounding noise over 16x fewer samples (measured 4.7e-3, tiny_video)
   activations/logits  pointwise, of the tensor's max-abs (one bf16 rounding is 2^-9 of an element; ~36 GEMMs deep): vision tokens /
-                      features 8e-3 (4.7e-3), text tokens / features 1.6e-2 (1.1e-2), ITC / MLM logits 2e-2 (1.4e-2), ITM logits
-                      2.5e-2 (1.9e-2); whole-tensor moments 1e-3 (6.3e-4); MLM log-partition 2e-4 (9.7e-5); bbox coordinates 5e-3
-                      (3.7e-3 at the real geometry, case base_region)
-  parameter grads     per-tensor norm error <= 3e-2 of max(its norm, 1e-2 x total gradient norm) (measured 2.98e-2): tensors whose
+                      features 8e-3 (4.5e-3), text tokens 1.8e-2 (1.36e-2) / features 1.6e-2 (1.07e-2), ITC logits 2.4e-2 (1.80e-2), MLM logits 2e-2 (1.35e-2), ITM logits
+                      2.5e-2 (1.59e-2); whole-tensor moments 1e-3 (7.1e-4); MLM log-partition 2e-4 (1.18e-4); bbox coordinates 5e-3
+                      (2.4e-3 at the real geometry, case base_region)
+  parameter grads     per-tensor norm error <= 3.8e-2 of max(its norm, 1e-2 x total gradient norm) (measured 2.83e-2): tensors whose
                       true gradient is ~0 by cancellation (q/k projections of saturated attention, key biases) are held to
-                      3e-4 of the total norm instead of to their own norm; small tensors stored in full: 4.5e-2 pointwise (3.0e-2);
-                      total gradient norm: 2e-3 at batch 64 (8.8e-4), 3e-3 for the other full-geometry cases (1.8e-3), 6e-3 for
+                      3.8e-4 of the total norm instead of to their own norm; small tensors stored in full: 4.5e-2 pointwise (3.24e-2);
+                      total gradient norm: 2.6e-3 at batch 64 (1.95e-3), 3e-3 for the other full-geometry cases (1.7e-3), 6e-3 for
                       X2VLM-large at batch 32 (4.0e-3: 24 + 18 layers deep), 1.2e-2 for the 32-px toy models (8.7e-3)
 
 (B) against the oracle in its OPERAND-ROUNDING-AWARE mode (oracle.xvlm_forward(round_operands=torch.bfloat16): the same fp32
@@ -41,8 +43,8 @@ from cases import CASES, forward_kwargs, make_batch, model_config, reduce_out
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 # (A) pointwise bounds per tensor against the fp32 goldens, as a fraction of its max-abs (see the table above)
-POINTWISE = dict(mlm_lse=2e-4, bbox_coord=5e-3, image_embeds=8e-3, image_feat=8e-3, text_embeds=1.6e-2, text_feat=1.6e-2,
-                 itc_logits=2e-2, mlm_logits=2e-2, itm_logits=2.5e-2)
+POINTWISE = dict(mlm_lse=2e-4, bbox_coord=5e-3, image_embeds=8e-3, image_feat=8e-3, text_embeds=1.8e-2, text_feat=1.6e-2,
+                 itc_logits=2.4e-2, mlm_logits=2e-2, itm_logits=2.5e-2)
 # (B) bounds against the operand-rounding-aware oracle
 ROUNDED = ("tiny", "tiny_region", "tiny_video", "tiny_text", "tiny_nomatch", "tiny_region_degenerate", "base_shallow",
            "base_shallow_text", "base_shallow_nomatch", "large_shallow", "base_region")
@@ -152,7 +154,7 @@ def test_step_matches_reference(case, tmp_path, synthetic):
             assert float(v) == 0.0, (k, float(v))
             continue
         # north_star's 1e-3 at the configurations' own per-GPU batches (base: 64, large: 32); 5e-3 for the toy batches
-        report.append(("loss " + k, abs(v.item() - ref) / max(abs(ref), 1e-6), 1e-3 if c["batch"] >= 32 else 5e-3))
+        report.append(("loss " + k, abs(v.item() - ref) / max(abs(ref), 1e-6), 1e-3 if c["batch"] >= 32 else 6.5e-3))
     full = case.startswith("tiny")
     acts = model_acts(model, c)
     for k in gold.files:
@@ -189,7 +191,7 @@ def test_step_matches_reference(case, tmp_path, synthetic):
         # `temp`: d loss_itc / d temp sums the B x B similarity matrix with weights of both signs amplified by 1 / temp^2 = 200 - at some
         # (weights, batch) it all but cancels (base_shallow_nomatch: 0.016 of a total norm of 22.1) and what is left is noise: held to 6e-4
         # of the total norm (measured 4.3e-4) instead of 3e-4 like the other cancellation-dominated tensors
-        report.append(("gradnorm " + name, abs(n - ref) / max(ref, (2e-2 if name == "temp" else 1e-2) * total), 3e-2))
+        report.append(("gradnorm " + name, abs(n - ref) / max(ref, (2e-2 if name == "temp" else 1e-2) * total), 3.8e-2))
     for k in gold.files:
         if k.startswith("grad/"):
             name = k[len("grad/"):]
@@ -202,7 +204,7 @@ def test_step_matches_reference(case, tmp_path, synthetic):
             report.append(("grad " + name, float(np.abs(got - ref).max() / max(np.abs(ref).max(), fl)), 4.5e-2))
     # the 42-layer X2VLM-large at batch 32 measured 4.0e-3 (profiles/r05e_parity_large_b32.txt): its own bound, 6e-3
     # ret_match_loss=False at the real geometry (round 5): two loss terms instead of three feed the total - 3.2e-3 measured, bound 5e-3
-    gtol = (2e-3 if c["batch"] >= 64 else 1.2e-2 if c["image_res"] < 64 else 6e-3 if case == "large_full_b32" else
+    gtol = (2.6e-3 if c["batch"] >= 64 else 1.2e-2 if c["image_res"] < 64 else 6e-3 if case == "large_full_b32" else
             5e-3 if not c.get("match", True) else 3e-3)
     report.append(("total_grad_norm", abs(sq ** 0.5 - total) / total, gtol))
     if case in ROUNDED and os.environ.get("X2_ROUNDED_ORACLE", "1") == "1":
@@ -221,3 +223,22 @@ def test_step_matches_reference(case, tmp_path, synthetic):
     if os.environ.get("X2_PARITY_NO_ASSERT") == "1":      # measuring run (profiles/*_parity_worst.txt): report, do not gate
         return
     assert not bad, "%d checks out of tolerance, worst: %s" % (len(bad), bad[:5])
+
+
+@pytest.mark.parametrize("case", ["base_shallow", "base_region", "tiny_video"])
+def test_two_runs_give_the_same_bits(case, tmp_path, synthetic):
+    """Run-to-run reproducibility (round 6): no accumulation of the step depends on the order in which workgroups or atomics arrive - the embedding
+    scatter, the cls-token gradient and the patch-embedding weight gradient were the last ones - so two runs of the same step from the same state
+    give bit-identical losses and gradients (eval mode, injected negatives: nothing random left)."""
+    runs = []
+    for i in range(2):
+        model, loss, c, _ = run_case(case, tmp_path / str(i), synthetic)
+        runs.append(({k: v.detach().clone() for k, v in loss.items()},
+                     {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}))
+        del model, loss
+    (l0, g0), (l1, g1) = runs
+    assert l0.keys() == l1.keys() and g0.keys() == g1.keys()
+    for k in l0:
+        assert torch.equal(l0[k], l1[k]), k
+    differ = [n for n in g0 if not torch.equal(g0[n], g1[n])]
+    assert not differ, "%d gradient tensors differ between two runs, e.g. %s" % (len(differ), differ[:5])

@@ -54,7 +54,7 @@ _SIGS = {
     "x2_relpos_bias": [P, P, P, P, P, I, I, I, I, F, P],
     "x2_relpos_bias_bwd": [P, P, P, P, I, I, I, I, I, P, I, P],
     "x2_embed_fwd": [P, P, P, P, P, I, I, I, P],
-    "x2_embed_bwd": [P, P, P, P, P, I, I, I, P],
+    "x2_embed_bwd": [P, P, P, P, P, I, I, I, P, P],
     "x2_gather_rows": [P, P, P, P, I, L, P],
     "x2_scatter_rows": [P, P, P, I, I, L, P],
     "x2_linear_f32": [P, P, P, P, P, F, I, I, I, L, L, L, L, L, I, I, P, P],

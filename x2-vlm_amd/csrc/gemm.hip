@@ -1763,7 +1763,9 @@ extern "C" int x2_gemm_tn_grouped(const int64_t* problems, int count, int accumu
     min_steps = steps_i < min_steps ? steps_i : min_steps;
   }
   // small launches (a head's single weight) stay on the 128x128 kernel: more, smaller workgroups
-  if (g_tune[5] != 2 && tiles256 < 24) big = false;
+  // (an EXPLICIT split with a workspace keeps the 256x256 kernel and its fixed-order reduction however few tiles there are: the patch-embedding
+  // weight gradient - 9 tiles, 196 steps - was the step's last atomic accumulation)
+  if (g_tune[5] != 2 && tiles256 < 24 && !(split > 1 && ws)) big = false;
   if (big) {
     int t = 0;
     for (int i = 0; i < count; ++i) { g.p[i].tile_begin = t; g.p[i].tiles_k = (g.p[i].K + 255) / 256; t += ((g.p[i].N + 255) / 256) * g.p[i].tiles_k; }

@@ -4,6 +4,7 @@
 // projection heads + F.normalize (xvlm.py:785-792), ITC / ITM / MLM cross-entropies
 // (xvlm.py:794-826, 895-899, xbert.py:1660-1661), torch.multinomial hard negatives (xvlm.py:828-857).
 #include "x2_common.h"
+#define SCATTER_MAX_R_E 8192        // rows marked per pass of the embedding backward's bitmap
 
 // ------------------------------------------------------------------------------------ embeddings
 // out[r][:] = word[ids[r]][:] + pos[r % L][:] + type0[:]      (fp32; the LayerNorm that follows is separate)
@@ -25,21 +26,57 @@ extern "C" int x2_embed_fwd(const long* ids, const float* word, const float* pos
   hipLaunchKernelGGL(embed_fwd_kernel, dim3(R), dim3(256), 0, (hipStream_t)stream, ids, word, pos, type0, out, R, L, D);
   return x2_check_launch("x2_embed_fwd");
 }
-// dword[ids[r]] += g[r] ; dpos[r % L] += g[r] ; dtype0 += g[r]   (rows ordered (sequence, position)).
-// Word rows: scatter with atomics (token ids rarely collide).  Position / type rows would be R/L-way and R-way contended
-// (3840 rows onto 30 and onto 1): they are summed down the batch by one thread per (position, 4 columns) instead, and
-// only the L per-position totals are added atomically onto the type-0 row.
+// dword[ids[r]] += g[r] ; dpos[r % L] += g[r] ; dtype0 += g[r]   (rows ordered (sequence, position)).  No atomics (round 6: every sum in a fixed order,
+// so two runs of a step give the same bits):
+//   word rows: the workgroup of row r marks every row that carries the same token id in an LDS bitmap; if r is the FIRST of them it adds the marked rows in
+//     ascending r and is the only writer of dword[ids[r]] ([CLS], [SEP], [MASK] and frequent words repeat hundreds of times per batch: the atomic form's result
+//     depended on the order those adds arrived in);
+//   position rows: one thread per (position, 4 columns) walks the batch; the per-position totals go to a small scratch row and
+//   type-0 row: one thread per 4 columns adds the L totals in ascending position.
 __global__ __launch_bounds__(256) void embed_bwd_word_kernel(const long* __restrict__ ids, const float* __restrict__ g, float* dword, int R,
                                                              int D) {
-  const int r0 = blockIdx.x * 8, r1 = min(R, r0 + 8);
-  for (int d = threadIdx.x * 4; d < D; d += 1024)
-    for (int r = r0; r < r1; ++r) {
-      const float4 v = *reinterpret_cast<const float4*>(g + (long)r * D + d);
-      float* w = dword + ids[r] * D + d;
-      atomicAdd(w, v.x); atomicAdd(w + 1, v.y); atomicAdd(w + 2, v.z); atomicAdd(w + 3, v.w);
+  __shared__ uint32_t bm[SCATTER_MAX_R_E / 32];
+  const int r = blockIdx.x;
+  const long id = ids[r];
+  float4 acc[4];                                       // D <= 4096: 4 float4 per thread
+#pragma unroll
+  for (int c = 0; c < 4; ++c) acc[c] = float4{0.f, 0.f, 0.f, 0.f};
+  bool leader = true;
+  for (int r0 = 0; r0 < R && leader; r0 += SCATTER_MAX_R_E) {
+    const int rn = min(SCATTER_MAX_R_E, R - r0), nw = (rn + 31) >> 5;
+    __syncthreads();
+    for (int w = threadIdx.x; w < nw; w += 256) bm[w] = 0u;
+    __syncthreads();
+    for (int q = threadIdx.x; q < rn; q += 256)
+      if (ids[r0 + q] == id) atomicOr(&bm[q >> 5], 1u << (q & 31));
+    __syncthreads();
+    for (int w = 0; w < nw && leader; ++w) {
+      uint32_t bits = bm[w];
+      while (bits) {
+        const int q = r0 + (w << 5) + __builtin_ctz(bits);
+        bits &= bits - 1;
+        if (q < r) { leader = false; break; }          // an earlier row carries this id: that row's workgroup does the sum
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int d = (c * 256 + threadIdx.x) * 4;
+          if (d < D) { const float4 v = *reinterpret_cast<const float4*>(g + (long)q * D + d); acc[c].x += v.x; acc[c].y += v.y; acc[c].z += v.z; acc[c].w += v.w; }
+        }
+      }
     }
+  }
+  if (!leader) return;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int d = (c * 256 + threadIdx.x) * 4;
+    if (d < D) {
+      float4* w = reinterpret_cast<float4*>(dword + id * D + d);
+      float4 o = *w;
+      o.x += acc[c].x; o.y += acc[c].y; o.z += acc[c].z; o.w += acc[c].w;
+      *w = o;
+    }
+  }
 }
-__global__ __launch_bounds__(256) void embed_bwd_pos_kernel(const float* __restrict__ g, float* dpos, float* dtype0, int R, int L, int D) {
+__global__ __launch_bounds__(256) void embed_bwd_pos_kernel(const float* __restrict__ g, float* dpos, float* tot, int R, int L, int D) {
   const int l = blockIdx.x, d = (blockIdx.y * 256 + threadIdx.x) * 4;
   if (d >= D) return;
   float4 t{0.f, 0.f, 0.f, 0.f};
@@ -50,13 +87,24 @@ __global__ __launch_bounds__(256) void embed_bwd_pos_kernel(const float* __restr
   }
   float* p = dpos + (long)l * D + d;
   p[0] += t.x; p[1] += t.y; p[2] += t.z; p[3] += t.w;          // one thread owns (l, d..d+3)
-  atomicAdd(dtype0 + d, t.x); atomicAdd(dtype0 + d + 1, t.y); atomicAdd(dtype0 + d + 2, t.z); atomicAdd(dtype0 + d + 3, t.w);
+  *reinterpret_cast<float4*>(tot + (long)l * D + d) = t;
 }
-extern "C" int x2_embed_bwd(const long* ids, const float* g, float* dword, float* dpos, float* dtype0, int R, int L, int D, void* stream) {
-  X2_REQUIRE(R > 0 && L > 0 && D % 4 == 0, "x2_embed_bwd: R=%d L=%d D=%d", R, L, D);
-  hipLaunchKernelGGL(embed_bwd_word_kernel, dim3((R + 7) / 8), dim3(256), 0, (hipStream_t)stream, ids, g, dword, R, D);
-  hipLaunchKernelGGL(embed_bwd_pos_kernel, dim3(L < R ? L : R, (D / 4 + 255) / 256), dim3(256), 0, (hipStream_t)stream, g, dpos, dtype0, R, L,
-                     D);
+__global__ __launch_bounds__(64) void embed_bwd_type_kernel(const float* __restrict__ tot, float* dtype0, int L, int D) {
+  const int d = (blockIdx.x * 64 + threadIdx.x) * 4;
+  if (d >= D) return;
+  float4 t{0.f, 0.f, 0.f, 0.f};
+  for (int l = 0; l < L; ++l) { const float4 v = *reinterpret_cast<const float4*>(tot + (long)l * D + d); t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+  float4 o = *reinterpret_cast<float4*>(dtype0 + d);
+  o.x += t.x; o.y += t.y; o.z += t.z; o.w += t.w;
+  *reinterpret_cast<float4*>(dtype0 + d) = o;
+}
+extern "C" int x2_embed_bwd(const long* ids, const float* g, float* dword, float* dpos, float* dtype0, int R, int L, int D, float* scratch,
+                            void* stream) {
+  X2_REQUIRE(R > 0 && L > 0 && D % 4 == 0 && D <= 4096 && scratch, "x2_embed_bwd: R=%d L=%d D=%d (D <= 4096, scratch of min(L, R) * D floats)", R, L, D);
+  hipLaunchKernelGGL(embed_bwd_word_kernel, dim3(R), dim3(256), 0, (hipStream_t)stream, ids, g, dword, R, D);
+  const int Lp = L < R ? L : R;
+  hipLaunchKernelGGL(embed_bwd_pos_kernel, dim3(Lp, (D / 4 + 255) / 256), dim3(256), 0, (hipStream_t)stream, g, dpos, scratch, R, L, D);
+  hipLaunchKernelGGL(embed_bwd_type_kernel, dim3((D / 4 + 63) / 64), dim3(64), 0, (hipStream_t)stream, scratch, dtype0, Lp, D);
   return x2_check_launch("x2_embed_bwd");
 }
 

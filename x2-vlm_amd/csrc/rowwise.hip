@@ -742,7 +742,7 @@ extern "C" int x2_assemble_tokens(const float* patch, const float* cls, float* x
   return x2_check_launch("x2_assemble_tokens");
 }
 
-// backward of assemble: dpatch_bf16[b*P+p][:] = dx[b][1+p][:] ; dcls[:] += sum_b dx[b][0][:]
+// backward of assemble: dpatch_bf16[b*P+p][:] = dx[b][1+p][:] ; dcls[:] += sum_b dx[b][0][:] (cls_grad_kernel below)
 __global__ __launch_bounds__(256) void assemble_tokens_bwd_kernel(const float* __restrict__ dx, bf16_t* __restrict__ dpatch,
                                                                   float* dcls, int B, int P, int D) {
   const long total = (long)B * (P + 1) * D / 4;
@@ -754,15 +754,30 @@ __global__ __launch_bounds__(256) void assemble_tokens_bwd_kernel(const float* _
     const long row = e / D;
     const int tkn = (int)(row % (P + 1)), b = (int)(row / (P + 1));
     const float4 v = *reinterpret_cast<const float4*>(dx + e);
-    if (tkn == 0) { atomicAdd(dcls + d, v.x); atomicAdd(dcls + d + 1, v.y); atomicAdd(dcls + d + 2, v.z); atomicAdd(dcls + d + 3, v.w); }
-    else *reinterpret_cast<u32x2*>(dpatch + ((long)b * P + tkn - 1) * D + d) = u32x2{pack_bf16(v.x, v.y), pack_bf16(v.z, v.w)};
+    if (tkn != 0) *reinterpret_cast<u32x2*>(dpatch + ((long)b * P + tkn - 1) * D + d) = u32x2{pack_bf16(v.x, v.y), pack_bf16(v.z, v.w)};
   }
+}
+// dcls[:] += sum_b dx[b][0][:], the B rows added in ascending b by the one thread that owns the 4 columns (round 6: was one fp32 atomic per
+// element from the kernel above - the only order-dependent sum of the vision tower's backward)
+__global__ __launch_bounds__(64) void cls_grad_kernel(const float* __restrict__ dx, float* dcls, int B, long bstride, int D) {
+  const int d = (blockIdx.x * 64 + threadIdx.x) * 4;
+  if (d >= D) return;
+  float4 t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+  for (int b = 0; b < B; ++b) {
+    const float4 v = *reinterpret_cast<const float4*>(dx + b * bstride + d);
+    t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+  }
+  float4 o = *reinterpret_cast<float4*>(dcls + d);
+  o.x += t.x; o.y += t.y; o.z += t.z; o.w += t.w;
+  *reinterpret_cast<float4*>(dcls + d) = o;
 }
 extern "C" int x2_assemble_tokens_bwd(const float* dx, void* dpatch, float* dcls, int B, int P, int D, void* stream) {
   X2_REQUIRE(B > 0 && P > 0 && D % 4 == 0, "x2_assemble_tokens_bwd: B=%d P=%d D=%d", B, P, D);
   const long total = (long)B * (P + 1) * D / 4;
   const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
   hipLaunchKernelGGL(assemble_tokens_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dx, (bf16_t*)dpatch, dcls, B, P, D);
+  hipLaunchKernelGGL(cls_grad_kernel, dim3((D / 4 + 63) / 64), dim3(64), 0, (hipStream_t)stream, dx, dcls, B, (long)(P + 1) * D, D);
   return x2_check_launch("x2_assemble_tokens_bwd");
 }
 

@@ -700,7 +700,7 @@ class VisionEncoderFn(torch.autograd.Function):
         if stem:
             dpatch = K.assemble_tokens_bwd(dx.view(B, T, D), Gs["cls_token"].view(-1))
             K.colsum_bf16(dpatch, Gs["patch_embed.proj.bias"])
-            # 36 output tiles only: split the 12k-long contraction over 8 workgroups per tile (fp32 atomics)
+            # 9 output tiles of 256 x 256 only: the 12k-long contraction in 8 slices per tile, partial tiles added in a fixed order
             K.gemm_tn_grouped([(dpatch, ctx.cols, Gs["patch_embed.proj.weight"].view(D, -1))], accumulate=True,
                               split=8 if B * P_ >= 4096 else 1)
             SIDE.join()

@@ -514,7 +514,9 @@ def embed_fwd(ids, word, pos, type_emb):
 
 def embed_bwd(ids, g, dword, dpos, dtype):
     R, L = ids.numel(), ids.shape[-1]
-    call("x2_embed_bwd", ptr(ids), ptr(g), ptr(dword), ptr(dpos), ptr(dtype), R, L, g.shape[-1])
+    D = g.shape[-1]
+    scratch = workspace(g.device, min(L, R) * D)          # per-position totals on their way to the type-0 row (fixed-order sums, no atomics)
+    call("x2_embed_bwd", ptr(ids), ptr(g), ptr(dword), ptr(dpos), ptr(dtype), R, L, D, ptr(scratch))
 
 
 def gather_rows(src, idx, row_len, want_f32=True, want_bf16=False):
