@@ -159,6 +159,24 @@ def other_configs(args):
     return res
 
 
+def with_collectives(args):
+    """The base step at ONE rank with the collectives of the N > 1 step issued for real (X2_DDP_SINGLE_RANK_COLLECTIVES=1: ITC all-gathers
+    and the per-segment gradient all-reduces over a one-rank RCCL group), by a child run of this script."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--steps", str(args.steps), "--warmup", str(args.warmup), "--graph", args.graph,
+           "--no-cpu-baseline", "--no-other-configs"]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600,
+                           env=dict(os.environ, X2_DDP_SINGLE_RANK_COLLECTIVES="1", X2_BENCH_UNPATCHED="0", X2_GRAPH_CANARY="0"))
+        d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{") and '"metric"' in l][-1])
+        return {"host_enqueue_ms_per_step": d["host_enqueue_ms_per_step"], "ms_per_step": d["ms_per_step"], "launch_mode": d["launch_mode"],
+                "collectives_per_step": d.get("collectives_per_step"),
+                "what": "the same step at one rank with every collective of the N > 1 step issued (one-rank RCCL group, "
+                        "X2_DDP_SINGLE_RANK_COLLECTIVES=1): host time to enqueue a step incl. the RCCL calls between the segments"}
+    except Exception as e:      # noqa: BLE001 - the headline line must still be printed
+        return {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -205,6 +223,13 @@ def main():
             # backward needs ~100 GB/s: well within 16 channels over 7 xGMI links.  X2_RCCL_CHANNELS / NCCL_MAX_NCHANNELS override.
             os.environ.setdefault("NCCL_MAX_NCHANNELS", os.environ.get("X2_RCCL_CHANNELS", "16"))
         dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
+    elif os.environ.get("X2_DDP_SINGLE_RANK_COLLECTIVES", "0") == "1":
+        # one rank, but every collective of the N > 1 step issued for real (a one-rank RCCL group: AVG / all-gather over one rank are the
+        # identity): the only multi-GPU cost a 1-GPU box can measure is the host time of those ~40 calls between the segments
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 2000))
+        os.environ.setdefault("NCCL_MAX_NCHANNELS", os.environ.get("X2_RCCL_CHANNELS", "16"))
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
 
     K = importlib.import_module("x2-vlm_amd.kernels")
     mp = importlib.import_module("x2-vlm_amd.model_pretrain")
@@ -482,6 +507,7 @@ def main():
                "ms_per_step_spread": {"min": round(per_step[0], 2), "median": round(per_step[len(per_step) // 2], 2),
                                       "max": round(per_step[-1], 2), "how": "HIP events between consecutive timed steps"},
                "host_enqueue_ms_per_step": round(1e3 * host_dt / args.steps, 2), "launch_mode": runner.mode,
+               **({"collectives_per_step": runner.messages} if getattr(runner, "coll", False) else {}),
                "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
                "config": {"workload": conf["workload"] + ", %d-token captions, 12 masks" % args.seq_len, "name": args.config,
@@ -506,9 +532,11 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(conf)
         if world == 1 and args.config == "base" and not (args.no_other_configs or args.tiny or args.serialize or args.eval_mode):
+            if args.graph == "segments" and use_graph:
+                out["roofline"]["also"]["host_enqueue_ms_with_collectives"] = with_collectives(args)
             out["other_configs"] = other_configs(args)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

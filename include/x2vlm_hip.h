@@ -25,7 +25,7 @@ extern "C" {
 #endif
 
 const char* x2_last_error(void);
-int x2_abi_version(void);          /* == 12 */
+int x2_abi_version(void);          /* == 13 */
 int x2_device_cus(void);           /* compute units of the current HIP device, 0 if none */
 int x2_tune(int key, int value);   /* kernel-variant knobs for probes/ and tests (0 = automatic); keys listed in csrc/gemm.hip.
                                     * key 12 = compute units every tile plan leaves to RCCL's channel kernels (world > 1);
@@ -111,12 +111,16 @@ typedef struct X2AttnArgs {
   int grid_nx, grid_ny, grid_nz, grid_map;           /* written by the library (XCD-aware workgroup order of the bias kernels): pass 0 */
   int phase;                                         /* x2_attn_bwd: 0 = dQ (+dS, Delta) then dK/dV; 1 = the dQ half only; 2 = the dK/dV half only
                                                         (reads the Delta a phase-1 call wrote): the K/V-side gradients on another stream */
+  float* ws; long ws_floats;                         /* x2_attn_bwd (ABI v13): fp32 scratch of B * H * ceil(Lq / 128) * 8192 floats for the long one-pass
+                                                        backward (form 3 below), or NULL / smaller: such a geometry runs the two kernels */
 } X2AttnArgs;
 int x2_attn_fwd(const X2AttnArgs* args, void* stream);
 int x2_attn_bwd(const X2AttnArgs* args, void* stream);   /* dQ (+dS, Delta) then dK/dV; no atomics */
 /* Which backward a phase-0 x2_attn_bwd call with these arguments runs: 0 = two kernels (dQ, then dK/dV), 1 = one pass, one workgroup per
  * (sequence, head) (64 < Lq, Lk <= 208, no K/V sharing, no probability dropout: the BEiT-2 blocks, beit2.py:135-159), 2 = one pass, one
- * workgroup per (shared K/V batch, head) (Lq <= 128, Lk <= 208, no bias: the cross-attention of xbert.py:322-415).  A caller that
+ * workgroup per (shared K/V batch, head) (Lq <= 128, Lk <= 208, no bias: the cross-attention of xbert.py:322-415), 3 = one pass, one workgroup
+ * per (sequence, head) that walks 256-key parts x 128-query chunks (208 < Lq <= 640, 208 < Lk <= 768, no K/V sharing, no probability
+ * dropout, `ws` given, biasT_ld >= 128 ceil(Lq / 128): the BEiT-2 blocks of X2VLM-large at 384 px, N = 577).  A caller that
  * would put the dK/dV half (phase 2) on another stream asks first: in one pass there is no such half. */
 int x2_attn_bwd_one_pass(const X2AttnArgs* args);
 

@@ -330,7 +330,7 @@ def attn_ref(q, k, v, scale, add):
     return O.attention_core(q, k, v, scale, add)
 
 
-def run_attention(K, B, Bkv, H, Lq, Lk, use_bias, use_mask, kv_map, seed, bias_log2=False):
+def run_attention(K, B, Bkv, H, Lq, Lk, use_bias, use_mask, kv_map, seed, bias_log2=False, narrow_biasT=False):
     d = 64
     qh = bf(rnd(B, Lq, H * d, seed=seed)); kh = bf(rnd(Bkv, Lk, H * d, seed=seed + 1)); vh = bf(rnd(Bkv, Lk, H * d, seed=seed + 2))
     doh = bf(rnd(B, Lq, H * d, seed=seed + 3))
@@ -356,7 +356,8 @@ def run_attention(K, B, Bkv, H, Lq, Lk, use_bias, use_mask, kv_map, seed, bias_l
     out.backward(doh.float().view(B, Lq, H, d).permute(0, 2, 1, 3))
     ref_out = out.permute(0, 2, 1, 3).reshape(B, Lq, H * d)
     # ---- HIP ----
-    Lkp, Lqp = K.round_up(Lk, 64), K.round_up(Lq, 64)
+    # (transposed bias: whole 128-query chunks for the long one-pass backward, as round_up(577, 64) = 640 happens to be; `narrow_biasT` keeps 64)
+    Lkp, Lqp = K.round_up(Lk, 64), K.round_up(Lq, 128 if Lq > 208 and not narrow_biasT else 64)
     kw = {}
     if use_bias:
         bp = torch.zeros(H, Lq, Lkp); bp[:, :, :Lk] = bias
@@ -410,7 +411,11 @@ def run_attention(K, B, Bkv, H, Lq, Lk, use_bias, use_mask, kv_map, seed, bias_l
     # the same inputs - against the oracle as well, and the two forms against each other (same products, different summation
     # order in Delta and in the accumulators: bf16-rounding-sized differences)
     form = backward(ask_form=True)
-    assert form == (1 if kv_map is None and 64 < Lq <= 208 and 64 < Lk <= 208 else 2 if kv_map is not None and Lq <= 128 and Lk <= 208 else 0)
+    # ... and 208 < L (<= 640 queries, <= 768 keys) without K/V sharing: form 3, one workgroup per (sequence, head) walking 256-key parts x 128-query
+    # chunks (X2VLM-large, N = 577), when the transposed bias covers whole chunks
+    long_ok = kv_map is None and 208 < Lq <= 640 and 208 < Lk <= 768 and (not use_bias or Lqp >= 128 * ((Lq + 127) // 128))
+    assert form == (1 if kv_map is None and 64 < Lq <= 208 and 64 < Lk <= 208 else 2 if kv_map is not None and Lq <= 128 and Lk <= 208
+                    else 3 if long_ok else 0)
     one_pass = form != 0
     lib = importlib.import_module("x2-vlm_amd._lib").lib()
     if one_pass:
@@ -522,9 +527,22 @@ def test_attention_one_pass_forms_agree_under_dropout(K):
 
 
 def test_attention_long_keys(K):
-    """N = 577 (384 px) exercises many key tiles of the online softmax."""
+    """N = 577 (384 px) exercises many key tiles of the online softmax - and, in the backward, the long one-pass kernel (three 256-key
+    parts x five 128-query chunks, dQ partials through the workspace) against the oracle and against the dQ + dK/dV pair."""
     run_attention(K, B=1, Bkv=1, H=2, Lq=577, Lk=577, use_bias=True, use_mask=False, kv_map=None, seed=400)
     run_attention(K, B=2, Bkv=2, H=4, Lq=577, Lk=577, use_bias=True, use_mask=False, kv_map=None, seed=410, bias_log2=True)
+
+
+def test_attention_long_one_pass_backward_shapes(K):
+    """attn_bwd_onepass_long_kernel beyond N = 577: the largest geometry it takes (640 x 768: full parts and chunks), one part + a ragged second
+    one (one strip: seven waves idle in it), more queries than keys and the reverse, no bias (no dS stream) with a mask, a whole batch of heads
+    through the XCD-aware block order - and a transposed bias that stops short of whole chunks (the pair runs, form 0)."""
+    run_attention(K, B=1, Bkv=1, H=2, Lq=640, Lk=768, use_bias=True, use_mask=True, kv_map=None, seed=700)
+    run_attention(K, B=2, Bkv=2, H=2, Lq=272, Lk=272, use_bias=True, use_mask=False, kv_map=None, seed=710, bias_log2=True)
+    run_attention(K, B=1, Bkv=1, H=3, Lq=500, Lk=230, use_bias=False, use_mask=True, kv_map=None, seed=720)
+    run_attention(K, B=2, Bkv=2, H=2, Lq=215, Lk=600, use_bias=True, use_mask=False, kv_map=None, seed=730, bias_log2=True)
+    run_attention(K, B=5, Bkv=5, H=16, Lq=577, Lk=577, use_bias=True, use_mask=False, kv_map=None, seed=740, bias_log2=True)
+    run_attention(K, B=1, Bkv=1, H=2, Lq=300, Lk=300, use_bias=True, use_mask=False, kv_map=None, seed=750, narrow_biasT=True)
 
 
 @pytest.mark.parametrize("rows,D,period", [(37, 768, 0), (788, 768, 0), (4 * 196, 768, 196), (50, 128, 0), (9, 1536, 0)])

@@ -51,6 +51,8 @@ struct AttnArgs {
   int grid_nx, grid_ny, grid_nz, grid_map;
   int phase;                           // x2_attn_bwd: 0 = dQ (+ dS, Delta) then dK / dV; 1 = dQ (+ dS, Delta) only; 2 = dK / dV only (Delta as a
                                        // phase-1 call left it): lets a caller put the K/V-side gradients on another stream
+  float* ws; long ws_floats;           // x2_attn_bwd: fp32 scratch for attn_bwd_onepass_long_kernel's dQ partials (B * H * ceil(Lq / 128) * 8192 floats),
+                                       // or NULL / too small: the dQ + dK/dV pair runs instead
 };
 
 // Workgroup -> (tile, head, batch).  grid_map == 0: the 3-D grid as launched.  grid_map = C > 0 (the kernels with a relative-
@@ -1518,6 +1520,259 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_onepass_grouped_kernel(AttnAr
   }
 }
 
+// ------------------------------------------------------------------------------------------ backward in one pass, long sequences
+// Self-attention with 208 < Lq <= 640, 208 < Lk <= 768 and no K/V sharing (the BEiT-2 blocks of X2VLM-large at 384 px: N = 577): a
+// (sequence, head) no longer fits a workgroup's registers + LDS at once, so ONE eight-wave workgroup per (sequence, head) walks it as
+//   for every key PART (256 keys = 16 strips, two per wave: K / V fragments in registers, dK / dV accumulators, K rows in LDS)
+//     for every query CHUNK (128 queries = 8 strips: Q / dO staged into LDS, Delta recomputed from dO . O on the way)
+//       phase A: every wave forms S, P, dP, dS of its key strips x the chunk's query strips ONCE (the tile arithmetic of
+//                attn_bwd_onepass_kernel), accumulates dK / dV and leaves dS in LDS as bf16 [query strip][key][16 queries]
+//       phase B: wave w forms the chunk's query strip w: dQ += K^T . dS^T over the part's keys; the dS fragments it reads are also the
+//                HBM dS stream of the bias gradient
+// dQ of a strip is a sum over the parts: it travels between parts as an fp32 partial in the caller's workspace (`ws`: [B][H][chunks][8
+// strips][4][64 lanes][4] floats - written and read back by the SAME lane, added in part order: deterministic, no atomics) and leaves as
+// bf16 after the last part.  5 matrix products per score instead of the 7 of the dQ + dK/dV pair, scores exponentiated once.
+// LDS (129 KB): dO chunk | Q chunk | K part (256 rows; strips the part does not have: zeros) | dS blocks (8 x 8 KB) | LSE | Delta.
+#define LP_STRIPS 8
+#define LP_ROWS (LP_STRIPS * 16)
+#define LP_KEYS 256
+#define LP_BLK (LP_KEYS * 32)
+#define LP_DO 0
+#define LP_Q (LP_ROWS * 128)
+#define LP_K (2 * LP_ROWS * 128)
+#define LP_DS (LP_K + LP_KEYS * 128)
+#define LP_LSE (LP_DS + LP_STRIPS * LP_BLK)
+#define LP_DEL (LP_LSE + LP_ROWS * 4)
+#define LP_BYTES (LP_DEL + LP_ROWS * 4)
+#define LP_MAX_LQ 640
+#define LP_MAX_LK 768
+template <bool BL2>
+__global__ __launch_bounds__(512, 2) void attn_bwd_onepass_long_kernel(AttnArgs a) {
+  __shared__ __attribute__((aligned(16))) char smem[LP_BYTES];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fi = lane & 15, g = lane >> 4;
+  int bx_, h, b;
+  if (!attn_block(a, bx_, h, b)) return;
+  const float sc2 = a.scale * LOG2E;
+  const int nsq = (a.Lq + 15) >> 4, nsk = (a.Lk + 15) >> 4;
+  const int nchunk = (nsq + LP_STRIPS - 1) / LP_STRIPS, npart = (nsk + 15) >> 4;
+  const uint32_t lbase = lds_addr(smem), dotile = lbase + LP_DO, qtile = lbase + LP_Q, ktile = lbase + LP_K;
+  float* lse_s = reinterpret_cast<float*>(smem + LP_LSE);
+  float* del_s = reinterpret_cast<float*>(smem + LP_DEL);
+  float* wsq = a.ws + (((long)b * a.H + h) * nchunk * LP_STRIPS + wave) * 1024 + lane * 4;      // + chunk * 8192 + dt * 256
+  const int r4 = fi >> 2, c4 = fi & 3;
+
+  for (int part = 0; part < npart; ++part) {
+    const int nkp = min(16, nsk - part * 16);                      // key strips of this part
+    const int ng = wave + 8 < nkp ? 2 : (wave < nkp ? 1 : 0);
+    int key[2]; bool kok[2];
+    bf16x8 kf[2][2], vf[2][2];
+#pragma unroll
+    for (int gk = 0; gk < 2; ++gk) {
+      const int k0 = (part * 16 + wave + 8 * gk) * 16;
+      kok[gk] = k0 + fi < a.Lk;
+      key[gk] = min(k0 + fi, a.Lk - 1);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        kf[gk][ks] = *reinterpret_cast<const bf16x8*>(a.K + b * a.k_bs + (long)key[gk] * a.k_rs + h * HD + ks * 32 + g * 8);
+        vf[gk][ks] = *reinterpret_cast<const bf16x8*>(a.V + b * a.v_bs + (long)key[gk] * a.v_rs + h * HD + ks * 32 + g * 8);
+      }
+    }
+    // (the barrier that ended the previous part's last chunk: nobody reads the K image or the dS blocks any more)
+#pragma unroll
+    for (int gk = 0; gk < 2; ++gk) {
+      const int row = (wave + 8 * gk) * 16 + fi;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+        *reinterpret_cast<bf16x8*>(smem + LP_K + row * 128 + (((ks * 4 + g) ^ (row & 7)) << 4)) = gk < ng ? kf[gk][ks] : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    }
+    if (nkp < 16)        // block-uniform: key rows no wave writes in this part still hold the previous part's dS
+      for (int o = tid * 16; o < LP_STRIPS * LP_BLK; o += 512 * 16) *reinterpret_cast<u32x4*>(smem + LP_DS + o) = u32x4{0u, 0u, 0u, 0u};
+    f32x4 dk[2][4], dv[2][4];
+#pragma unroll
+    for (int gk = 0; gk < 2; ++gk)
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) { dk[gk][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[gk][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+    for (int c = 0; c < nchunk; ++c) {
+      const int nvs = min(LP_STRIPS, nsq - c * LP_STRIPS);         // query strips of this chunk
+      const int q0c = c * LP_ROWS;
+      {
+        // stage the chunk (rows past Lq: copies of the last row - finite - with LSE = +1e30: P = dS = 0), Delta on the way
+        u32x4 rq[2], rdo[2], ro[2];
+        float rl[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int cc = tid + i * 512, row = cc >> 3, ch = cc & 7, q = q0c + row, gr = min(q, a.Lq - 1);
+          rq[i] = *reinterpret_cast<const u32x4*>(a.Q + b * a.q_bs + (long)gr * a.q_rs + h * HD + ch * 8);
+          rdo[i] = *reinterpret_cast<const u32x4*>(a.dO + b * a.do_bs + (long)gr * a.do_rs + h * HD + ch * 8);
+          ro[i] = *reinterpret_cast<const u32x4*>(a.O + b * a.o_bs + (long)gr * a.o_rs + h * HD + ch * 8);
+          rl[i] = (ch == 0 && q < a.Lq) ? a.LSE[((long)b * a.H + h) * a.Lq + q] : 1e30f;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int cc = tid + i * 512, row = cc >> 3, ch = cc & 7, q = q0c + row;
+          float dl = 0.f;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) dl += bf_lo(rdo[i][e]) * bf_lo(ro[i][e]) + bf_hi(rdo[i][e]) * bf_hi(ro[i][e]);
+          dl += __shfl_xor(dl, 1, 64); dl += __shfl_xor(dl, 2, 64); dl += __shfl_xor(dl, 4, 64);
+          const int off = row * 128 + ((ch ^ (row & 7)) << 4);
+          *reinterpret_cast<u32x4*>(smem + LP_Q + off) = rq[i];
+          *reinterpret_cast<u32x4*>(smem + LP_DO + off) = rdo[i];
+          if (ch == 0) {
+            const bool ok = q < a.Lq;
+            lse_s[row] = rl[i];
+            del_s[row] = ok ? dl : 0.f;
+            if (ok && part == 0) a.Delta[((long)b * a.H + h) * a.Lq + q] = dl;
+          }
+        }
+      }
+      __syncthreads();
+      // ---- phase A (attn_bwd_onepass_kernel's, on this part's keys and this chunk's queries)
+      auto phase_a = [&](auto ng_) {
+        constexpr int NG = decltype(ng_)::value;
+        float mk[NG];
+#pragma unroll
+        for (int gk = 0; gk < NG; ++gk) mk[gk] = (a.mask ? a.mask[(long)b * a.mask_ld + key[gk]] : 0.f) * LOG2E;
+        const int last_pair = ((nvs + 1) >> 1) - 1;
+        float4 bnext[NG][2];
+        auto load_bias = [&](int s) {         // columns < 128 * nchunk <= biasT_ld (checked by the entry point)
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int gk = 0; gk < NG; ++gk) {
+              bnext[gk][t] = float4{0.f, 0.f, 0.f, 0.f};
+              if (BL2 || a.biasT) bnext[gk][t] = *reinterpret_cast<const float4*>(a.biasT + ((long)h * a.Lk + key[gk]) * a.biasT_ld + q0c + 32 * s + 16 * t + g * 4);
+            }
+        };
+        load_bias(0);
+        auto pair = [&](int s, auto full_) {
+          constexpr int NTQ = decltype(full_)::value ? 2 : 1;
+          float4 btv[NG][2];
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int gk = 0; gk < NG; ++gk) {
+              btv[gk][t] = bnext[gk][t];
+              if (!BL2 && (a.dbg & 16)) { btv[gk][t].x *= LN2; btv[gk][t].y *= LN2; btv[gk][t].z *= LN2; btv[gk][t].w *= LN2; }
+            }
+          load_bias(min(s + 1, last_pair));
+          f32x4 p[NG][2], ds[NG][2];
+#pragma unroll
+          for (int gk = 0; gk < NG; ++gk) { p[gk][1] = f32x4{0.f, 0.f, 0.f, 0.f}; ds[gk][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+          for (int t = 0; t < NTQ; ++t) {
+            f32x4 sa[NG], dp[NG];
+#pragma unroll
+            for (int gk = 0; gk < NG; ++gk) { sa[gk] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[gk] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+              const bf16x8 qfr = frag_rows(qtile, 32 * s + 16 * t + fi, ks * 4 + g), dofr = frag_rows(dotile, 32 * s + 16 * t + fi, ks * 4 + g);
+#pragma unroll
+              for (int gk = 0; gk < NG; ++gk) {
+                sa[gk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qfr, kf[gk][ks], sa[gk], 0, 0, 0);
+                dp[gk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dofr, vf[gk][ks], dp[gk], 0, 0, 0);
+              }
+            }
+            const float4 ls = *reinterpret_cast<const float4*>(lse_s + 32 * s + 16 * t + g * 4);
+            const float4 dl = *reinterpret_cast<const float4*>(del_s + 32 * s + 16 * t + g * 4);
+            const float lsv[4] = {ls.x, ls.y, ls.z, ls.w}, dlv[4] = {dl.x, dl.y, dl.z, dl.w};
+#pragma unroll
+            for (int gk = 0; gk < NG; ++gk) {
+              const float bbv[4] = {btv[gk][t].x, btv[gk][t].y, btv[gk][t].z, btv[gk][t].w};
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const float x = BL2 ? fmaf(sa[gk][r], sc2, bbv[r]) : fmaf(sa[gk][r], sc2, fmaf(bbv[r], LOG2E, mk[gk]));
+                const float pv = fast_exp2(fminf(x, 1e29f) - lsv[r]);
+                p[gk][t][r] = pv;
+                ds[gk][t][r] = pv * (dp[gk][r] - dlv[r]);
+              }
+            }
+          }
+          bf16x8 pf[NG], dsf[NG];
+#pragma unroll
+          for (int gk = 0; gk < NG; ++gk) {
+            pf[gk] = pack8(p[gk][0], p[gk][1]);
+            dsf[gk] = pack8(ds[gk][0], ds[gk][1]);
+            const u32x4 w = __builtin_bit_cast(u32x4, dsf[gk]);
+            char* blk = smem + LP_DS + (2 * s) * LP_BLK + ((wave + 8 * gk) * 16 + fi) * 32 + g * 8;
+            *reinterpret_cast<u32x2*>(blk) = kok[gk] ? u32x2{w[0], w[1]} : u32x2{0u, 0u};
+            if (NTQ == 2) *reinterpret_cast<u32x2*>(blk + LP_BLK) = kok[gk] ? u32x2{w[2], w[3]} : u32x2{0u, 0u};
+          }
+#pragma unroll
+          for (int dt = 0; dt < 4; ++dt) {
+            const bf16x8 dotr = frag_cols(dotile, s, dt, lane), qtr = frag_cols(qtile, s, dt, lane);
+#pragma unroll
+            for (int gk = 0; gk < NG; ++gk) {
+              dv[gk][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dotr, pf[gk], dv[gk][dt], 0, 0, 0);
+              dk[gk][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qtr, dsf[gk], dk[gk][dt], 0, 0, 0);
+            }
+          }
+        };
+        for (int s = 0; s < (nvs >> 1); ++s) pair(s, std::true_type{});
+        if (nvs & 1) pair(nvs >> 1, std::false_type{});
+      };
+      if (ng == 2) phase_a(std::integral_constant<int, 2>{});
+      else if (ng == 1) phase_a(std::integral_constant<int, 1>{});
+      __syncthreads();
+      // ---- phase B: query strip `wave` of the chunk over the part's keys
+      if (wave < nvs) {
+        const int q = q0c + wave * 16 + fi;
+        const int kend = min(nsk * 16, a.ds_ld);
+        // the partial dQ of this strip as the earlier parts left it (this very lane wrote it: program order makes it visible), requested
+        // now and added behind the products (held through phase A it spilled)
+        float4 prev[4];
+        f32x4 dq[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+          prev[dt] = float4{0.f, 0.f, 0.f, 0.f};
+          if (part > 0) prev[dt] = *reinterpret_cast<const float4*>(wsq + (long)c * (LP_STRIPS * 1024) + dt * 256);
+        }
+        for (int s = 0; s < ((nkp + 1) >> 1); ++s) {
+          const uint32_t a0 = lbase + LP_DS + wave * LP_BLK + (32 * s + 4 * g + r4) * 32 + c4 * 8;
+          const bf16x8 dsf = lds_read_tr_frag(a0, a0 + 16 * 32);
+          if (a.dS && q < a.Lq) {          // the dS stream of the bias gradient, as attn_bwd_onepass_kernel writes it (columns < min(16 ceil(Lk / 16), ds_ld))
+            const u32x4 w = __builtin_bit_cast(u32x4, dsf);
+            const int kc = part * LP_KEYS + 32 * s + 4 * g;
+            bf16_t* dsp = a.dS + (((long)b * a.H + h) * a.Lq + q) * a.ds_ld + kc;
+            if (kc < kend) *reinterpret_cast<u32x2*>(dsp) = u32x2{w[0], w[1]};
+            if (kc + 16 < kend) *reinterpret_cast<u32x2*>(dsp + 16) = u32x2{w[2], w[3]};
+          }
+#pragma unroll
+          for (int dt = 0; dt < 4; ++dt) dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_cols(ktile, s, dt, lane), dsf, dq[dt], 0, 0, 0);
+        }
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) { dq[dt][0] += prev[dt].x; dq[dt][1] += prev[dt].y; dq[dt][2] += prev[dt].z; dq[dt][3] += prev[dt].w; }
+        if (part + 1 < npart) {
+#pragma unroll
+          for (int dt = 0; dt < 4; ++dt)
+            *reinterpret_cast<float4*>(wsq + (long)c * (LP_STRIPS * 1024) + dt * 256) = float4{dq[dt][0], dq[dt][1], dq[dt][2], dq[dt][3]};
+        } else if (q < a.Lq) {
+          bf16_t* op = a.dQ + b * a.dq_bs + (long)q * a.dq_rs + h * HD + g * 4;
+#pragma unroll
+          for (int dt = 0; dt < 4; ++dt)
+            *reinterpret_cast<u32x2*>(op + dt * 16) = u32x2{pack_bf16(dq[dt][0] * a.scale, dq[dt][1] * a.scale),
+                                                             pack_bf16(dq[dt][2] * a.scale, dq[dt][3] * a.scale)};
+        }
+      }
+      __syncthreads();                 // the next chunk overwrites Q / dO / LSE / Delta, its phase A the dS blocks; the next part the K image
+    }
+#pragma unroll
+    for (int gk = 0; gk < 2; ++gk) {
+      if (gk >= ng || !kok[gk]) continue;
+      bf16_t* kp = a.dK + b * a.dk_bs + (long)key[gk] * a.dk_rs + h * HD + g * 4;
+      bf16_t* vp = a.dV + b * a.dv_bs + (long)key[gk] * a.dv_rs + h * HD + g * 4;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        *reinterpret_cast<u32x2*>(kp + dt * 16) = u32x2{pack_bf16(dk[gk][dt][0] * a.scale, dk[gk][dt][1] * a.scale),
+                                                         pack_bf16(dk[gk][dt][2] * a.scale, dk[gk][dt][3] * a.scale)};
+        *reinterpret_cast<u32x2*>(vp + dt * 16) = u32x2{pack_bf16(dv[gk][dt][0], dv[gk][dt][1]), pack_bf16(dv[gk][dt][2], dv[gk][dt][3])};
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------ C ABI
 // `args` is the AttnArgs struct laid out as 8-byte slots (pointers, longs) followed by ints/floats;
 // the Python side fills it through ctypes.Structure with the same field order.
@@ -1575,7 +1830,7 @@ extern "C" int x2_attn_fwd(const AttnArgs* pa, void* stream) {
   return x2_check_launch("x2_attn_fwd");
 }
 
-// Which backward runs for these arguments: 0 = the dQ + dK/dV pair, 1 = attn_bwd_onepass_kernel (one sequence per K/V batch, 64 < Lq,
+// Which backward runs for these arguments (3: see attn_bwd_one_pass_long below): 0 = the dQ + dK/dV pair, 1 = attn_bwd_onepass_kernel (one sequence per K/V batch, 64 < Lq,
 // Lk <= 208, no probability dropout), 2 = attn_bwd_onepass_grouped_kernel (rows sharing K/V through the CSR, Lq <= 128, Lk <= 208, no
 // bias).  Only a phase-0 call can take the one-pass forms; x2_tune(14, 1) switches them off (A/B measurements, tests of both forms).
 static int attn_bwd_one_pass(const AttnArgs& a) {
@@ -1585,9 +1840,24 @@ static int attn_bwd_one_pass(const AttnArgs& a) {
   if (a.seq_off && a.seq_ids && a.kv_idx && a.Lq <= XP_ROWS && !a.bias && !a.dS) return 2;
   return 0;
 }
+// 3 = attn_bwd_onepass_long_kernel (one sequence per K/V batch, 208 < Lq <= 640, 208 < Lk <= 768, no probability dropout, a workspace for
+// the dQ partials, the transposed bias padded to whole 128-query chunks)
+static int attn_bwd_one_pass_long(const AttnArgs& a) {
+  if (a.phase != 0 || x2_tune_get(14) == 1 || a.Lk <= OP_ROWS || a.Lq <= OP_ROWS || a.Lk > LP_MAX_LK || a.Lq > LP_MAX_LQ) return 0;
+  if ((a.do_rs % 8 | a.do_bs % 8 | a.o_rs % 8 | a.o_bs % 8) != 0) return 0;
+  if (a.seq_off || a.kv_idx || a.B != a.Bkv || a.drop.thr16) return 0;
+  const long chunks = (a.Lq + LP_ROWS - 1) / LP_ROWS;
+  if (!a.ws || a.ws_floats < (long)a.B * a.H * chunks * LP_STRIPS * 1024) return 0;
+  if (a.biasT && a.biasT_ld < chunks * LP_ROWS) return 0;
+  return 3;
+}
 // for callers that place the K/V-side half on another stream only when there is one (engine.py): 1 / 2 as above when a phase-0 call
 // with these arguments runs in one pass
-extern "C" int x2_attn_bwd_one_pass(const AttnArgs* pa) { AttnArgs a = *pa; a.phase = 0; return attn_bwd_one_pass(a); }
+extern "C" int x2_attn_bwd_one_pass(const AttnArgs* pa) {
+  AttnArgs a = *pa; a.phase = 0;
+  const int f = attn_bwd_one_pass(a);
+  return f ? f : attn_bwd_one_pass_long(a);
+}
 
 extern "C" int x2_attn_bwd(const AttnArgs* pa, void* stream) {
   AttnArgs a = *pa;
@@ -1613,6 +1883,11 @@ extern "C" int x2_attn_bwd(const AttnArgs* pa, void* stream) {
     if (bl2) attn_launch(attn_bwd_onepass_kernel<true>, a, 1, a.H, a.B, 512, xm, st);
     else attn_launch(attn_bwd_onepass_kernel<false>, a, 1, a.H, a.B, 512, xm, st);
     return x2_check_launch("x2_attn_bwd(one pass)");
+  }
+  if (attn_bwd_one_pass_long(a) == 3) {
+    if (bl2) attn_launch(attn_bwd_onepass_long_kernel<true>, a, 1, a.H, a.B, 512, xm, st);
+    else attn_launch(attn_bwd_onepass_long_kernel<false>, a, 1, a.H, a.B, 512, xm, st);
+    return x2_check_launch("x2_attn_bwd(one pass, long)");
   }
   if (a.phase == 2) { /* the dQ half ran in an earlier call */ }
   else if (a.seq_off && a.Lk <= 256 && !a.bias && !a.dS)      // rows sharing K/V: one workgroup per (K/V batch, head)

@@ -307,6 +307,11 @@ def attn_bwd(q, k, v, o, do, B, Bkv, H, Lq, Lk, scale, lse, delta, dq, dk, dv, d
     if dS is not None:
         assert dS.dtype == BF16 and dS.is_contiguous() and dS.shape[:3] == (B, H, Lq)
         a.dS, a.ds_ld = dS.data_ptr(), dS.shape[3]
+    if phase == 0 and Lq > 208 and Lk > 208 and a.kv_idx is None and not a.drop_thr16:
+        # long self-attention (X2VLM-large, N = 577): the one-pass kernel carries the dQ of a query strip from key part to key part as an
+        # fp32 partial in this scratch (include/x2vlm_hip.h, X2AttnArgs.ws)
+        ws = workspace(lse.device, B * H * ((Lq + 127) // 128) * 8192)
+        a.ws, a.ws_floats = ws.data_ptr(), ws.numel()
     if ask_form:
         return _lib.lib().x2_attn_bwd_one_pass(C.byref(a))
     call("x2_attn_bwd", C.byref(a))
