@@ -29,7 +29,7 @@ int x2_abi_version(void);          /* == 13 */
 int x2_device_cus(void);           /* compute units of the current HIP device, 0 if none */
 int x2_tune(int key, int value);   /* kernel-variant knobs for probes/ and tests (0 = automatic); keys listed in csrc/gemm.hip.
                                     * key 12 = compute units every tile plan leaves to RCCL's channel kernels (world > 1);
-                                    * key 14 = 1: attention backward as two kernels even where the one-pass kernel applies;
+                                    * key 14 = 1: attention backward as two kernels even where a one-pass kernel applies (3: only the long form 3 off);
                                     * key 15 = NT ping-pong kernel (32x32x16 MFMAs): 0 automatic, 1 never, 3 .. 6 always, at 32 x value rows;
                                     * key 2 (work-skipping ablation bits) is refused unless the library was built with -DX2_PROBE */
 int x2_tune_get(int key);          /* current value of a knob, -1 for an unknown key (bench.py reports the non-default ones) */

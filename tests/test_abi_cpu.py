@@ -46,7 +46,8 @@ def test_attn_args_struct_matches_header_layout():
 def test_attention_backward_form_rules():
     """x2_attn_bwd_one_pass is a host-side query (no launch, pointers only tested for null): which geometries the one-pass backward
     kernels take - the BEiT-2 blocks (one sequence per K/V batch, 64 < N <= 208, no probability dropout), the cross-attention of rows
-    sharing K/V (Lq <= 128 per sequence, Lk <= 208) - and that x2_tune(14, 1) switches both off."""
+    sharing K/V (Lq <= 128 per sequence, Lk <= 208), long self-attention given a workspace (208 < N: up to 640 queries x 768 keys) - and that
+    x2_tune(14, 1) switches all of them off."""
     K = importlib.import_module("x2-vlm_amd.kernels")
     h = importlib.import_module("x2-vlm_amd._lib").lib()
     own = {(197, 197): 1, (208, 208): 1, (65, 65): 1, (150, 90): 1, (64, 64): 0, (30, 30): 0, (209, 209): 0, (577, 577): 0, (197, 60): 0}
@@ -57,9 +58,18 @@ def test_attention_backward_form_rules():
     for (lq, lk), form in shared.items():
         assert K.attn_bwd_form(lq, lk, shared_kv=True) == form, (lq, lk)
         assert K.attn_bwd_form(lq, lk, shared_kv=True, dropout=True) == form          # the shared-K/V kernel regenerates the masks
+    # long self-attention (X2VLM-large, N = 577): one pass when the caller hands over the workspace of the dQ partials, up to 640 queries x 768 keys
+    long_ = {(577, 577): 3, (209, 209): 3, (640, 768): 3, (300, 215): 3, (641, 577): 0, (577, 769): 0, (577, 208): 0, (208, 577): 0}
+    for (lq, lk), form in long_.items():
+        assert K.attn_bwd_form(lq, lk, workspace=True) == form, (lq, lk)
+        assert K.attn_bwd_form(lq, lk) == 0 and K.attn_bwd_form(lq, lk, workspace=True, dropout=True) == 0
+        assert K.attn_bwd_form(lq, lk, workspace=True, shared_kv=True) == 0
     try:
         assert h.x2_tune(14, 1) == 0
         assert all(K.attn_bwd_form(lq, lk) == 0 for lq, lk in own) and all(K.attn_bwd_form(lq, lk, shared_kv=True) == 0 for lq, lk in shared)
+        assert all(K.attn_bwd_form(lq, lk, workspace=True) == 0 for lq, lk in long_)
+        assert h.x2_tune(14, 3) == 0               # only the long form off
+        assert K.attn_bwd_form(577, 577, workspace=True) == 0 and K.attn_bwd_form(197, 197) == 1
     finally:
         h.x2_tune(14, 0)
     assert h.x2_tune_get(14) == 0

@@ -225,11 +225,12 @@ def test_step_matches_reference(case, tmp_path, synthetic):
     assert not bad, "%d checks out of tolerance, worst: %s" % (len(bad), bad[:5])
 
 
-@pytest.mark.parametrize("case", ["base_shallow", "base_region", "tiny_video"])
+@pytest.mark.parametrize("case", ["base_shallow", "base_region", "tiny_video", "large_shallow"])
 def test_two_runs_give_the_same_bits(case, tmp_path, synthetic):
     """Run-to-run reproducibility (round 6): no accumulation of the step depends on the order in which workgroups or atomics arrive - the embedding
     scatter, the cls-token gradient and the patch-embedding weight gradient were the last ones - so two runs of the same step from the same state
-    give bit-identical losses and gradients (eval mode, injected negatives: nothing random left)."""
+    give bit-identical losses and gradients (eval mode, injected negatives: nothing random left).  large_shallow (N = 577): the long one-pass
+    attention backward, whose dQ partials travel through a workspace in a fixed order."""
     runs = []
     for i in range(2):
         model, loss, c, _ = run_case(case, tmp_path / str(i), synthetic)

@@ -1843,7 +1843,7 @@ static int attn_bwd_one_pass(const AttnArgs& a) {
 // 3 = attn_bwd_onepass_long_kernel (one sequence per K/V batch, 208 < Lq <= 640, 208 < Lk <= 768, no probability dropout, a workspace for
 // the dQ partials, the transposed bias padded to whole 128-query chunks)
 static int attn_bwd_one_pass_long(const AttnArgs& a) {
-  if (a.phase != 0 || x2_tune_get(14) == 1 || a.Lk <= OP_ROWS || a.Lq <= OP_ROWS || a.Lk > LP_MAX_LK || a.Lq > LP_MAX_LQ) return 0;
+  if (a.phase != 0 || x2_tune_get(14) == 1 || x2_tune_get(14) == 3 || a.Lk <= OP_ROWS || a.Lq <= OP_ROWS || a.Lk > LP_MAX_LK || a.Lq > LP_MAX_LQ) return 0;
   if ((a.do_rs % 8 | a.do_bs % 8 | a.o_rs % 8 | a.o_bs % 8) != 0) return 0;
   if (a.seq_off || a.kv_idx || a.B != a.Bkv || a.drop.thr16) return 0;
   const long chunks = (a.Lq + LP_ROWS - 1) / LP_ROWS;
@@ -1855,8 +1855,8 @@ static int attn_bwd_one_pass_long(const AttnArgs& a) {
 // with these arguments runs in one pass
 extern "C" int x2_attn_bwd_one_pass(const AttnArgs* pa) {
   AttnArgs a = *pa; a.phase = 0;
-  const int f = attn_bwd_one_pass(a);
-  return f ? f : attn_bwd_one_pass_long(a);
+  if (const int f = attn_bwd_one_pass(a)) return f;
+  return attn_bwd_one_pass_long(a);
 }
 
 extern "C" int x2_attn_bwd(const AttnArgs* pa, void* stream) {
@@ -1892,6 +1892,9 @@ extern "C" int x2_attn_bwd(const AttnArgs* pa, void* stream) {
   if (a.phase == 2) { /* the dQ half ran in an earlier call */ }
   else if (a.seq_off && a.Lk <= 256 && !a.bias && !a.dS)      // rows sharing K/V: one workgroup per (K/V batch, head)
     hipLaunchKernelGGL((attn_bwd_dq_grouped_kernel<8>), dim3(1, a.H, a.Bkv), dim3(512), 0, st, a);
+  // (the 30-token self-attentions stay two launches: dQ and dK / dV fused into one two-wave workgroup per (sequence, head) - Q / dO / K staged once,
+  // no Delta round trip - measured 22.80 vs 22.70 ms per base step, profiles/r12e_attn_short_fused_ab.txt: these launches are a load -> multiply ->
+  // store chain per workgroup, and one workgroup doing both halves is that chain twice as long on half as many workgroups.  Removed.)
   else if (a.Lq <= 32 && a.Lk <= 64) hipLaunchKernelGGL((attn_bwd_dq_kernel<2, 1, true, 1>), dim3(1, a.H, a.B), dim3(128), 0, st, a);
   else if (a.Lq <= 32) hipLaunchKernelGGL((attn_bwd_dq_kernel<2, 1, false>), dim3(1, a.H, a.B), dim3(128), 0, st, a);
   else if (a.Lk > 256 && a.Lq > 64)      // N = 577: dQ + dK/dV 810 -> 652 us with 8-wave workgroups

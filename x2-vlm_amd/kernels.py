@@ -277,9 +277,9 @@ def attn_fwd(q, k, v, B, Bkv, H, Lq, Lk, scale, out, lse, **kw):
     call("x2_attn_fwd", C.byref(a))
 
 
-def attn_bwd_form(Lq, Lk, shared_kv=False, dropout=False):
+def attn_bwd_form(Lq, Lk, shared_kv=False, dropout=False, workspace=False):
     """Which backward x2_attn_bwd runs for this geometry (x2_attn_bwd_one_pass on an argument block with placeholder pointers - the
-    library reads sizes, strides and which pointers are null): 0 two kernels, 1 / 2 one pass.  For callers that decide BEFORE the
+    library reads sizes, strides and which pointers are null): 0 two kernels, 1 / 2 / 3 one pass.  For callers that decide BEFORE the
     backward whether a second stream has anything to do (engine.BertLayersFn.forward: the K/V projections ahead of the layers)."""
     a = AttnArgs()
     a.B = a.Bkv = a.H = 1
@@ -289,6 +289,8 @@ def attn_bwd_form(Lq, Lk, shared_kv=False, dropout=False):
     if shared_kv:
         a.kv_idx = a.seq_off = a.seq_ids = 8        # non-null, never dereferenced by the query
     a.drop_thr16 = 1 if dropout else 0
+    if workspace:                                  # as attn_bwd hands one over for long self-attention (form 3)
+        a.ws, a.ws_floats = 8, ((Lq + 127) // 128) * 8192
     return _lib.lib().x2_attn_bwd_one_pass(C.byref(a))
 
 
