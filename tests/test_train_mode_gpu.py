@@ -264,4 +264,5 @@ def test_whole_model_train_mode_matches_oracle_with_same_masks(synthetic):
         err = float((g.cpu().double() - r.double()).norm()) / max(float(r.double().norm()), 1e-2 * tot)
         worst = max(worst, (n, err), key=lambda t: t[1])
         assert err < 5e-2, (n, err)
-    print("whole-model train mode: losses", {k: (round(float(loss[k]), 5), round(float(ref[k]), 5)) for k in ref}, "worst grad", worst)
+    print("whole-model train mode: losses", {k: (round(float(loss[k]), 5), round(float(ref[k]), 5)) for k in ref}, "worst grad", worst,
+          "total norm err %.3e" % (abs(gn - tot) / tot))
