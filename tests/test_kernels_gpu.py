@@ -729,6 +729,22 @@ def test_embed_gather_linear_l2norm(K):
     K.embed_bwd(ids.to(dev), g.to(dev), dword, dpos, dtyp)
     rw = torch.zeros(V, D).index_add_(0, ids.reshape(-1), g)
     assert relerr(dword, rw) < 1e-5 and relerr(dpos[:L], g.view(Bn, L, D).sum(0)) < 1e-5 and relerr(dtyp[0], g.sum(0)) < 1e-5
+    # the step's shapes: 7680 token rows of a region batch with [CLS] / [SEP] / [MASK]-like ids on hundreds of rows (the row list of a leader is walked by four
+    # row lanes, eight rows in flight each, combined in a fixed order: same bits every time), more rows than one 8192-row bitmap pass, D = 1024 and a D
+    # that needs a second round of columns
+    for Rr, Lr, Dr, Vr in ((7680, 30, 768, 3000), (9000, 30, 128, 50), (640, 32, 1024, 40), (96, 8, 1536, 7)):
+        g_ = torch.Generator().manual_seed(Rr)
+        idr = torch.randint(0, Vr, (Rr // Lr, Lr), generator=g_)
+        idr[:, 0] = 1; idr[:, -1] = 2; idr[torch.rand(Rr // Lr, Lr, generator=g_) < 0.3] = 3
+        gr = torch.randn(Rr, Dr, generator=g_)
+        outs = []
+        for _ in range(2):
+            dw, dp, dt = torch.zeros(Vr, Dr, device=dev), torch.zeros(Lr, Dr, device=dev), torch.zeros(2, Dr, device=dev)
+            K.embed_bwd(idr.to(dev), gr.to(dev), dw, dp, dt)
+            outs.append((dw, dp, dt))
+        assert relerr(outs[0][0], torch.zeros(Vr, Dr).index_add_(0, idr.reshape(-1), gr)) < 2e-6
+        assert relerr(outs[0][1], gr.view(-1, Lr, Dr).sum(0)) < 2e-6 and relerr(outs[0][2][0], gr.sum(0)) < 1e-5
+        assert all(torch.equal(a_, b_) for a_, b_ in zip(outs[0], outs[1]))
     src = rnd(6, 40, seed=6); idx = torch.tensor([3, 3, 0, 5], dtype=torch.int32)
     d32, d16 = K.gather_rows(src.to(dev), idx.to(dev), 40, want_bf16=True)
     assert torch.equal(d32.cpu(), src[idx.long()]) and torch.equal(d16.cpu(), bf(src[idx.long()]))

@@ -33,45 +33,81 @@ extern "C" int x2_embed_fwd(const long* ids, const float* word, const float* pos
 //     depended on the order those adds arrived in);
 //   position rows: one thread per (position, 4 columns) walks the batch; the per-position totals go to a small scratch row and
 //   type-0 row: one thread per 4 columns adds the L totals in ascending position.
-__global__ __launch_bounds__(256) void embed_bwd_word_kernel(const long* __restrict__ ids, const float* __restrict__ g, float* dword, int R,
-                                                             int D) {
+// (round 6, second form: the first one added a leader's rows one after the other - [MASK] is on ~600 rows of a base batch, ~1200 of a region
+// batch: a chain of that many dependent row loads, 220 / 900 us.  Now the marked rows become a LIST in LDS, four row lanes of 256 threads walk it
+// interleaved, eight rows in flight each; lane partials and the eight accumulators are combined in a fixed order: still no atomics, same bits
+// on every run, 32 rows in flight instead of one.)
+__global__ __launch_bounds__(1024) void embed_bwd_word_kernel(const long* __restrict__ ids, const float* __restrict__ g, float* dword, int R,
+                                                              int D) {
   __shared__ uint32_t bm[SCATTER_MAX_R_E / 32];
-  const int r = blockIdx.x;
+  __shared__ uint16_t lst[SCATTER_MAX_R_E];
+  __shared__ int woff[SCATTER_MAX_R_E / 32 + 1];
+  __shared__ float4 part[3][256];
+  const int r = blockIdx.x, tid = threadIdx.x, rl = tid >> 8, t = tid & 255;
   const long id = ids[r];
-  float4 acc[4];                                       // D <= 4096: 4 float4 per thread
+  for (int c0 = 0; c0 < D / 4; c0 += 256) {            // 1024 columns per round (D = 768 / 1024: one round)
+    const int col = c0 + t;
+    float4 tot{0.f, 0.f, 0.f, 0.f};
+    for (int r0 = 0; r0 < R; r0 += SCATTER_MAX_R_E) {
+      const int rn = min(SCATTER_MAX_R_E, R - r0), nw = (rn + 31) >> 5;
+      __syncthreads();
+      for (int w = tid; w < nw; w += 1024) bm[w] = 0u;
+      __syncthreads();
+      for (int q = tid; q < rn; q += 1024)
+        if (ids[r0 + q] == id) atomicOr(&bm[q >> 5], 1u << (q & 31));
+      __syncthreads();
+      // exclusive prefix of the word populations (nw <= 256): Hillis-Steele over woff[1 .. nw]
+      if (tid < 256) woff[tid + 1] = tid < nw ? __popc(bm[tid]) : 0;
+      if (tid == 0) woff[0] = 0;
+      __syncthreads();
+      for (int st = 1; st < 256; st <<= 1) {
+        int v = 0;
+        if (tid < 256 && tid >= st) v = woff[tid + 1 - st];
+        __syncthreads();
+        if (tid < 256 && tid >= st) woff[tid + 1] += v;
+        __syncthreads();
+      }
+      if (tid < nw) {
+        uint32_t bits = bm[tid];
+        int o = woff[tid];
+        while (bits) { lst[o++] = (uint16_t)((tid << 5) + __builtin_ctz(bits)); bits &= bits - 1; }
+      }
+      __syncthreads();
+      const int n = woff[256];
+      if (n == 0) continue;
+      if (r0 + (int)lst[0] < r) return;                  // an earlier row carries this id: that row's workgroup does the sum (block-uniform)
+      if (col < D / 4) {
+        float4 acc[8];
 #pragma unroll
-  for (int c = 0; c < 4; ++c) acc[c] = float4{0.f, 0.f, 0.f, 0.f};
-  bool leader = true;
-  for (int r0 = 0; r0 < R && leader; r0 += SCATTER_MAX_R_E) {
-    const int rn = min(SCATTER_MAX_R_E, R - r0), nw = (rn + 31) >> 5;
-    __syncthreads();
-    for (int w = threadIdx.x; w < nw; w += 256) bm[w] = 0u;
-    __syncthreads();
-    for (int q = threadIdx.x; q < rn; q += 256)
-      if (ids[r0 + q] == id) atomicOr(&bm[q >> 5], 1u << (q & 31));
-    __syncthreads();
-    for (int w = 0; w < nw && leader; ++w) {
-      uint32_t bits = bm[w];
-      while (bits) {
-        const int q = r0 + (w << 5) + __builtin_ctz(bits);
-        bits &= bits - 1;
-        if (q < r) { leader = false; break; }          // an earlier row carries this id: that row's workgroup does the sum
+        for (int j = 0; j < 8; ++j) acc[j] = float4{0.f, 0.f, 0.f, 0.f};
+        for (int i = rl; i < n; i += 32) {               // row lane rl: list entries rl, rl + 4, ...; eight of them per trip
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const int d = (c * 256 + threadIdx.x) * 4;
-          if (d < D) { const float4 v = *reinterpret_cast<const float4*>(g + (long)q * D + d); acc[c].x += v.x; acc[c].y += v.y; acc[c].z += v.z; acc[c].w += v.w; }
+          for (int j = 0; j < 8; ++j) {
+            const int e = i + 4 * j;
+            if (e < n) {
+              const float4 v = *reinterpret_cast<const float4*>(g + (long)(r0 + lst[e]) * D + col * 4);
+              acc[j].x += v.x; acc[j].y += v.y; acc[j].z += v.z; acc[j].w += v.w;
+            }
+          }
         }
+        float4 p;
+        p.x = ((acc[0].x + acc[1].x) + (acc[2].x + acc[3].x)) + ((acc[4].x + acc[5].x) + (acc[6].x + acc[7].x));
+        p.y = ((acc[0].y + acc[1].y) + (acc[2].y + acc[3].y)) + ((acc[4].y + acc[5].y) + (acc[6].y + acc[7].y));
+        p.z = ((acc[0].z + acc[1].z) + (acc[2].z + acc[3].z)) + ((acc[4].z + acc[5].z) + (acc[6].z + acc[7].z));
+        p.w = ((acc[0].w + acc[1].w) + (acc[2].w + acc[3].w)) + ((acc[4].w + acc[5].w) + (acc[6].w + acc[7].w));
+        if (rl > 0) part[rl - 1][t] = p;
+        else tot.x += p.x, tot.y += p.y, tot.z += p.z, tot.w += p.w;
+      }
+      __syncthreads();
+      if (rl == 0 && col < D / 4) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { const float4 v = part[k][t]; tot.x += v.x; tot.y += v.y; tot.z += v.z; tot.w += v.w; }
       }
     }
-  }
-  if (!leader) return;
-#pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    const int d = (c * 256 + threadIdx.x) * 4;
-    if (d < D) {
-      float4* w = reinterpret_cast<float4*>(dword + id * D + d);
+    if (rl == 0 && col < D / 4) {
+      float4* w = reinterpret_cast<float4*>(dword + id * D + col * 4);
       float4 o = *w;
-      o.x += acc[c].x; o.y += acc[c].y; o.z += acc[c].z; o.w += acc[c].w;
+      o.x += tot.x; o.y += tot.y; o.z += tot.z; o.w += tot.w;
       *w = o;
     }
   }
@@ -101,7 +137,7 @@ __global__ __launch_bounds__(64) void embed_bwd_type_kernel(const float* __restr
 extern "C" int x2_embed_bwd(const long* ids, const float* g, float* dword, float* dpos, float* dtype0, int R, int L, int D, float* scratch,
                             void* stream) {
   X2_REQUIRE(R > 0 && L > 0 && D % 4 == 0 && D <= 4096 && scratch, "x2_embed_bwd: R=%d L=%d D=%d (D <= 4096, scratch of min(L, R) * D floats)", R, L, D);
-  hipLaunchKernelGGL(embed_bwd_word_kernel, dim3(R), dim3(256), 0, (hipStream_t)stream, ids, g, dword, R, D);
+  hipLaunchKernelGGL(embed_bwd_word_kernel, dim3(R), dim3(1024), 0, (hipStream_t)stream, ids, g, dword, R, D);
   const int Lp = L < R ? L : R;
   hipLaunchKernelGGL(embed_bwd_pos_kernel, dim3(Lp, (D / 4 + 255) / 256), dim3(256), 0, (hipStream_t)stream, g, dpos, scratch, R, L, D);
   hipLaunchKernelGGL(embed_bwd_type_kernel, dim3((D / 4 + 63) / 64), dim3(64), 0, (hipStream_t)stream, scratch, dtype0, Lp, D);
