@@ -245,12 +245,12 @@ class SegmentedStep:
                 img = batch["image"]
                 nimg = img.shape[0] * (img.shape[1] if img.dim() == 5 else 1)
                 text_rows = 4 * batch["text_ids"].shape[0] * batch["text_ids"].shape[1]
-                # Round 6 (profiles/r12h_vision_cut_ab.txt): with the masking kernel in T and the fixed-order reductions on stream B that stream became
-                # the longer one again (B ended 0.6 ms after A): only the top SIXTH's weight gradients go there now (base: cut at block 10 of 12,
-                # 21.84 vs 22.01 ms); X2VLM-large, whose attention backward is one kernel as well since the long one-pass form (208 < N <= 640),
-                # is cut at 1/2 and 3/4 (69.04 vs 69.62 ms with thirds)
+                # Round 6 (profiles/r12h_vision_cut_ab.txt): the balance of the two streams is within 0.1 ms of a block's weight gradients - with the first
+                # fixed-order embedding backward (270 us on stream B) a cut at block 10 of 12 won by 0.17 ms, with its second form (85 us) 3/4 wins
+                # again by 0.08 ms: 3/4 stays.  X2VLM-large, whose attention backward is one kernel as well since the long one-pass form
+                # (208 < N <= 640), is cut at 1/2 and 3/4 (69.04 vs 69.62 ms with thirds)
                 if 64 < ntok <= 208 and 2 * text_rows >= nimg * ntok:
-                    vision_cuts = [depth * 5 // 6]
+                    vision_cuts = [depth * 3 // 4]
                 elif 208 < ntok <= 640 and img.dim() == 4:
                     vision_cuts = [depth // 2, depth * 3 // 4]
         self.vcuts = sorted(c for c in vision_cuts if 0 < c < depth)
