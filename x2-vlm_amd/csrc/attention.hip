@@ -9,7 +9,9 @@
 // the online softmax in registers, packs P straight into the next MFMA's operand, and reads V
 // (and K^T, Q^T, dO^T in the backward) with the transposing LDS read ds_read_b64_tr_b16.
 // Backward = two kernels (no atomics, deterministic): dQ (+ the dS stream the bias gradient is
-// reduced from) and dK/dV.
+// reduced from) and dK/dV - or ONE kernel where a (sequence, head) can be walked by one workgroup:
+// attn_bwd_onepass_kernel (N <= 208), attn_bwd_onepass_grouped_kernel (text rows sharing an image's
+// K/V), attn_bwd_onepass_long_kernel (208 < N <= 640: X2VLM-large); x2_attn_bwd picks.
 #include "x2_common.h"
 #include <cstdlib>
 extern "C" int x2_tune_get(int key);
@@ -1521,7 +1523,8 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_onepass_grouped_kernel(AttnAr
 }
 
 // ------------------------------------------------------------------------------------------ backward in one pass, long sequences
-// Self-attention with 208 < Lq <= 640, 208 < Lk <= 768 and no K/V sharing (the BEiT-2 blocks of X2VLM-large at 384 px: N = 577): a
+// Self-attention with 208 < Lq <= 640, 208 < Lk <= 768 and no K/V sharing (the BEiT-2 blocks of X2VLM-large at 384 px: N = 577; the
+// autograd backward of /root/reference/models/beit2.py:135-159 - q * scale, QK^T + relative_position_bias, softmax, PV): a
 // (sequence, head) no longer fits a workgroup's registers + LDS at once, so ONE eight-wave workgroup per (sequence, head) walks it as
 //   for every key PART (256 keys = 16 strips, two per wave: K / V fragments in registers, dK / dV accumulators, K rows in LDS)
 //     for every query CHUNK (128 queries = 8 strips: Q / dO staged into LDS, Delta recomputed from dO . O on the way)
