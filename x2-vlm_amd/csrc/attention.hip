@@ -1823,9 +1823,8 @@ extern "C" int x2_attn_fwd(const AttnArgs* pa, void* stream) {
   if (a.Lq <= 32 && a.Lk <= 64) hipLaunchKernelGGL((attn_fwd_kernel<2, 1, true, 1>), dim3(1, a.H, a.B), dim3(128), 0, st, a);
   else if (a.Lq <= 32) hipLaunchKernelGGL((attn_fwd_kernel<2, 1, false>), dim3(1, a.H, a.B), dim3(128), 0, st, a);
   else if (a.Lk > 256 && a.Lq > 64)      // long sequences (X2VLM-large, N = 577): 8 waves share each streamed K/V tile (285 -> 254 us)
-    { if (bl2 && x2_tune_get(14) == 4) attn_launch(attn_fwd_kernel<4, 2, false, 2, 2, true>, a, (a.Lq + 127) / 128, a.H, a.B, 256, xm, st);
-      else if (bl2 && x2_tune_get(14) == 5) attn_launch(attn_fwd_kernel<8, 2, false, 2, 2, true>, a, (a.Lq + 255) / 256, a.H, a.B, 512, xm, st);
-      else if (bl2) attn_launch(attn_fwd_kernel<8, 1, false, 2, 4, true>, a, (a.Lq + 127) / 128, a.H, a.B, 512, xm, st);
+    // (two query strips per wave sharing the K / V fragment reads - <4, 2> and <8, 2> at two waves per SIMD - measured 176-190 and 215-231 us against 160-170, round 6)
+    { if (bl2) attn_launch(attn_fwd_kernel<8, 1, false, 2, 4, true>, a, (a.Lq + 127) / 128, a.H, a.B, 512, xm, st);
       else attn_launch(attn_fwd_kernel<8, 1, false>, a, (a.Lq + 127) / 128, a.H, a.B, 512, xm, st); }
   else if (a.Lq <= 64 || a.Lk > 256) hipLaunchKernelGGL((attn_fwd_kernel<4, 1, false>), dim3((a.Lq + 63) / 64, a.H, a.B), dim3(256), 0, st, a);
   else if (!a.kv_idx && a.Lk <= WALK_ROWS)      // staged: one strip-walking workgroup per (sequence, head)
