@@ -180,7 +180,7 @@ def with_collectives(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--steps", type=int, default=50)          # >= 50 timed steps
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", choices=sorted(CONFIGS), default="base",
                     help="base = the headline metric (BASELINE.json configs[1]); large / video = configs[3] / [4] on one GPU")
