@@ -25,7 +25,7 @@ extern "C" {
 #endif
 
 const char* x2_last_error(void);
-int x2_abi_version(void);          /* == 13 */
+int x2_abi_version(void);          /* == 14 */
 int x2_device_cus(void);           /* compute units of the current HIP device, 0 if none */
 int x2_tune(int key, int value);   /* kernel-variant knobs for probes/ and tests (0 = automatic); keys listed in csrc/gemm.hip.
                                     * key 12 = compute units every tile plan leaves to RCCL's channel kernels (world > 1);
@@ -113,6 +113,10 @@ typedef struct X2AttnArgs {
                                                         (reads the Delta a phase-1 call wrote): the K/V-side gradients on another stream */
   float* ws; long ws_floats;                         /* x2_attn_bwd (ABI v13): fp32 scratch of B * H * ceil(Lq / 128) * 8192 floats for the long one-pass
                                                         backward (form 3 below), or NULL / smaller: such a geometry runs the two kernels */
+  float* colsum_ws;                                  /* x2_attn_bwd (ABI v14), honoured by form 1 only (ask x2_attn_bwd_one_pass), or NULL: [B][2][H*64] fp32,
+                                                        per sequence the column sums of the stored dQ (k = 0) and dV (k = 1) rows - summed over B
+                                                        (x2_reduce_partials, nblk = B, nk = 2) they are the q / v bias gradient of the fused qkv
+                                                        projection (beit2.py:129-131: qkv_bias = cat(q_bias, 0, v_bias)) without a pass over [M, 3D] */
 } X2AttnArgs;
 int x2_attn_fwd(const X2AttnArgs* args, void* stream);
 int x2_attn_bwd(const X2AttnArgs* args, void* stream);   /* dQ (+dS, Delta) then dK/dV; no atomics */

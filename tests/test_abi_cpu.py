@@ -29,15 +29,15 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(h, name), "include/x2vlm_hip.h declares %s but libx2vlm_hip.so does not export it" % name
     assert sorted(lib.EXPORTS) == declared, set(lib.EXPORTS) ^ set(declared)
-    assert lib.lib().x2_abi_version() == 13
+    assert lib.lib().x2_abi_version() == 14
 
 
 def test_attn_args_struct_matches_header_layout():
     lib = importlib.import_module("x2-vlm_amd._lib")
     # 12 pointers + 16 longs + 5 ints + float + 3 x (pointer, int, pad) + 3 pointers + int (+pad)
     # ds_ld, 3 dropout words, dbg, head_dim, epoch pointer, 4 library-owned grid words, phase (+pad)
-    assert ctypes.sizeof(lib.AttnArgs) == 12 * 8 + 16 * 8 + 6 * 4 + 3 * 16 + 3 * 8 + 24 + 8 + 16 + 8 + 16
-    assert lib.AttnArgs.ws.offset == 376 and lib.AttnArgs.ws_floats.offset == 384
+    assert ctypes.sizeof(lib.AttnArgs) == 12 * 8 + 16 * 8 + 6 * 4 + 3 * 16 + 3 * 8 + 24 + 8 + 16 + 8 + 16 + 8
+    assert lib.AttnArgs.ws.offset == 376 and lib.AttnArgs.ws_floats.offset == 384 and lib.AttnArgs.colsum_ws.offset == 392
     assert lib.AttnArgs.grid_nx.offset == 352 and lib.AttnArgs.grid_map.offset == 364 and lib.AttnArgs.phase.offset == 368
     assert lib.AttnArgs.bias.offset == 248 and lib.AttnArgs.kv_idx.offset == 296 and lib.AttnArgs.ds_ld.offset == 320
     assert lib.AttnArgs.drop_thr16.offset == 324 and lib.AttnArgs.dbg.offset == 336 and lib.AttnArgs.head_dim.offset == 340 and lib.AttnArgs.drop_epoch.offset == 344

@@ -26,7 +26,7 @@ class AttnArgs(C.Structure):
                 ("kv_idx", P), ("seq_off", P), ("seq_ids", P), ("ds_ld", I),
                 ("drop_thr16", C.c_uint), ("drop_seed", C.c_uint), ("drop_scale", F), ("dbg", I), ("head_dim", I), ("drop_epoch", P),
                 ("grid_nx", I), ("grid_ny", I), ("grid_nz", I), ("grid_map", I),                     # filled by the library: leave zero
-                ("phase", I), ("ws", P), ("ws_floats", L)]
+                ("phase", I), ("ws", P), ("ws_floats", L), ("colsum_ws", P)]
 
 
 # name -> argtypes (all return int: 0 ok, < 0 error; message via x2_last_error)

@@ -55,6 +55,9 @@ struct AttnArgs {
                                        // phase-1 call left it): lets a caller put the K/V-side gradients on another stream
   float* ws; long ws_floats;           // x2_attn_bwd: fp32 scratch for attn_bwd_onepass_long_kernel's dQ partials (B * H * ceil(Lq / 128) * 8192 floats),
                                        // or NULL / too small: the dQ + dK/dV pair runs instead
+  float* colsum_ws;                    // x2_attn_bwd, form 1 only (attn_bwd_onepass_kernel), or NULL: [B][2][H * 64] fp32 partial column sums over a sequence's
+                                       // rows of the STORED (bf16) dQ (k = 0) and dV (k = 1): the q / v bias gradient of a fused qkv projection is their sum
+                                       // over B (x2_reduce_partials with nblk = B, nk = 2) - no pass over the [M, 3D] gradient
 };
 
 // Workgroup -> (tile, head, batch).  grid_map == 0: the 3-D grid as launched.  grid_map = C > 0 (the kernels with a relative-
@@ -1050,7 +1053,15 @@ __global__ __launch_bounds__(64 * KW, WPS) void attn_bwd_dkv_kernel(AttnArgs a) 
 #define OP_Z2 (OP_DS + OP_NBLK * OP_BLK)
 #define OP_LSE (OP_Z2 + 16 * 32)
 #define OP_DEL (OP_LSE + OP_ROWS * 4)
-#define OP_BYTES (OP_DEL + OP_ROWS * 4)
+#define OP_CS (OP_DEL + OP_ROWS * 4)          // [2 kinds: dQ, dV][8 waves][64 d] fp32 column sums of the wave's rows (colsum_ws)
+#define OP_BYTES (OP_CS + 2 * 8 * 64 * 4)
+// column sums over the 16 lanes that share g (rows fi = 0 .. 15 of a strip): afterwards lane fi == 0 of every g holds the 16 sums of its d = dt * 16 + 4 g + r
+__device__ __forceinline__ void strip_colsum16(float (&v)[16]) {
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    v[i] += __shfl_xor(v[i], 1, 64); v[i] += __shfl_xor(v[i], 2, 64); v[i] += __shfl_xor(v[i], 4, 64); v[i] += __shfl_xor(v[i], 8, 64);
+  }
+}
 template <bool BL2>
 __global__ __launch_bounds__(512, 2) void attn_bwd_onepass_kernel(AttnArgs a) {
   __shared__ __attribute__((aligned(16))) char smem[OP_BYTES];
@@ -1213,6 +1224,9 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_onepass_kernel(AttnArgs a) {
     };
     for (int s = 0; s < (nsq >> 1); ++s) pair(s, std::true_type{});
     if (nsq & 1) pair(nsq >> 1, std::false_type{});
+    float vs[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) vs[i] = 0.f;
 #pragma unroll
     for (int gk = 0; gk < NG; ++gk) {
       if (!kok[gk]) continue;
@@ -1222,11 +1236,27 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_onepass_kernel(AttnArgs a) {
       for (int dt = 0; dt < 4; ++dt) {
         *reinterpret_cast<u32x2*>(kp + dt * 16) = u32x2{pack_bf16(dk[gk][dt][0] * a.scale, dk[gk][dt][1] * a.scale),
                                                          pack_bf16(dk[gk][dt][2] * a.scale, dk[gk][dt][3] * a.scale)};
-        *reinterpret_cast<u32x2*>(vp + dt * 16) = u32x2{pack_bf16(dv[gk][dt][0], dv[gk][dt][1]), pack_bf16(dv[gk][dt][2], dv[gk][dt][3])};
+        const u32x2 wv = u32x2{pack_bf16(dv[gk][dt][0], dv[gk][dt][1]), pack_bf16(dv[gk][dt][2], dv[gk][dt][3])};
+        *reinterpret_cast<u32x2*>(vp + dt * 16) = wv;
+        vs[dt * 4 + 0] += bf_lo(wv[0]); vs[dt * 4 + 1] += bf_hi(wv[0]); vs[dt * 4 + 2] += bf_lo(wv[1]); vs[dt * 4 + 3] += bf_hi(wv[1]);
+      }
+    }
+    if (a.colsum_ws) {                 // this wave's share of colsum(dV): keys past Lk added nothing (skipped above)
+      strip_colsum16(vs);
+      if (fi == 0) {
+        float* cs = reinterpret_cast<float*>(smem + OP_CS) + (8 + wave) * 64;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) cs[dt * 16 + g * 4 + r] = vs[dt * 4 + r];
       }
     }
   };
   const int ng = wave + 8 < nsk ? 2 : (wave < nsk ? 1 : 0);
+  if (a.colsum_ws && lane < 64) {      // zero this wave's slots first: waves without key / query strips contribute zeros
+    float* cs = reinterpret_cast<float*>(smem + OP_CS);
+    cs[wave * 64 + lane] = 0.f; cs[(8 + wave) * 64 + lane] = 0.f;
+  }
   if (ng == 2) phase_a(std::integral_constant<int, 2>{});
   else if (ng == 1) phase_a(std::integral_constant<int, 1>{});
   __syncthreads();                     // every wave is done with Q
@@ -1274,19 +1304,45 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_onepass_kernel(AttnArgs a) {
         for (int j = 0; j < NQ; ++j) dq[j][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktr, dsf[j], dq[j][dt], 0, 0, 0);
       }
     }
+    float qs[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) qs[i] = 0.f;
 #pragma unroll
     for (int j = 0; j < NQ; ++j) {
       const int q = (wave + 8 * j) * 16 + fi;
       if (q >= a.Lq) continue;
       bf16_t* op = a.dQ + b * a.dq_bs + (long)q * a.dq_rs + h * HD + g * 4;
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt)
-        *reinterpret_cast<u32x2*>(op + dt * 16) = u32x2{pack_bf16(dq[j][dt][0] * a.scale, dq[j][dt][1] * a.scale),
-                                                         pack_bf16(dq[j][dt][2] * a.scale, dq[j][dt][3] * a.scale)};
+      for (int dt = 0; dt < 4; ++dt) {
+        const u32x2 wq = u32x2{pack_bf16(dq[j][dt][0] * a.scale, dq[j][dt][1] * a.scale), pack_bf16(dq[j][dt][2] * a.scale, dq[j][dt][3] * a.scale)};
+        *reinterpret_cast<u32x2*>(op + dt * 16) = wq;
+        qs[dt * 4 + 0] += bf_lo(wq[0]); qs[dt * 4 + 1] += bf_hi(wq[0]); qs[dt * 4 + 2] += bf_lo(wq[1]); qs[dt * 4 + 3] += bf_hi(wq[1]);
+      }
+    }
+    if (a.colsum_ws) {
+      strip_colsum16(qs);
+      if (fi == 0) {
+        float* cs = reinterpret_cast<float*>(smem + OP_CS) + wave * 64;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) cs[dt * 16 + g * 4 + r] = qs[dt * 4 + r];
+      }
     }
   };
   if (wave + 8 < nsq) phase_b(std::integral_constant<int, 2>{});
   else if (wave < nsq) phase_b(std::integral_constant<int, 1>{});
+  if (a.colsum_ws) {                   // (block-uniform) the eight waves' sums in wave order -> this (sequence, head)'s 2 x 64 partial columns
+    __syncthreads();
+    if (tid < 128) {
+      const int kind = tid >> 6, d = tid & 63;
+      const float* cs = reinterpret_cast<const float*>(smem + OP_CS) + kind * 8 * 64 + d;
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) t += cs[w * 64];
+      a.colsum_ws[((long)b * 2 + kind) * (a.H * HD) + h * HD + d] = t;
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------ backward in one pass, shared K/V

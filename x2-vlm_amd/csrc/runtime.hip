@@ -23,7 +23,7 @@ int x2_check_launch(const char* what) {
 }
 
 extern "C" const char* x2_last_error(void) { return g_err; }
-extern "C" int x2_abi_version(void) { return 13; }
+extern "C" int x2_abi_version(void) { return 14; }
 
 // device-side sanity: number of compute units of the current device (0 when no HIP device is usable)
 extern "C" int x2_device_cus(void) {

@@ -668,16 +668,28 @@ class VisionEncoderFn(torch.autograd.Function):
             # collects (then the dS stream needs a buffer of its own per block), in line otherwise
             po = []
             dS_i = torch.empty_like(dS) if WGRAD_QUEUE is not None else dS
-            K.attn_bwd(K.view3(qkv, B, T, 0), K.view3(qkv, B, T, D), K.view3(qkv, B, T, 2 * D), K.view3(att, B, T),
-                       K.view3(datt, B, T), B, B, H, T, T, scale, lse, delta, K.view3(dqkv, B, T, 0), K.view3(dqkv, B, T, D),
-                       K.view3(dqkv, B, T, 2 * D), dS=dS_i, bias=bias, biasT=biasT, bias_log2=True)
+            # q / v bias gradient: where the backward is one workgroup per (sequence, head) (form 1) it leaves per-sequence column sums of dQ / dV
+            # (round 6: no pass over the [M, 3D] gradient - 58 MB per block); their sum over B joins the layer's stage-2 reductions
+            cs = torch.empty(B, 2, D, device=qkv.device, dtype=F32) if os.environ.get("X2_FUSE_QKV_BIAS_COLSUM", "1") == "1" else None   # (=0: A/B)
+            form = K.attn_bwd(K.view3(qkv, B, T, 0), K.view3(qkv, B, T, D), K.view3(qkv, B, T, 2 * D), K.view3(att, B, T),
+                              K.view3(datt, B, T), B, B, H, T, T, scale, lse, delta, K.view3(dqkv, B, T, 0), K.view3(dqkv, B, T, D),
+                              K.view3(dqkv, B, T, 2 * D), dS=dS_i, bias=bias, biasT=biasT, bias_log2=True, colsum_ws=cs)
+            fused_cs = cs is not None and form == 1
+            if fused_cs:
+                item = (cs, B, 2, D, (G["qkv_bias"][:D], G["qkv_bias"][2 * D:]))
+                if K.DEFERRED is not None:
+                    K.DEFERRED.append(item)
+                else:
+                    K.reduce_partials(*item)
             if WGRAD_QUEUE is not None:
                 tbl_a, qb_a = G["attn.relative_position_bias_table"].detach(), G["qkv_bias"].detach()
                 po.append(lambda dS_i=dS_i, tbl_a=tbl_a: K.relpos_bias_bwd(dS_i, meta["rel_index"], tbl_a))
-                po.append(lambda dqkv=dqkv, qb_a=qb_a: K.colsum_bf16(dqkv, qb_a))
+                if not fused_cs:
+                    po.append(lambda dqkv=dqkv, qb_a=qb_a: K.colsum_bf16(dqkv, qb_a))
             else:
                 K.relpos_bias_bwd(dS_i, meta["rel_index"], G["attn.relative_position_bias_table"])
-                K.colsum_bf16(dqkv, G["qkv_bias"])
+                if not fused_cs:
+                    K.colsum_bf16(dqkv, G["qkv_bias"])
             G.alias("attn.q_bias", G["qkv_bias"][:D])
             G.alias("attn.v_bias", G["qkv_bias"][2 * D:])
             dh1 = K.gemm_nt(dqkv, wqkvT)

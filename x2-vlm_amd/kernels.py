@@ -294,7 +294,7 @@ def attn_bwd_form(Lq, Lk, shared_kv=False, dropout=False, workspace=False):
     return _lib.lib().x2_attn_bwd_one_pass(C.byref(a))
 
 
-def attn_bwd(q, k, v, o, do, B, Bkv, H, Lq, Lk, scale, lse, delta, dq, dk, dv, dS=None, phase=0, ask_form=False, **kw):
+def attn_bwd(q, k, v, o, do, B, Bkv, H, Lq, Lk, scale, lse, delta, dq, dk, dv, dS=None, phase=0, ask_form=False, colsum_ws=None, **kw):
     """phase: 0 both halves; 1 the dQ half (+ dS, delta); 2 the dK / dV half (needs the delta of a phase-1 call).
     ask_form: launch nothing, return which backward a phase-0 call with these arguments runs (x2_attn_bwd_one_pass: 0 = the two
     kernels, 1 / 2 = one pass) - a caller that would put the dK / dV half on a second stream has nothing to put there in one pass."""
@@ -316,6 +316,15 @@ def attn_bwd(q, k, v, o, do, B, Bkv, H, Lq, Lk, scale, lse, delta, dq, dk, dv, d
         a.ws, a.ws_floats = ws.data_ptr(), ws.numel()
     if ask_form:
         return _lib.lib().x2_attn_bwd_one_pass(C.byref(a))
+    if colsum_ws is not None:
+        # fp32 [B, 2, H * 64]: the one-pass kernel of form 1 leaves per-sequence column sums of the stored dQ / dV rows there (the q / v bias gradient of a
+        # fused qkv projection after a sum over B); returns the form that ran - any other form has NOT written the buffer
+        assert colsum_ws.dtype == F32 and colsum_ws.is_contiguous() and colsum_ws.shape == (B, 2, H * 64)
+        form = _lib.lib().x2_attn_bwd_one_pass(C.byref(a))
+        if form == 1:
+            a.colsum_ws = colsum_ws.data_ptr()
+        call("x2_attn_bwd", C.byref(a))
+        return form
     call("x2_attn_bwd", C.byref(a))
 
 
