@@ -113,7 +113,7 @@ typedef struct X2AttnArgs {
                                                         (reads the Delta a phase-1 call wrote): the K/V-side gradients on another stream */
   float* ws; long ws_floats;                         /* x2_attn_bwd (ABI v13): fp32 scratch of B * H * ceil(Lq / 128) * 8192 floats for the long one-pass
                                                         backward (form 3 below), or NULL / smaller: such a geometry runs the two kernels */
-  float* colsum_ws;                                  /* x2_attn_bwd (ABI v14), honoured by form 1 only (ask x2_attn_bwd_one_pass), or NULL: [B][2][H*64] fp32,
+  float* colsum_ws;                                  /* x2_attn_bwd (ABI v14), honoured by forms 1 and 3 only (ask x2_attn_bwd_one_pass), or NULL: [B][2][H*64] fp32,
                                                         per sequence the column sums of the stored dQ (k = 0) and dV (k = 1) rows - summed over B
                                                         (x2_reduce_partials, nblk = B, nk = 2) they are the q / v bias gradient of the fused qkv
                                                         projection (beit2.py:129-131: qkv_bias = cat(q_bias, 0, v_bias)) without a pass over [M, 3D] */

@@ -55,7 +55,7 @@ struct AttnArgs {
                                        // phase-1 call left it): lets a caller put the K/V-side gradients on another stream
   float* ws; long ws_floats;           // x2_attn_bwd: fp32 scratch for attn_bwd_onepass_long_kernel's dQ partials (B * H * ceil(Lq / 128) * 8192 floats),
                                        // or NULL / too small: the dQ + dK/dV pair runs instead
-  float* colsum_ws;                    // x2_attn_bwd, form 1 only (attn_bwd_onepass_kernel), or NULL: [B][2][H * 64] fp32 partial column sums over a sequence's
+  float* colsum_ws;                    // x2_attn_bwd, forms 1 and 3 only (attn_bwd_onepass_kernel, attn_bwd_onepass_long_kernel), or NULL: [B][2][H * 64] fp32 partial column sums over a sequence's
                                        // rows of the STORED (bf16) dQ (k = 0) and dV (k = 1): the q / v bias gradient of a fused qkv projection is their sum
                                        // over B (x2_reduce_partials with nblk = B, nk = 2) - no pass over the [M, 3D] gradient
 };
@@ -1602,7 +1602,8 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_onepass_grouped_kernel(AttnAr
 #define LP_DS (LP_K + LP_KEYS * 128)
 #define LP_LSE (LP_DS + LP_STRIPS * LP_BLK)
 #define LP_DEL (LP_LSE + LP_ROWS * 4)
-#define LP_BYTES (LP_DEL + LP_ROWS * 4)
+#define LP_CS (LP_DEL + LP_ROWS * 4)           // [2 kinds: dQ, dV][8 waves][64 d] fp32 column sums (colsum_ws), accumulated over chunks / parts
+#define LP_BYTES (LP_CS + 2 * 8 * 64 * 4)
 #define LP_MAX_LQ 640
 #define LP_MAX_LK 768
 template <bool BL2>
@@ -1620,6 +1621,9 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_onepass_long_kernel(AttnArgs 
   float* del_s = reinterpret_cast<float*>(smem + LP_DEL);
   float* wsq = a.ws + (((long)b * a.H + h) * nchunk * LP_STRIPS + wave) * 1024 + lane * 4;      // + chunk * 8192 + dt * 256
   const int r4 = fi >> 2, c4 = fi & 3;
+  // column-sum slots of this wave (only this wave touches them until the end); addressed from a scalar wave number where they are used
+#define LP_CS_SLOT(kind) (reinterpret_cast<float*>(smem + LP_CS) + ((kind) * 8 + __builtin_amdgcn_readfirstlane(wave)) * 64)
+  if (a.colsum_ws) { LP_CS_SLOT(0)[lane] = 0.f; LP_CS_SLOT(1)[lane] = 0.f; }
 
   for (int part = 0; part < npart; ++part) {
     const int nkp = min(16, nsk - part * 16);                      // key strips of this part
@@ -1807,16 +1811,35 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_onepass_long_kernel(AttnArgs 
 #pragma unroll
           for (int dt = 0; dt < 4; ++dt)
             *reinterpret_cast<float4*>(wsq + (long)c * (LP_STRIPS * 1024) + dt * 256) = float4{dq[dt][0], dq[dt][1], dq[dt][2], dq[dt][3]};
-        } else if (q < a.Lq) {
-          bf16_t* op = a.dQ + b * a.dq_bs + (long)q * a.dq_rs + h * HD + g * 4;
+        } else {
+          float qs[16];
 #pragma unroll
-          for (int dt = 0; dt < 4; ++dt)
-            *reinterpret_cast<u32x2*>(op + dt * 16) = u32x2{pack_bf16(dq[dt][0] * a.scale, dq[dt][1] * a.scale),
-                                                             pack_bf16(dq[dt][2] * a.scale, dq[dt][3] * a.scale)};
+          for (int i = 0; i < 16; ++i) qs[i] = 0.f;
+          if (q < a.Lq) {
+            bf16_t* op = a.dQ + b * a.dq_bs + (long)q * a.dq_rs + h * HD + g * 4;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+              const u32x2 wq = u32x2{pack_bf16(dq[dt][0] * a.scale, dq[dt][1] * a.scale), pack_bf16(dq[dt][2] * a.scale, dq[dt][3] * a.scale)};
+              *reinterpret_cast<u32x2*>(op + dt * 16) = wq;
+              qs[dt * 4 + 0] = bf_lo(wq[0]); qs[dt * 4 + 1] = bf_hi(wq[0]); qs[dt * 4 + 2] = bf_lo(wq[1]); qs[dt * 4 + 3] = bf_hi(wq[1]);
+            }
+          }
+          if (a.colsum_ws) {           // colsum of the stored dQ: this strip's share onto the wave's slot (chunks in order)
+            strip_colsum16(qs);
+            if (fi == 0) {
+#pragma unroll
+              for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) LP_CS_SLOT(0)[dt * 16 + g * 4 + r] += qs[dt * 4 + r];
+            }
+          }
         }
       }
       __syncthreads();                 // the next chunk overwrites Q / dO / LSE / Delta, its phase A the dS blocks; the next part the K image
     }
+    float vs[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) vs[i] = 0.f;
 #pragma unroll
     for (int gk = 0; gk < 2; ++gk) {
       if (gk >= ng || !kok[gk]) continue;
@@ -1826,8 +1849,30 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_onepass_long_kernel(AttnArgs 
       for (int dt = 0; dt < 4; ++dt) {
         *reinterpret_cast<u32x2*>(kp + dt * 16) = u32x2{pack_bf16(dk[gk][dt][0] * a.scale, dk[gk][dt][1] * a.scale),
                                                          pack_bf16(dk[gk][dt][2] * a.scale, dk[gk][dt][3] * a.scale)};
-        *reinterpret_cast<u32x2*>(vp + dt * 16) = u32x2{pack_bf16(dv[gk][dt][0], dv[gk][dt][1]), pack_bf16(dv[gk][dt][2], dv[gk][dt][3])};
+        const u32x2 wv = u32x2{pack_bf16(dv[gk][dt][0], dv[gk][dt][1]), pack_bf16(dv[gk][dt][2], dv[gk][dt][3])};
+        *reinterpret_cast<u32x2*>(vp + dt * 16) = wv;
+        vs[dt * 4 + 0] += bf_lo(wv[0]); vs[dt * 4 + 1] += bf_hi(wv[0]); vs[dt * 4 + 2] += bf_lo(wv[1]); vs[dt * 4 + 3] += bf_hi(wv[1]);
       }
+    }
+    if (a.colsum_ws) {                 // colsum of the stored dV: this part's share onto the wave's slot (parts in order)
+      strip_colsum16(vs);
+      if (fi == 0) {
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) LP_CS_SLOT(1)[dt * 16 + g * 4 + r] += vs[dt * 4 + r];
+      }
+    }
+  }
+  if (a.colsum_ws) {                   // (block-uniform) the eight waves' sums in wave order: see attn_bwd_onepass_kernel
+    __syncthreads();
+    if (tid < 128) {
+      const int kind = tid >> 6, d = tid & 63;
+      const float* cs = reinterpret_cast<const float*>(smem + LP_CS) + kind * 8 * 64 + d;
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) t += cs[w * 64];
+      a.colsum_ws[((long)b * 2 + kind) * (a.H * HD) + h * HD + d] = t;
     }
   }
 }

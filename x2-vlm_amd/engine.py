@@ -674,7 +674,7 @@ class VisionEncoderFn(torch.autograd.Function):
             form = K.attn_bwd(K.view3(qkv, B, T, 0), K.view3(qkv, B, T, D), K.view3(qkv, B, T, 2 * D), K.view3(att, B, T),
                               K.view3(datt, B, T), B, B, H, T, T, scale, lse, delta, K.view3(dqkv, B, T, 0), K.view3(dqkv, B, T, D),
                               K.view3(dqkv, B, T, 2 * D), dS=dS_i, bias=bias, biasT=biasT, bias_log2=True, colsum_ws=cs)
-            fused_cs = cs is not None and form == 1
+            fused_cs = cs is not None and form in (1, 3)
             if fused_cs:
                 item = (cs, B, 2, D, (G["qkv_bias"][:D], G["qkv_bias"][2 * D:]))
                 if K.DEFERRED is not None:

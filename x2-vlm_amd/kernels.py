@@ -317,11 +317,11 @@ def attn_bwd(q, k, v, o, do, B, Bkv, H, Lq, Lk, scale, lse, delta, dq, dk, dv, d
     if ask_form:
         return _lib.lib().x2_attn_bwd_one_pass(C.byref(a))
     if colsum_ws is not None:
-        # fp32 [B, 2, H * 64]: the one-pass kernel of form 1 leaves per-sequence column sums of the stored dQ / dV rows there (the q / v bias gradient of a
+        # fp32 [B, 2, H * 64]: the one-pass kernels of forms 1 / 3 leave per-sequence column sums of the stored dQ / dV rows there (the q / v bias gradient of a
         # fused qkv projection after a sum over B); returns the form that ran - any other form has NOT written the buffer
         assert colsum_ws.dtype == F32 and colsum_ws.is_contiguous() and colsum_ws.shape == (B, 2, H * 64)
         form = _lib.lib().x2_attn_bwd_one_pass(C.byref(a))
-        if form == 1:
+        if form in (1, 3):
             a.colsum_ws = colsum_ws.data_ptr()
         call("x2_attn_bwd", C.byref(a))
         return form
